@@ -1,0 +1,68 @@
+"""ctypes binding of fastkv_amd/lib/libfastkv_hip.so (C ABI: include/fastkv_hip.h).
+
+The library is the product: there is NO CPU or torch fallback.  If it cannot be loaded the
+import of the ops fails loudly (FastKVNativeError)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import _build
+
+
+class FastKVNativeError(RuntimeError):
+    pass
+
+
+class Problem(ctypes.Structure):
+    """struct fastkv_problem (include/fastkv_hip.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "H", "Hkv", "S", "D", "window", "kernel", "pooling", "capacity",
+                                              "tsp_len", "order", "reserved")]
+
+
+EXPORTS = ["fastkv_workspace_bytes", "fastkv_update_kv_f16", "fastkv_score_f16", "fastkv_select_f16",
+           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_strerror", "fastkv_version"]
+
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load (building first if the sources are newer) the HIP library and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    try:
+        if build_if_missing and _build.needs_build():
+            path = _build.build()
+        L = ctypes.CDLL(path)
+    except Exception as e:   # noqa: BLE001 - any failure here means the native path is unusable
+        raise FastKVNativeError(f"fastkv_amd: cannot load the HIP extension {path}: {e}") from e
+    vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t
+    i64p, pp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(Problem)
+    L.fastkv_workspace_bytes.argtypes = [pp]
+    L.fastkv_workspace_bytes.restype = sz
+    L.fastkv_update_kv_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.fastkv_update_kv_f16.restype = ci
+    L.fastkv_score_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, vp, vp, sz, vp]
+    L.fastkv_score_f16.restype = ci
+    L.fastkv_select_f16.argtypes = [vp, i64, i64, i64, i64, ci, ci, vp, vp, sz, vp]
+    L.fastkv_select_f16.restype = ci
+    L.fastkv_select_workspace_bytes.argtypes = [i64, i64, i64]
+    L.fastkv_select_workspace_bytes.restype = sz
+    L.fastkv_compact_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, vp, vp, vp]
+    L.fastkv_compact_f16.restype = ci
+    L.fastkv_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp]
+    L.fastkv_gather_rows.restype = ci
+    L.fastkv_strerror.argtypes = [ci]
+    L.fastkv_strerror.restype = ctypes.c_char_p
+    L.fastkv_version.argtypes = []
+    L.fastkv_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fastkv_strerror(rc).decode()
+        raise FastKVNativeError(f"fastkv_amd.{what}: {msg} (code {rc})")

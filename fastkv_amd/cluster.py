@@ -1,0 +1,114 @@
+"""Drop-in `FastKVCluster` (same names, attributes, argument meaning and error behaviour as
+/root/reference/baselines/fastkv/utils.py:48-138) whose compress branch runs on the HIP kernels.
+
+Host logic kept exactly: the 9 plain attributes `compress_fastkv` pushes (utils.py:29-46), the
+`cap - window > 0` assertion (utils.py:54), the proportional-mode mutation of
+`max_capacity_prompt` / `tsp_length` (utils.py:86-87, :123-124), the `q_len < cap` early-out that
+returns the SAME tensor objects (utils.py:89-91), the strict `q_len > tsp_length` TSP guard
+(utils.py:126) and `ValueError('Pooling method not supported')` (utils.py:110).
+"""
+from __future__ import annotations
+
+import os
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import ops
+
+
+class Plan(NamedTuple):
+    """What one `update_kv` call will do for a prompt of `q_len` tokens (pure host logic)."""
+    early_out: bool
+    capacity: int
+    tsp_len: int          # 0 = no TSP index on this call
+
+
+def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
+    """[B,Hkv,S,D] -> [B,Hkv*n_rep,S,D] (utils.py:13-22).  Kept for API parity; the HIP path never
+    materialises this tensor."""
+    if n_rep == 1:
+        return hidden_states
+    b, h, s, d = hidden_states.shape
+    return hidden_states.unsqueeze(2).expand(b, h, n_rep, s, d).reshape(b, h * n_rep, s, d)
+
+
+class FastKVCluster:
+    def __init__(self, window_size=8, max_capacity_prompt=512, kernel_size=7, pooling="avgpool", tsp_layer=False,
+                 tsp_length=2048, tsp_rate=0.25, retain_rate=0.25, eviction_mode="constant"):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.tsp_layer = tsp_layer
+        self.tsp_length = tsp_length
+        self.retain_rate = retain_rate
+        self.eviction_mode = eviction_mode
+        self.tsp_rate = tsp_rate
+        # row order of the compressed K/V: "score" = the reference's topk(sorted=True) order with the
+        # canonical tie rule; "index" = ascending position (no sort pass).  Not a reference attribute.
+        self.kv_order = os.environ.get("FASTKV_KV_ORDER", "score")
+
+    def reset(self, window_size=8, max_capacity_prompt=512, kernel_size=7, pooling="avgpool", tsp_layer=False,
+              tsp_length=2048, tsp_rate=0.25, retain_rate=0.25, eviction_mode="constant"):
+        self.window_size = window_size
+        self.max_capacity_prompt = max_capacity_prompt
+        assert self.max_capacity_prompt - self.window_size > 0
+        self.kernel_size = kernel_size
+        self.pooling = pooling
+        self.tsp_layer = tsp_layer
+        self.tsp_length = tsp_length          # (the reference stores a 1-tuple here, utils.py:73: a bug, not reproduced)
+        self.retain_rate = retain_rate
+        self.eviction_mode = eviction_mode
+        self.tsp_rate = tsp_rate
+
+    # ------------------------------------------------------------------ host logic (no device work)
+    def plan(self, q_len: int) -> Plan:
+        """Applies and returns the length rules of utils.py:86-91 and :123-126 (mutating state as the
+        reference does)."""
+        if self.eviction_mode == "proportional":
+            self.max_capacity_prompt = int(q_len * self.retain_rate)
+        if q_len < self.max_capacity_prompt:
+            return Plan(True, self.max_capacity_prompt, 0)
+        if self.pooling not in ("avgpool", "maxpool"):
+            raise ValueError("Pooling method not supported")
+        if self.tsp_layer and self.eviction_mode == "proportional":
+            self.tsp_length = int(q_len * self.tsp_rate)
+        tsp = self.tsp_length if (self.tsp_layer and q_len > self.tsp_length) else 0
+        return Plan(False, self.max_capacity_prompt, tsp)
+
+    # ------------------------------------------------------------------ the operator
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups, layer_idx):
+        # `attention_mask` and `layer_idx` are accepted and ignored, as in the reference (utils.py:99)
+        assert key_states.shape[-2] == query_states.shape[-2]
+        q_len = query_states.shape[2]
+        plan = self.plan(q_len)
+        if plan.early_out:
+            return key_states, value_states, None
+        assert query_states.shape[1] == key_states.shape[1] * num_key_value_groups
+        k_out, v_out, tsp_indices = ops.update_kv(query_states, key_states, value_states, self.window_size,
+                                                  self.kernel_size, self.pooling, plan.capacity, plan.tsp_len,
+                                                  self.kv_order)
+        return k_out, v_out, tsp_indices
+
+
+def init_fastkv(self):
+    """Attach a cluster to an attention module (utils.py:137-138)."""
+    self.kv_cluster = FastKVCluster()
+
+
+def compress_fastkv(model, args):
+    """Per-layer configuration push with the reference's rules (utils.py:25-46): layer `tsp_idx` is the
+    TSP layer; layers after it keep `retain_rate / tsp_rate` of their (already reduced) input."""
+    for i, layer in enumerate(model.model.layers):
+        c = layer.self_attn.kv_cluster
+        c.window_size = args.window_size[i]
+        c.kernel_size = args.kernel_size[i]
+        c.pooling = args.pooling
+        c.max_capacity_prompt = args.max_capacity_prompts
+        c.tsp_length = args.tsp_len
+        c.tsp_rate = args.tsp_rate
+        c.eviction_mode = args.eviction_mode
+        c.tsp_layer = (i == args.tsp_idx)
+        c.retain_rate = args.retain_rate if i <= args.tsp_idx else args.retain_rate / args.tsp_rate

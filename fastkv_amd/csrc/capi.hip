@@ -1,0 +1,164 @@
+// C ABI (include/fastkv_hip.h): argument validation and stream-ordered orchestration of the kernels.
+// Replaces the compress branch of FastKVCluster.update_kv, /root/reference/baselines/fastkv/utils.py:93-132.
+// No allocation, no synchronisation, no exceptions; everything goes on the caller's stream.
+#include "fk_host.h"
+
+using namespace fk;
+
+namespace {
+
+int check_problem(const fastkv_problem *p)
+{
+    if (!p) return FASTKV_EINVAL;
+    if (p->B < 1 || p->Hkv < 1 || p->H < p->Hkv || (p->H % p->Hkv) != 0) return FASTKV_EINVAL;
+    if (p->D != 64 && p->D != 128 && p->D != 256) return FASTKV_EUNSUPPORTED;
+    if (p->window < 1 || p->window > 64 || p->S <= p->window) return FASTKV_EINVAL;
+    if (p->kernel < 1 || (p->kernel & 1) == 0 || p->kernel > 63) return FASTKV_EINVAL;   // even kernels break the reference's view() too
+    if (p->pooling != FASTKV_POOL_AVG && p->pooling != FASTKV_POOL_MAX) return FASTKV_EINVAL;
+    if ((int64_t)p->S >= (1ll << 24)) return FASTKV_EUNSUPPORTED;                          // fixed-point softmax sum headroom
+    return FASTKV_OK;
+}
+
+int check_select(const fastkv_problem *p)
+{
+    if (p->capacity <= p->window || p->capacity > p->S) return FASTKV_EINVAL;
+    if (p->tsp_len != 0 && (p->tsp_len <= p->window || p->tsp_len >= p->S)) return FASTKV_EINVAL;
+    if (p->order != FASTKV_ORDER_INDEX && p->order != FASTKV_ORDER_SCORE) return FASTKV_EINVAL;
+    return FASTKV_OK;
+}
+
+int check_strides(const void *ptr, const int64_t *s)
+{
+    if (!ptr || !s) return FASTKV_EINVAL;
+    if (s[3] != 1) return FASTKV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(ptr) & 15) || (s[0] & 7) || (s[1] & 7) || (s[2] & 7)) return FASTKV_EINVAL;   // 16-B rows
+    return FASTKV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fastkv_workspace_bytes(const fastkv_problem *p)
+{
+    if (check_problem(p) != FASTKV_OK) return 0;
+    fastkv_problem q = *p;
+    if (q.capacity <= q.window || q.capacity > q.S) q.capacity = q.S;     // sizing only
+    return make_layout(q).total;
+}
+
+size_t fastkv_select_workspace_bytes(int64_t rows, int64_t n, int64_t k) { return select_ws_bytes(rows, n, k); }
+
+int fastkv_score_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
+                     const int64_t k_strides[4], void *scores_out, void *tsp_scores_out, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    int rc;
+    if ((rc = check_problem(p)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(q, q_strides)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
+    if (!scores_out || !workspace) return FASTKV_EINVAL;
+    fastkv_problem pp = *p;
+    if (pp.capacity <= pp.window || pp.capacity > pp.S) pp.capacity = pp.S;
+    const Layout L = make_layout(pp);
+    if (workspace_bytes < L.total) return FASTKV_EWORKSPACE;
+    hipError_t e = launch_score(pp, L, q, q_strides, k, k_strides, (uint16_t *)scores_out, L.n, (uint16_t *)tsp_scores_out, L.n,
+                                (char *)workspace, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_select_f16(const void *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int32_t order,
+                      int32_t append, int64_t *idx_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!scores || !idx_out || rows < 0 || n < 1 || k < 0 || k > n || append < 0 || row_stride < n) return FASTKV_EINVAL;
+    if (order != FASTKV_ORDER_INDEX && order != FASTKV_ORDER_SCORE) return FASTKV_EINVAL;
+    if (n >= (1ll << 31) - 8192) return FASTKV_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < select_ws_bytes(rows, n, k)) return FASTKV_EWORKSPACE;
+    hipError_t e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, order, append, idx_out, (char *)workspace,
+                                 (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_compact_f16(const fastkv_problem *p, const void *k, const int64_t k_strides[4], const void *v,
+                       const int64_t v_strides[4], const int64_t *idx, void *k_out, void *v_out, void *stream)
+{
+    int rc;
+    if ((rc = check_problem(p)) != FASTKV_OK) return rc;
+    if ((rc = check_select(p)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(v, v_strides)) != FASTKV_OK) return rc;
+    if (!idx || !k_out || !v_out) return FASTKV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(k_out) & 15) || (reinterpret_cast<uintptr_t>(v_out) & 15)) return FASTKV_EINVAL;
+    hipError_t e = launch_compact(*p, k, k_strides, v, v_strides, idx, k_out, v_out, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
+                         const int64_t k_strides[4], const void *v, const int64_t v_strides[4], void *k_out, void *v_out,
+                         int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    int rc;
+    if ((rc = check_problem(p)) != FASTKV_OK) return rc;
+    if ((rc = check_select(p)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(q, q_strides)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(v, v_strides)) != FASTKV_OK) return rc;
+    if (!k_out || !v_out || !workspace) return FASTKV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(k_out) & 15) || (reinterpret_cast<uintptr_t>(v_out) & 15)) return FASTKV_EINVAL;
+    if (p->tsp_len != 0 && !tsp_idx_out) return FASTKV_EINVAL;
+    const Layout L = make_layout(*p);
+    if (workspace_bytes < L.total) return FASTKV_EWORKSPACE;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t *c = reinterpret_cast<uint16_t *>(ws + L.off_c);
+    uint16_t *t = p->tsp_len ? reinterpret_cast<uint16_t *>(ws + L.off_t) : nullptr;
+    int64_t *idx = kv_idx_out ? kv_idx_out : reinterpret_cast<int64_t *>(ws + L.off_idx);
+    const int kk = p->capacity - p->window;
+
+    hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st);
+    if (e != hipSuccess) return FASTKV_ELAUNCH;
+    if (scores_out) {
+        e = hipMemcpy2DAsync(scores_out, (size_t)L.n * 2, c, (size_t)L.n_pad * 2, (size_t)L.n * 2, (size_t)p->B * p->Hkv,
+                             hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return FASTKV_ELAUNCH;
+    }
+    e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, p->order, 0, idx, ws + L.off_sel, st);
+    if (e != hipSuccess) return FASTKV_ELAUNCH;
+    if (p->tsp_len) {
+        e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, FASTKV_ORDER_INDEX, p->window, tsp_idx_out,
+                          ws + L.off_sel, st);
+        if (e != hipSuccess) return FASTKV_ELAUNCH;
+    }
+    e = launch_compact(*p, k, k_strides, v, v_strides, idx, k_out, v_out, st);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t src_row_stride_bytes, const int64_t *idx,
+                       int64_t idx_batch_stride, int64_t batches, int64_t rows_out, int64_t rows_in, int64_t row_bytes,
+                       void *dst, void *stream)
+{
+    if (!src || !idx || !dst || batches < 0 || rows_out < 0 || rows_in < 1 || row_bytes < 16 || (row_bytes & 15)) return FASTKV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15) || (src_row_stride_bytes & 15) ||
+        (src_batch_stride_bytes & 15))
+        return FASTKV_EINVAL;
+    hipError_t e = launch_gather_rows(src, src_batch_stride_bytes, src_row_stride_bytes, idx, idx_batch_stride, batches, rows_out,
+                                      rows_in, row_bytes, dst, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+const char *fastkv_strerror(int code)
+{
+    switch (code) {
+    case FASTKV_OK: return "ok";
+    case FASTKV_EINVAL: return "invalid argument (shape, stride, alignment, pooling or order)";
+    case FASTKV_EWORKSPACE: return "workspace missing or too small (see fastkv_workspace_bytes)";
+    case FASTKV_ELAUNCH: return "HIP kernel launch failed";
+    case FASTKV_EUNSUPPORTED: return "unsupported configuration (head_dim must be 64/128/256, S < 2^24)";
+    default: return "unknown error";
+    }
+}
+
+const char *fastkv_version(void) { return "fastkv-hip 0.1.0 gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Host-side shared declarations: workspace layout and kernel launchers (internal, not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/fastkv_hip.h"
+
+namespace fk {
+
+constexpr int TKA = 256;        // keys per workgroup in score_logits (4 waves x 64 lanes, one key per lane)
+constexpr int CHB = 2048;       // positions per workgroup in score_sumexp (256 threads x 8)
+constexpr int SEL_THREADS = 1024;
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Layout {
+    int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
+    int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
+    int ntA, nchB;                   // tiles of score_logits, chunks of score_sumexp
+    size_t off_qf, off_logits, off_pm, off_ps, off_c, off_t, off_idx, off_sel, total;
+};
+
+static inline size_t select_ws_bytes(int64_t rows, int64_t n, int64_t k)
+{
+    (void)n;
+    // global fallbacks of the stable radix sort (ping-pong (idx32,key16) lists + digit counters);
+    // only touched when the winner list does not fit LDS.  Must match launch_select().
+    const size_t kal = ((size_t)k + 7) & ~(size_t)7;
+    const size_t iters = ((size_t)k + SEL_THREADS - 1) / SEL_THREADS;
+    return align_up((size_t)rows * 2 * kal * sizeof(uint32_t), 256) + align_up((size_t)rows * 2 * kal * sizeof(uint16_t), 256) +
+           align_up((size_t)rows * (iters ? iters : 1) * 256 * sizeof(uint32_t), 256);
+}
+
+static inline Layout make_layout(const fastkv_problem &p)
+{
+    Layout L;
+    L.G = p.H / p.Hkv;
+    L.R = L.G * p.window;
+    int r8 = (L.R + 7) / 8 * 8;
+    if (r8 <= 64) { L.RB = r8 <= 8 ? 8 : r8 <= 16 ? 16 : r8 <= 32 ? 32 : 64; L.passes = 1; }
+    else { L.RB = 64; L.passes = (r8 + 63) / 64; }
+    L.R_alloc = L.RB * L.passes;
+    L.n = p.S - p.window;
+    L.Sp = (p.S + 7) / 8 * 8;
+    L.n_pad = (L.n + 7) / 8 * 8;
+    L.ntA = (p.S + TKA - 1) / TKA;
+    L.nchB = (p.S + CHB - 1) / CHB;
+    size_t o = 0;
+    L.off_qf = o;     o += align_up((size_t)p.B * p.Hkv * L.R_alloc * p.D * 4, 256);
+    L.off_logits = o; o += align_up((size_t)p.B * p.H * p.window * L.Sp * 2, 256);
+    L.off_pm = o;     o += align_up((size_t)p.B * p.H * p.window * L.ntA * 4, 256);
+    L.off_ps = o;     o += align_up((size_t)p.B * p.H * p.window * L.nchB * 8, 256);
+    L.off_c = o;      o += align_up((size_t)p.B * p.Hkv * L.n_pad * 2, 256);
+    L.off_t = o;      o += align_up((size_t)p.B * L.n_pad * 2, 256);
+    L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
+    L.off_sel = o;
+    int64_t kmax = p.capacity - p.window;
+    if (p.tsp_len - p.window > kmax) kmax = p.tsp_len - p.window;
+    o += select_ws_bytes((int64_t)p.B * p.Hkv, L.n, kmax > 0 ? kmax : 1);
+    L.total = o;
+    return L;
+}
+
+// launchers (defined in score.hip / select.hip / compact.hip); all return hipError_t of the launch
+hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
+                        const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
+                        char *ws, hipStream_t st);
+hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int order,
+                         int append, int64_t *idx_out, char *ws, hipStream_t st);
+hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
+                          const int64_t *idx, void *k_out, void *v_out, hipStream_t st);
+hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
+                              int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st);
+
+}  // namespace fk

@@ -1,0 +1,162 @@
+"""torch-tensor front-ends of the C ABI.  torch is used for device memory and the current HIP
+stream only; every byte of the hot path is moved/computed by the kernels in csrc/.
+
+All functions are stream-ordered on torch's current stream and never synchronise
+(same contract as the reference operator, /root/reference/baselines/fastkv/utils.py:80-134)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import Problem, check, load
+
+POOLING = {"avgpool": 0, "maxpool": 1}
+ORDER = {"index": 0, "score": 1}
+
+_ws_cache: dict = {}
+
+
+def _require_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fastkv_amd: the HIP path needs tensors on a ROCm device (no CPU fallback exists)")
+
+
+def _strides(t: torch.Tensor):
+    return (ctypes.c_int64 * 4)(*t.stride())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Grow-only per-(device, stream) scratch; reuse is safe because all users are ordered on that stream."""
+    key = (device.index, _stream())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _problem(q, k, window, kernel_size, pooling, capacity, tsp_len, order) -> Problem:
+    B, H, S, D = q.shape
+    if pooling not in POOLING:
+        raise ValueError("Pooling method not supported")          # utils.py:110
+    return Problem(B=B, H=H, Hkv=k.shape[1], S=S, D=D, window=window, kernel=kernel_size, pooling=POOLING[pooling],
+                   capacity=capacity, tsp_len=tsp_len, order=ORDER[order], reserved=0)
+
+
+def _check_qkv(q, k, v=None):
+    _require_cuda(q, k, v)
+    for t in (q, k, v):
+        if t is None:
+            continue
+        if t.dtype != torch.float16:
+            raise TypeError(f"fastkv_amd: fp16 tensors expected, got {t.dtype}")
+        if t.dim() != 4 or t.stride(3) != 1:
+            raise ValueError("fastkv_amd: expected [B,H,S,D] tensors with unit head_dim stride")
+    if k.shape[0] != q.shape[0] or k.shape[2] != q.shape[2] or k.shape[3] != q.shape[3]:
+        raise ValueError("fastkv_amd: q/k shape mismatch")
+
+
+def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, kernel_size: int, pooling: str,
+              capacity: int, tsp_len: int = 0, order: str = "score", return_indices: bool = False,
+              return_scores: bool = False):
+    """Compress branch of FastKVCluster.update_kv (utils.py:93-132) in one stream-ordered call.
+
+    Returns (k_out [B,Hkv,cap,D], v_out, tsp_idx [B,tsp_len] int64 | None[, kv_idx][, scores])."""
+    _check_qkv(q, k, v)
+    L = load()
+    p = _problem(q, k, window, kernel_size, pooling, capacity, tsp_len, order)
+    B, Hkv, D = p.B, p.Hkv, p.D
+    dev = q.device
+    ko = torch.empty(B, Hkv, capacity, D, dtype=torch.float16, device=dev)
+    vo = torch.empty_like(ko)
+    tsp = torch.empty(B, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
+    kv_idx = torch.empty(B, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
+    sc = torch.empty(B, Hkv, p.S - window, dtype=torch.float16, device=dev) if return_scores else None
+    nbytes = L.fastkv_workspace_bytes(ctypes.byref(p))
+    if nbytes == 0:
+        check(-1, "workspace_bytes")
+    ws = _workspace(nbytes, dev)
+    rc = L.fastkv_update_kv_f16(ctypes.byref(p), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), v.data_ptr(),
+                                _strides(v), ko.data_ptr(), vo.data_ptr(),
+                                kv_idx.data_ptr() if kv_idx is not None else None,
+                                tsp.data_ptr() if tsp is not None else None,
+                                sc.data_ptr() if sc is not None else None, ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "update_kv")
+    out = [ko, vo, tsp]
+    if return_indices:
+        out.append(kv_idx)
+    if return_scores:
+        out.append(sc)
+    return tuple(out)
+
+
+def scores(q: torch.Tensor, k: torch.Tensor, window: int, kernel_size: int, pooling: str, want_tsp: bool = True):
+    """attn_cache c[B,Hkv,n] (utils.py:112) and optionally the TSP row t[B,n] (utils.py:127)."""
+    _check_qkv(q, k)
+    L = load()
+    p = _problem(q, k, window, kernel_size, pooling, q.shape[2], 0, "index")
+    n = p.S - window
+    c = torch.empty(p.B, p.Hkv, n, dtype=torch.float16, device=q.device)
+    t = torch.empty(p.B, n, dtype=torch.float16, device=q.device) if want_tsp else None
+    ws = _workspace(L.fastkv_workspace_bytes(ctypes.byref(p)), q.device)
+    rc = L.fastkv_score_f16(ctypes.byref(p), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), c.data_ptr(),
+                            t.data_ptr() if t is not None else None, ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "score")
+    return c, t
+
+
+def select(scores2d: torch.Tensor, k: int, order: str = "index", append: int = 0) -> torch.Tensor:
+    """Canonical top-k of every row of a [rows, n] fp16 tensor -> int64 [rows, k + append]."""
+    _require_cuda(scores2d)
+    assert scores2d.dim() == 2 and scores2d.dtype == torch.float16 and scores2d.stride(1) == 1
+    L = load()
+    rows, n = scores2d.shape
+    out = torch.empty(rows, k + append, dtype=torch.int64, device=scores2d.device)
+    ws = _workspace(L.fastkv_select_workspace_bytes(rows, n, k), scores2d.device)
+    rc = L.fastkv_select_f16(scores2d.data_ptr(), rows, scores2d.stride(0), n, k, ORDER[order], append, out.data_ptr(),
+                             ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "select")
+    return out
+
+
+def compact(k: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, window: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """K/V gather + window append (utils.py:114-121) for given per-head indices [B,Hkv,cap-W] int64."""
+    _check_qkv(k, k, v)
+    L = load()
+    B, Hkv, S, D = k.shape
+    cap = idx.shape[2] + window
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.is_cuda
+    p = Problem(B=B, H=Hkv, Hkv=Hkv, S=S, D=D, window=window, kernel=1, pooling=0, capacity=cap, tsp_len=0, order=0, reserved=0)
+    ko = torch.empty(B, Hkv, cap, D, dtype=torch.float16, device=k.device)
+    vo = torch.empty_like(ko)
+    rc = L.fastkv_compact_f16(ctypes.byref(p), k.data_ptr(), _strides(k), v.data_ptr(), _strides(v), idx.data_ptr(),
+                              ko.data_ptr(), vo.data_ptr(), _stream())
+    check(rc, "compact")
+    return ko, vo
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """dst[b, r, ...] = src[b, idx[b, r], ...]: the TSP propagation gather (llama_model.py:254-257).
+
+    `src` is [B, S, ...] with contiguous trailing dims whose byte size is a multiple of 16
+    (hidden states), or [B, S] int64 position ids (handled as 8-byte rows via a 16-byte staging trick:
+    not supported -> use torch.gather for those 16 KiB)."""
+    _require_cuda(src, idx)
+    assert idx.dtype == torch.int64 and idx.dim() == 2 and idx.stride(1) == 1
+    B, S = src.shape[0], src.shape[1]
+    row_bytes = src[0, 0].numel() * src.element_size()
+    if not src[0, 0].is_contiguous() and src[0, 0].numel() > 1:
+        raise ValueError("fastkv_amd.gather_rows: trailing dims must be contiguous")
+    L = load()
+    out = torch.empty((B, idx.shape[1]) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    rc = L.fastkv_gather_rows(src.data_ptr(), src.stride(0) * src.element_size(), src.stride(1) * src.element_size(),
+                              idx.data_ptr(), idx.stride(0), B, idx.shape[1], S, row_bytes, out.data_ptr(), _stream())
+    check(rc, "gather_rows")
+    return out

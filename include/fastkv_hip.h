@@ -1,0 +1,122 @@
+/*
+ * fastkv_hip.h -- C ABI of the MI355X (gfx950) implementation of FastKV's hot path.
+ *
+ * The reference (dongwonjo/FastKV) is pure Python: the operator this library replaces is
+ *   FastKVCluster.update_kv            /root/reference/baselines/fastkv/utils.py:80-134
+ * and its one extra consumer, the TSP hidden-state gather in the decoder layer
+ *   llama_decoderlayer_forward_fastkv  /root/reference/baselines/fastkv/llama_model.py:252-259
+ * The reference has no FFI of its own; these entry points are what a ctypes binding inside
+ * that Python method would call (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor storage);
+ *   - fp16 tensors are passed as `const void*`, strides are in ELEMENTS, the innermost
+ *     (head_dim) stride must be 1 and every row must be 16-byte aligned;
+ *   - logical layout of q/k/v is [B, H, S, D]; any physical layout is accepted through the
+ *     strides (the attention module hands over [B,S,H,D] storage, llama_model.py:117-122);
+ *   - all work is enqueued on `stream`; no allocation, no host synchronisation, no
+ *     exceptions across the ABI; the calls are hipGraph-capturable;
+ *   - return value 0 = success, negative = error code (fastkv_strerror).
+ */
+#ifndef FASTKV_HIP_H
+#define FASTKV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTKV_OK 0
+#define FASTKV_EINVAL (-1)     /* bad argument (shape, stride, alignment, pooling, ...) */
+#define FASTKV_EWORKSPACE (-2) /* workspace too small */
+#define FASTKV_ELAUNCH (-3)    /* HIP launch error */
+#define FASTKV_EUNSUPPORTED (-4)
+
+#define FASTKV_POOL_AVG 0 /* F.avg_pool1d(k, padding=k//2, stride=1)   utils.py:105-106 */
+#define FASTKV_POOL_MAX 1 /* F.max_pool1d(k, padding=k//2, stride=1)   utils.py:107-108 */
+
+#define FASTKV_ORDER_INDEX 0 /* selected rows in ascending position                         */
+#define FASTKV_ORDER_SCORE 1 /* score descending, ties by ascending position: the order of  */
+                             /* `topk(sorted=True)` (utils.py:113) with a canonical tie rule */
+
+/* Problem description shared by the entry points (plain data, passed by pointer). */
+typedef struct fastkv_problem {
+    int32_t B;         /* batch */
+    int32_t H;         /* query heads */
+    int32_t Hkv;       /* key/value heads, H % Hkv == 0 */
+    int32_t S;         /* prompt length (q_len == kv_len, utils.py:82) */
+    int32_t D;         /* head dim: 64, 128 or 256 */
+    int32_t window;    /* FastKVCluster.window_size */
+    int32_t kernel;    /* FastKVCluster.kernel_size (odd) */
+    int32_t pooling;   /* FASTKV_POOL_* */
+    int32_t capacity;  /* max_capacity_prompt after the proportional rule (utils.py:86-87); window < capacity <= S */
+    int32_t tsp_len;   /* 0 = no TSP on this layer; else window < tsp_len < S (utils.py:126) */
+    int32_t order;     /* FASTKV_ORDER_* for the K/V rows */
+    int32_t reserved;
+} fastkv_problem;
+
+/* Bytes of scratch `fastkv_update_kv_f16` / `fastkv_score_f16` need for this problem. */
+size_t fastkv_workspace_bytes(const fastkv_problem *p);
+
+/*
+ * The whole operator: replaces the compress branch of FastKVCluster.update_kv (utils.py:93-132).
+ *   q, k, v        fp16, logical [B,H,S,D] / [B,Hkv,S,D] with the given element strides
+ *   k_out, v_out   fp16 [B,Hkv,capacity,D] contiguous: rows 0..capacity-window-1 are the selected
+ *                  rows in `order`, the last `window` rows are the window rows (utils.py:114-121)
+ *   kv_idx_out     optional int64 [B,Hkv,capacity-window]: the per-head selected positions
+ *                  (internal `indices` of utils.py:113; not returned by the reference)
+ *   tsp_idx_out    int64 [B,tsp_len] ascending (utils.py:127-130); required iff tsp_len > 0
+ *   scores_out     optional fp16 [B,Hkv,S-window]: `attn_cache` (utils.py:112), for tests
+ */
+int fastkv_update_kv_f16(const fastkv_problem *p,
+                         const void *q, const int64_t q_strides[4],
+                         const void *k, const int64_t k_strides[4],
+                         const void *v, const int64_t v_strides[4],
+                         void *k_out, void *v_out, int64_t *kv_idx_out, int64_t *tsp_idx_out,
+                         void *scores_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Stage 1 alone: window-attention scores (utils.py:93-112 [+ :127 head sum]).
+ *   scores_out      fp16 [B,Hkv,S-window] contiguous
+ *   tsp_scores_out  optional fp16 [B,S-window]
+ */
+int fastkv_score_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4],
+                     const void *k, const int64_t k_strides[4], void *scores_out, void *tsp_scores_out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Stage 2 alone: canonical top-k of `rows` independent fp16 score rows (utils.py:113 / :127).
+ *   scores          fp16, row r starts at scores + r*row_stride (elements), n valid entries
+ *   idx_out         int64 [rows, k + append]; `append` > 0 appends n, n+1, ... (the window positions,
+ *                   utils.py:128-129) after the k selected entries
+ *   order           FASTKV_ORDER_*
+ */
+int fastkv_select_f16(const void *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int32_t order,
+                      int32_t append, int64_t *idx_out, void *workspace, size_t workspace_bytes, void *stream);
+size_t fastkv_select_workspace_bytes(int64_t rows, int64_t n, int64_t k);
+
+/*
+ * Stage 3 alone: gather/compact of K and V (utils.py:114-121).  idx int64 [B,Hkv,capacity-window].
+ */
+int fastkv_compact_f16(const fastkv_problem *p, const void *k, const int64_t k_strides[4],
+                       const void *v, const int64_t v_strides[4], const int64_t *idx,
+                       void *k_out, void *v_out, void *stream);
+
+/*
+ * Generic row gather: dst[b, r, :] = src[b, idx[b, r], :]; rows of `row_bytes` (multiple of 16).
+ * Serves the TSP propagation of hidden states and position ids (llama_model.py:254-257).
+ */
+int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t src_row_stride_bytes,
+                       const int64_t *idx, int64_t idx_batch_stride, int64_t batches, int64_t rows_out,
+                       int64_t rows_in, int64_t row_bytes, void *dst, void *stream);
+
+const char *fastkv_strerror(int code);
+/* "fastkv-hip <version> gfx950" */
+const char *fastkv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTKV_HIP_H */

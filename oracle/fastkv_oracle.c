@@ -1,0 +1,401 @@
+/*
+ * fastkv_oracle.c -- CPU restatement of the FastKV hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP kernels in fastkv_amd/csrc.  It may be
+ * imported / linked / executed only by tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py.  The product path never calls into it.
+ *
+ * What it restates (reference = dongwonjo/FastKV, /root/reference):
+ *   baselines/fastkv/utils.py:80-134   FastKVCluster.update_kv
+ *   baselines/fastkv/llama_model.py:252-259  TSP hidden-state / position gather
+ *
+ * Pinning: tests/test_oracle_golden.py checks this restatement against golden vectors
+ * captured from the imported reference (tests/golden/make_golden.py): score tensors
+ * (<= 1 fp16 ulp on <= 0.1 % of the elements -- the reference's own torch kernels are
+ * not bit-reproducible across accumulation orders / exp implementations),
+ * canonical top-k of the reference's scores == oracle indices, bit-exact K/V rows.
+ *
+ * Arithmetic contract (shared bit-for-bit with the HIP kernels):
+ *   dot      fp32 fma chain over d = 0..D-1 (products of two fp16 are exact in fp32)   utils.py:94
+ *   round    -> fp16, then fp32 true division by (float)sqrt(D), -> fp16              utils.py:94
+ *   mask     window block: + (-65504.0f) in fp32 where col > row, -> fp16             utils.py:95-101
+ *   softmax  fp32: e = det_exp(x - rowmax); sum in 2^-40 fixed point (order free,
+ *            hence identical for any tiling / any sequence sharding); p = e * (1/sum)
+ *            -> fp16                                                                   utils.py:103
+ *   rowsum   fp32 over the W window rows in row order -> fp16                          utils.py:104
+ *   pool     avg: fp32 sum of the taps in ascending position, / (float)k -> fp16
+ *            (zero padding, divisor always k); max: -inf padding                       utils.py:105-108
+ *   groups   fp32 sum over the G query heads of a KV head in head order -> fp16        utils.py:112
+ *   top-k    canonical: value descending, index ascending among equal values           utils.py:113
+ *   tsp      fp32 sum over KV heads in head order -> fp16; canonical top-k;
+ *            union with the window; ascending                                          utils.py:127-130
+ *
+ * Build: gcc -O3 -ffp-contract=off -mavx2 -mfma -mf16c -fopenmp -shared -fPIC
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <immintrin.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define FK_OK 0
+#define FK_EINVAL (-1)
+#define FK_ENOMEM (-2)
+
+/* ---------------------------------------------------------------- scalar helpers */
+
+static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* Deterministic exp for d <= 0 built only from IEEE fp32 fma / mul / add, so that the
+ * HIP kernels reproduce it bit for bit.  ~1 ulp.  d < -87 (and -inf) -> 0, NaN -> NaN. */
+static inline float det_expf(float d)
+{
+    if (!(d >= -87.0f)) return (d != d) ? d : 0.0f;
+    if (d > 0.0f) d = 0.0f;                       /* never happens for x - rowmax */
+    const float LOG2E = 1.44269504088896341f;
+    const float LN2_HI = 0.693359375f;            /* 0x3f318000: 9 trailing-zero-free bits */
+    const float LN2_LO = -2.12194440e-4f;
+    float n = rintf(d * LOG2E);
+    float r = fmaf(n, -LN2_HI, d);
+    r = fmaf(n, -LN2_LO, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    p = fmaf(p, r2, r);
+    p = p + 1.0f;
+    /* scale by 2^n, n in [-126, 0]: p in [0.70, 1.42] so the result stays normal */
+    int32_t ni = (int32_t)n;
+    return bits_f32((uint32_t)((int32_t)f32_bits(p) + ni * (1 << 23)));
+}
+
+/* e in [0,1] -> 2^-40 fixed point split in two 32-bit addends (hi*2^24 + lo). */
+static inline void exp_to_fix(float e, uint32_t *hi, uint32_t *lo)
+{
+    float a = e * 65536.0f;
+    float hf = truncf(a);
+    float rem = a - hf;                            /* exact */
+    float lf = rintf(rem * 16777216.0f);           /* <= 2^24 */
+    *hi = (uint32_t)hf;
+    *lo = (uint32_t)lf;
+}
+
+/* u64 (2^-40 fixed point) -> fp32 value, round to nearest even, integer arithmetic only. */
+static inline float fix_to_f32(uint64_t s)
+{
+    if (s == 0) return 0.0f;
+    int msb = 63 - __builtin_clzll(s);
+    uint32_t mant; int exp2 = msb;
+    if (msb <= 23) {
+        mant = (uint32_t)(s << (23 - msb));
+    } else {
+        int sh = msb - 23;
+        uint64_t q = s >> sh;
+        uint64_t rem = s & ((1ull << sh) - 1);
+        uint64_t half = 1ull << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) q++;
+        if (q == (1ull << 24)) { q >>= 1; exp2++; }
+        mant = (uint32_t)q;
+    }
+    /* value = mant * 2^(exp2-23) * 2^-40 */
+    uint32_t bits = ((uint32_t)(exp2 - 40 + 127) << 23) | (mant & 0x7fffffu);
+    return bits_f32(bits);
+}
+
+/* ---------------------------------------------------------------- stage 1: logits */
+
+/* L[b,h,r,j] = fp16( fp32(fp16(q_r . k_j)) / sqrtD ) (+ window mask), utils.py:93-101 */
+static void logits_bh(const uint16_t *q, int64_t qs_s, const uint16_t *k, int64_t ks_s,
+                      int S, int D, int W, float sqrtD, uint16_t *L /* [W][S] */)
+{
+    enum { TJ = 64 };
+    float *qf = (float *)malloc(sizeof(float) * (size_t)W * D);
+    float *kT = (float *)aligned_alloc(64, sizeof(float) * (size_t)D * TJ);
+    float acc[TJ] __attribute__((aligned(64)));
+    for (int r = 0; r < W; r++)
+        for (int d = 0; d < D; d++)
+            qf[r * D + d] = h2f(q[(int64_t)(S - W + r) * qs_s + d]);
+    for (int j0 = 0; j0 < S; j0 += TJ) {
+        int tj = S - j0 < TJ ? S - j0 : TJ;
+        for (int jj = 0; jj < TJ; jj++) {
+            const uint16_t *kr = k + (int64_t)(j0 + (jj < tj ? jj : 0)) * ks_s;
+            for (int d = 0; d < D; d++) kT[d * TJ + jj] = h2f(kr[d]);
+        }
+        for (int r = 0; r < W; r++) {
+            for (int jj = 0; jj < TJ; jj++) acc[jj] = 0.0f;
+            for (int d = 0; d < D; d++) {
+                float qv = qf[r * D + d];
+                const float *kd = kT + d * TJ;
+#pragma omp simd
+                for (int jj = 0; jj < TJ; jj++) acc[jj] = fmaf(qv, kd[jj], acc[jj]);
+            }
+            for (int jj = 0; jj < tj; jj++) {
+                int j = j0 + jj;
+                uint16_t l16 = f2h(acc[jj]);
+                uint16_t s16 = f2h(h2f(l16) / sqrtD);
+                if (j >= S - W && (j - (S - W)) > r)            /* strictly upper triangle */
+                    s16 = f2h(h2f(s16) + (-65504.0f));
+                L[(int64_t)r * S + j] = s16;
+            }
+        }
+    }
+    free(qf); free(kT);
+}
+
+/* ---------------------------------------------------------------- stage 2: softmax -> row sums */
+
+/* s[j] = fp16( sum_r fp32( fp16( softmax_row_r(L)[j] ) ) ), j < n = S-W.  utils.py:103-104 */
+static void softmax_rowsum_h(const uint16_t *L, int S, int W, uint16_t *s_out)
+{
+    int n = S - W;
+    float *rmax = (float *)malloc(sizeof(float) * W);
+    float *rinv = (float *)malloc(sizeof(float) * W);
+    for (int r = 0; r < W; r++) {
+        const uint16_t *row = L + (int64_t)r * S;
+        float m = -INFINITY; int has_nan = 0;
+        for (int j = 0; j < S; j++) { float x = h2f(row[j]); if (x != x) has_nan = 1; if (x > m) m = x; }
+        uint64_t acc_hi = 0, acc_lo = 0;
+        for (int j = 0; j < S; j++) {
+            uint32_t hi, lo;
+            float e = det_expf(h2f(row[j]) - m);
+            if (e != e) { has_nan = 1; continue; }
+            exp_to_fix(e, &hi, &lo);
+            acc_hi += hi; acc_lo += lo;
+        }
+        float sum = fix_to_f32((acc_hi << 24) + acc_lo);
+        rmax[r] = m;
+        rinv[r] = has_nan ? NAN : 1.0f / sum;
+    }
+    for (int j = 0; j < n; j++) {
+        float a = 0.0f;
+        for (int r = 0; r < W; r++) {
+            float e = det_expf(h2f(L[(int64_t)r * S + j]) - rmax[r]);
+            a = a + h2f(f2h(e * rinv[r]));
+        }
+        s_out[j] = f2h(a);
+    }
+    free(rmax); free(rinv);
+}
+
+/* ---------------------------------------------------------------- stage 3: pooling */
+
+/* utils.py:105-108; pooling 0 = avgpool, 1 = maxpool; kernel odd, pad = kernel/2, stride 1 */
+static void pool_row(const uint16_t *s, int n, int ksize, int pooling, uint16_t *out)
+{
+    int pad = ksize / 2;
+    if (pooling == 0) {
+        float div = (float)ksize;
+        for (int j = 0; j < n; j++) {
+            float a = 0.0f;
+            for (int t = j - pad; t <= j + pad; t++)
+                if (t >= 0 && t < n) a = a + h2f(s[t]);
+            out[j] = f2h(a / div);
+        }
+    } else {
+        for (int j = 0; j < n; j++) {
+            float a = -INFINITY;
+            for (int t = j - pad; t <= j + pad; t++)
+                if (t >= 0 && t < n) { float x = h2f(s[t]); if (x > a || x != x) a = x; }
+            out[j] = f2h(a);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- scores */
+
+/* c[b,g,j] (utils.py:93-112) and optionally t[b,j] = fp16(sum_g c[b,g,j]) (utils.py:127).
+ * logits_out (optional): [B,H,W,S] fp16 scaled+masked logits, for kernel-level tests. */
+int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
+                             int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
+                             uint16_t *c_out, uint16_t *t_out, uint16_t *logits_out)
+{
+    if (!q || !k || !c_out || B < 1 || Hkv < 1 || H < Hkv || H % Hkv || D < 1 || W < 1 || S <= W) return FK_EINVAL;
+    if (ksize < 1 || !(ksize & 1) || (pooling != 0 && pooling != 1)) return FK_EINVAL;
+    if (qs[3] != 1 || ks[3] != 1) return FK_EINVAL;
+    const int G = H / Hkv, n = S - W;
+    const float sqrtD = (float)sqrt((double)D);
+    uint16_t *pooled = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B * H * n);
+    if (!pooled) return FK_ENOMEM;
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bh = 0; bh < B * H; bh++) {
+        int b = bh / H, h = bh % H, g = h / G;
+        uint16_t *L = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)W * S);
+        uint16_t *srow = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n);
+        if (!L || !srow) { err = 1; free(L); free(srow); continue; }
+        logits_bh(q + b * qs[0] + h * qs[1], qs[2], k + b * ks[0] + g * ks[1], ks[2], S, D, W, sqrtD, L);
+        if (logits_out) memcpy(logits_out + (int64_t)bh * W * S, L, sizeof(uint16_t) * (size_t)W * S);
+        softmax_rowsum_h(L, S, W, srow);
+        pool_row(srow, n, ksize, pooling, pooled + (int64_t)bh * n);
+        free(L); free(srow);
+    }
+    if (err) { free(pooled); return FK_ENOMEM; }
+#pragma omp parallel for schedule(static)
+    for (int bg = 0; bg < B * Hkv; bg++) {
+        int b = bg / Hkv, g = bg % Hkv;
+        for (int j = 0; j < n; j++) {
+            float a = 0.0f;
+            for (int i = 0; i < G; i++) a = a + h2f(pooled[((int64_t)b * H + g * G + i) * n + j]);
+            c_out[(int64_t)bg * n + j] = f2h(a);
+        }
+    }
+    if (t_out) {
+        for (int b = 0; b < B; b++)
+            for (int j = 0; j < n; j++) {
+                float a = 0.0f;
+                for (int g = 0; g < Hkv; g++) a = a + h2f(c_out[((int64_t)b * Hkv + g) * n + j]);
+                t_out[(int64_t)b * n + j] = f2h(a);
+            }
+    }
+    free(pooled);
+    return FK_OK;
+}
+
+/* ---------------------------------------------------------------- canonical top-k */
+
+/* Canonical top-k of one row of fp16 scores (bit patterns): the k largest by value,
+ * ties at the k-th value resolved towards the LOWEST index.  order 0: indices ascending;
+ * order 1: value descending, index ascending among equal values (the reference's
+ * `topk(sorted=True)` order up to its arbitrary tie order, utils.py:113).
+ * Keys: fp16 -> uint16 monotone map so that NaN-free signed values order correctly. */
+static inline uint16_t mono16(uint16_t h) { return (h & 0x8000u) ? (uint16_t)~h : (uint16_t)(h | 0x8000u); }
+
+int fastkv_oracle_topk_f16(const uint16_t *scores, int64_t n, int64_t k, int order, int64_t *idx_out)
+{
+    if (!scores || !idx_out || k < 0 || k > n) return FK_EINVAL;
+    if (k == 0) return FK_OK;
+    uint32_t *hist = (uint32_t *)calloc(65536, sizeof(uint32_t));
+    if (!hist) return FK_ENOMEM;
+    for (int64_t j = 0; j < n; j++) hist[mono16(scores[j])]++;
+    int64_t above = 0; int thr = 65535;
+    for (; thr >= 0; thr--) { if (above + hist[thr] >= k) break; above += hist[thr]; }
+    int64_t quota = k - above;                       /* ties taken at key == thr */
+    if (order == 0) {
+        int64_t o = 0;
+        for (int64_t j = 0; j < n; j++) {
+            int key = mono16(scores[j]);
+            if (key > thr) idx_out[o++] = j;
+            else if (key == thr && quota > 0) { idx_out[o++] = j; quota--; }
+        }
+    } else {
+        /* counting sort by key descending, stable in index */
+        int64_t *start = (int64_t *)malloc(sizeof(int64_t) * 65536);
+        if (!start) { free(hist); return FK_ENOMEM; }
+        int64_t pos = 0;
+        for (int key = 65535; key > thr; key--) { start[key] = pos; pos += hist[key]; }
+        start[thr] = pos;
+        for (int64_t j = 0; j < n; j++) {
+            int key = mono16(scores[j]);
+            if (key > thr) idx_out[start[key]++] = j;
+            else if (key == thr && quota > 0) { idx_out[start[key]++] = j; quota--; }
+        }
+        free(start);
+    }
+    free(hist);
+    return FK_OK;
+}
+
+/* ---------------------------------------------------------------- gather / compact */
+
+/* dst[r, :] = src[idx[r] * pitch : +row_bytes]; generic row gather used for K/V rows
+ * (utils.py:114-117) and for the TSP hidden-state gather (llama_model.py:255-257). */
+int fastkv_oracle_gather_rows(const void *src, int64_t src_pitch_bytes, const int64_t *idx, int64_t nrows,
+                              int64_t row_bytes, void *dst, int64_t dst_pitch_bytes)
+{
+    if (!src || !dst || (!idx && nrows) || row_bytes < 0) return FK_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nrows; r++)
+        memcpy((char *)dst + r * dst_pitch_bytes, (const char *)src + idx[r] * src_pitch_bytes, (size_t)row_bytes);
+    return FK_OK;
+}
+
+/* ---------------------------------------------------------------- whole operator */
+
+/* FastKVCluster.update_kv compress branch (utils.py:93-132).
+ *   k_out, v_out   [B,Hkv,cap,D] contiguous fp16: rows 0..cap-W-1 = selected rows in `order`,
+ *                  rows cap-W..cap-1 = the window rows                          utils.py:114-121
+ *   kv_idx_out     [B,Hkv,cap-W] int64 (optional)
+ *   tsp_idx_out    [B,tsp_len] int64 ascending, only if tsp_len > 0 (caller applies the
+ *                  `tsp_layer and S > tsp_len` guard of utils.py:126)
+ *   scores_out     [B,Hkv,n] fp16 (optional), tsp_scores_out [B,n] fp16 (optional)
+ */
+int fastkv_oracle_update_kv_f16(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
+                                const uint16_t *v, const int64_t *vs,
+                                int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
+                                int cap, int tsp_len, int order,
+                                uint16_t *k_out, uint16_t *v_out, int64_t *kv_idx_out, int64_t *tsp_idx_out,
+                                uint16_t *scores_out, uint16_t *tsp_scores_out)
+{
+    if (!v || !k_out || !v_out || cap <= W || cap > S) return FK_EINVAL;
+    if (vs[3] != 1 || ks[3] != 1) return FK_EINVAL;
+    if (tsp_len != 0 && (tsp_len <= W || tsp_len > S || !tsp_idx_out)) return FK_EINVAL;
+    const int n = S - W, kk = cap - W;
+    uint16_t *c = scores_out ? scores_out : (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B * Hkv * n);
+    uint16_t *t = NULL;
+    if (tsp_len) t = tsp_scores_out ? tsp_scores_out : (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B * n);
+    int64_t *idx = kv_idx_out ? kv_idx_out : (int64_t *)malloc(sizeof(int64_t) * (size_t)B * Hkv * kk);
+    if (!c || !idx || (tsp_len && !t)) return FK_ENOMEM;
+    int rc = fastkv_oracle_scores_f16(q, qs, k, ks, B, H, Hkv, S, D, W, ksize, pooling, c, t, NULL);
+    if (rc == FK_OK) {
+        for (int bg = 0; bg < B * Hkv && rc == FK_OK; bg++) {
+            int b = bg / Hkv, g = bg % Hkv;
+            int64_t *ib = idx + (int64_t)bg * kk;
+            rc = fastkv_oracle_topk_f16(c + (int64_t)bg * n, n, kk, order, ib);
+            if (rc != FK_OK) break;
+            const uint16_t *ksrc = k + b * ks[0] + g * ks[1], *vsrc = v + b * vs[0] + g * vs[1];
+            uint16_t *kd = k_out + (int64_t)bg * cap * D, *vd = v_out + (int64_t)bg * cap * D;
+            fastkv_oracle_gather_rows(ksrc, ks[2] * 2, ib, kk, (int64_t)D * 2, kd, (int64_t)D * 2);
+            fastkv_oracle_gather_rows(vsrc, vs[2] * 2, ib, kk, (int64_t)D * 2, vd, (int64_t)D * 2);
+            for (int w = 0; w < W; w++) {
+                memcpy(kd + (int64_t)(kk + w) * D, ksrc + (int64_t)(n + w) * ks[2], (size_t)D * 2);
+                memcpy(vd + (int64_t)(kk + w) * D, vsrc + (int64_t)(n + w) * vs[2], (size_t)D * 2);
+            }
+        }
+        if (rc == FK_OK && tsp_len) {
+            for (int b = 0; b < B && rc == FK_OK; b++) {
+                int64_t *tb = tsp_idx_out + (int64_t)b * tsp_len;
+                rc = fastkv_oracle_topk_f16(t + (int64_t)b * n, n, tsp_len - W, 0, tb);   /* ascending */
+                for (int w = 0; w < W; w++) tb[tsp_len - W + w] = n + w;                   /* window is > every candidate */
+            }
+        }
+    }
+    if (!scores_out) free(c);
+    if (tsp_len && !tsp_scores_out) free(t);
+    if (!kv_idx_out) free(idx);
+    return rc;
+}
+
+/* exposed scalar helpers so the tests can pin the arithmetic contract element-wise */
+float fastkv_oracle_det_expf(float d) { return det_expf(d); }
+float fastkv_oracle_fix_to_f32(uint64_t s) { return fix_to_f32(s); }
+uint64_t fastkv_oracle_exp_to_fix(float e) { uint32_t hi, lo; exp_to_fix(e, &hi, &lo); return ((uint64_t)hi << 24) + lo; }
+uint16_t fastkv_oracle_f2h(float f) { return f2h(f); }
+float fastkv_oracle_h2f(uint16_t h) { return h2f(h); }
+uint16_t fastkv_oracle_scale_logit(uint16_t l16, int D) { return f2h(h2f(l16) / (float)sqrt((double)D)); }
+
+void fastkv_oracle_set_threads(int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+}
+int fastkv_oracle_get_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

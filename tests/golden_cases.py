@@ -1,0 +1,48 @@
+"""Case table shared by tests/golden/make_golden.py (capture) and the parity tests (replay).
+
+Shapes follow BASELINE.json's configs: cfg1 = Llama-3-8B 4k / budget 512,
+cfg2 = Llama-3-8B 32k / budget 2048 / TSP length 2048, cfg5 = one TP rank of Llama-3-70B.
+`store_scores`: "full" keeps the reference's whole score tensors in the fixture; an integer N
+keeps every N-th element (the big cases are pinned through their canonical indices instead).
+"""
+
+CASES = {
+    # small, everything stored; B=2 exercises the per-batch-row TSP index
+    "tiny_avg": dict(seed=3, B=2, H=8, Hkv=2, S=640, D=128, W=8, ks=7, pooling="avgpool", cap=96, tsp_len=160),
+    "tiny_max": dict(seed=4, B=2, H=8, Hkv=2, S=640, D=128, W=8, ks=5, pooling="maxpool", cap=96, tsp_len=160),
+    # ragged length (S not a multiple of any tile), MHA (G=1), D=64
+    "ragged_mha_d64": dict(seed=5, B=1, H=4, Hkv=4, S=777, D=64, W=8, ks=7, pooling="avgpool", cap=100, tsp_len=300),
+    # G=8 (cfg5 rank geometry: H=8, Hkv=1), wider window
+    "gqa8_w16": dict(seed=6, B=1, H=8, Hkv=1, S=1500, D=128, W=16, ks=7, pooling="maxpool", cap=144, tsp_len=400),
+    # k == n permutation case (post-TSP layers): S == cap, TSP still evaluated
+    "k_eq_n": dict(seed=7, B=1, H=8, Hkv=2, S=256, D=128, W=8, ks=7, pooling="avgpool", cap=256, tsp_len=64),
+    # non-TSP layer
+    "no_tsp": dict(seed=8, B=1, H=8, Hkv=2, S=1024, D=128, W=8, ks=7, pooling="maxpool", cap=128, tsp_len=0),
+    # BASELINE.json configs[0]
+    "cfg1": dict(seed=0, B=1, H=32, Hkv=8, S=4096, D=128, W=8, ks=7, pooling="maxpool", cap=512, tsp_len=2048),
+    # BASELINE.json configs[1]
+    "cfg2_max": dict(seed=0, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="maxpool", cap=2048, tsp_len=2048,
+                     store_scores="full"),
+    "cfg2_avg_peaked": dict(seed=2, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="avgpool", cap=2048,
+                            tsp_len=2048, peaked=3000, store_scores=16),
+    # the published recipe at 32k: proportional retain 0.1 / tsp_rate 0.2 -> cap 3276, tsp_len 6553
+    "cfg2_recipe": dict(seed=1, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="avgpool", cap=3276,
+                        tsp_len=6553, store_scores=16),
+}
+
+HOST_CASES = {
+    "update_kv_host": {
+        "early_out": dict(S=300, cap=512, tsp_layer=True, tsp_len=128),                       # utils.py:89-91
+        "s_eq_cap": dict(S=512, cap=512, tsp_layer=True, tsp_len=128),                        # compress, k == n
+        "s_eq_tsp": dict(S=600, cap=128, tsp_layer=True, tsp_len=600),                        # strict > at utils.py:126
+        "not_tsp_layer": dict(S=600, cap=128, tsp_layer=False, tsp_len=128),
+        "proportional": dict(S=1000, cap=512, tsp_layer=True, tsp_len=2048, mode="proportional", retain_rate=0.1, tsp_rate=0.2),
+        "proportional_post_tsp": dict(S=655, cap=512, tsp_layer=False, tsp_len=2048, mode="proportional", retain_rate=0.5, tsp_rate=0.2),
+    },
+    "compress_fastkv": {
+        "published": dict(layers=32, window_size=8, kernel_size=7, pooling="avgpool", max_capacity_prompts=512, tsp_len=2048,
+                          tsp_rate=0.2, eviction_mode="proportional", tsp_idx=15, retain_rate=0.1),
+        "constant": dict(layers=32, window_size=8, kernel_size=7, pooling="maxpool", max_capacity_prompts=2048, tsp_len=2048,
+                         tsp_rate=0.2, eviction_mode="constant", tsp_idx=15, retain_rate=0.1),
+    },
+}

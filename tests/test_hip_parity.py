@@ -1,0 +1,176 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs, and
+against the golden vectors captured from the reference.  Bit-exact: scores, indices, K/V rows."""
+import numpy as np
+import pytest
+import torch
+
+from gen_inputs import make_qkv
+from golden_cases import CASES
+from helpers import expected_kv, f16_from_bits, load_golden, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [c for c in CASES if CASES[c]["S"] <= 4096]
+BIG = [c for c in CASES if CASES[c]["S"] > 4096]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _to_dev(t, dev):
+    # keep the [B,S,H,D]-physical / [B,H,S,D]-logical layout (llama_model.py:117-122)
+    return t.transpose(1, 2).contiguous().to(dev).transpose(1, 2)
+
+
+def _run_both(name, dev, order):
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    case = CASES[name]
+    q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"],
+                       peaked=case.get("peaked", 0))
+    ref = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], order, return_scores=True)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    assert kd.stride() == k.stride()
+    got = ops.update_kv(qd, kd, vd, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], order,
+                        return_indices=True, return_scores=True)
+    torch.cuda.synchronize()
+    return case, (q, k, v), ref, got
+
+
+@pytest.mark.parametrize("order", ["index", "score"])
+@pytest.mark.parametrize("name", SMALL + BIG)
+def test_update_kv_bit_exact_vs_oracle(name, order, dev):
+    case, (q, k, v), (ko, vo, idx, tsp, c, t), (gko, gvo, gtsp, gidx, gc) = _run_both(name, dev, order)
+    assert torch.equal(gc.cpu().view(torch.int16), c.view(torch.int16)), "scores differ from the oracle (bit patterns)"
+    assert torch.equal(gidx.cpu(), idx), "per-head indices differ from the oracle"
+    assert torch.equal(gko.cpu(), ko) and torch.equal(gvo.cpu(), vo), "compacted K/V differ"
+    assert gko.is_contiguous() and gko.dtype == torch.float16 and list(gko.shape) == list(ko.shape)
+    if case["tsp_len"]:
+        assert gtsp.dtype == torch.int64 and torch.equal(gtsp.cpu(), tsp)
+    else:
+        assert gtsp is None
+
+
+@pytest.mark.parametrize("name", SMALL + BIG)
+def test_update_kv_vs_reference_golden(name, dev):
+    """Directly against what the reference produced: canonical top-k of ITS scores, its TSP index, score ulps."""
+    case, (q, k, v), _, (gko, gvo, gtsp, gidx, gc) = _run_both(name, dev, "index")
+    g = load_golden(name)
+    assert torch.equal(gidx.cpu(), torch.from_numpy(g["idx_canonical"].astype(np.int64)))
+    if case["tsp_len"]:
+        assert torch.equal(gtsp.cpu(), torch.from_numpy(g["tsp_canonical"].astype(np.int64)))
+    if "c_ref" in g:
+        d = ulp_diff(gc.cpu(), f16_from_bits(g["c_ref"]))
+        assert int(d.max()) <= 1 and int((d > 0).sum()) <= max(1, int(0.001 * d.numel()))
+    # compressed KV values vs the reference rows, canonical order: exact (tolerance 1e-3 in the north star is slack)
+    want = expected_kv(k, torch.from_numpy(g["idx_canonical"].astype(np.int64)), case["W"])
+    assert torch.allclose(gko.cpu().float(), want.float(), atol=1e-3, rtol=0) and torch.equal(gko.cpu(), want)
+
+
+def test_stage_apis_and_properties(dev):
+    """score / select / compact separately, plus size-independent properties of the selection."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    q, k, v = make_qkv(21, 1, 8, 2, 3000, 128, 8)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    c, t = ops.scores(qd, kd, 8, 7, "maxpool")
+    co, to, _ = O.scores(q, k, 8, 7, "maxpool")
+    assert torch.equal(c.cpu().view(torch.int16), co.view(torch.int16)) and torch.equal(t.cpu().view(torch.int16), to.view(torch.int16))
+    n = c.shape[-1]
+    for kk in (1, 5, 1024, 1025, n - 1, n):
+        for order in ("index", "score"):
+            idx = ops.select(c[0], kk, order).cpu()
+            for g in range(2):
+                assert torch.equal(idx[g], O.canonical_topk(co[0, g].contiguous(), kk, order)), (kk, order)
+    # k == n is a permutation; index order is sorted; idempotence on the selected scores
+    full = ops.select(c[0], n, "score").cpu()
+    assert torch.equal(torch.sort(full, dim=1).values, torch.arange(n).expand(2, -1))
+    idx = ops.select(c[0], 500, "index")
+    assert bool((idx[:, 1:] > idx[:, :-1]).all())
+    sub = torch.gather(c[0], 1, idx)
+    assert torch.equal(torch.sort(ops.select(sub, 500, "index"), dim=1).values.cpu(), torch.arange(500).expand(2, -1))
+    # append = window union of the TSP index (utils.py:128-129)
+    ti = ops.select(t, 100, "index", append=8).cpu()
+    assert torch.equal(ti[0, -8:], torch.arange(n, n + 8))
+    # compact with explicit indices
+    idx3 = ops.select(c[0], 200, "score")[None]
+    ko, vo = ops.compact(kd, vd, idx3.contiguous(), 8)
+    assert torch.equal(ko.cpu(), expected_kv(k, idx3.cpu(), 8)) and torch.equal(vo.cpu(), expected_kv(v, idx3.cpu(), 8))
+
+
+def test_degenerate_rows(dev):
+    """All-equal scores (the reference benchmark's all-ones prompt) and heavy ties: canonical = lowest positions."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    z = torch.zeros(3, 40000, dtype=torch.float16, device=dev)
+    idx = ops.select(z, 2040, "score").cpu()
+    assert torch.equal(idx, torch.arange(2040).expand(3, -1))
+    r = (torch.arange(40000) % 7).to(torch.float16)[None].to(dev)
+    for order in ("index", "score"):
+        got = ops.select(r, 9000, order).cpu()[0]
+        assert torch.equal(got, O.canonical_topk(r[0].cpu().contiguous(), 9000, order))
+    # identical K rows (all-ones prompt): every key scores the same -> first k positions + window
+    q, k, v = make_qkv(5, 1, 8, 2, 2048, 128, 8)
+    k = k.clone(); k[:] = k[:, :, :1]
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    ko, vo, tsp, kvi = ops.update_kv(qd, kd, vd, 8, 7, "avgpool", 256, 512, "score", return_indices=True)
+    want = O.update_kv(q, k, v, 8, 7, "avgpool", 256, 512, "score")
+    assert torch.equal(kvi.cpu(), want[2]) and torch.equal(tsp.cpu(), want[3])
+
+
+def test_gather_rows_tsp_propagation(dev):
+    """hidden.gather(1, tsp_idx[...,None].expand(..)) of llama_model.py:255-257."""
+    from fastkv_amd import ops
+    h = torch.randn(2, 700, 4096, dtype=torch.float16, device=dev)
+    idx = torch.stack([torch.sort(torch.randperm(700, device=dev)[:333]).values for _ in range(2)])
+    out = ops.gather_rows(h, idx)
+    assert torch.equal(out, torch.gather(h, 1, idx[..., None].expand(-1, -1, 4096)))
+
+
+def test_cluster_dropin_matches_oracle_cluster(dev):
+    """FastKVCluster.update_kv end to end incl. host logic: early-out identity, proportional mode, TSP guard."""
+    from fastkv_amd import FastKVCluster
+    from oracle.fastkv_oracle import OracleFastKVCluster
+    q, k, v = make_qkv(9, 1, 8, 2, 1000, 128, 8)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    for kw in (dict(max_capacity_prompt=128, tsp_layer=True, tsp_length=256, pooling="maxpool"),
+               dict(max_capacity_prompt=128, tsp_layer=False, pooling="avgpool"),
+               dict(max_capacity_prompt=512, tsp_layer=True, tsp_length=2048, eviction_mode="proportional", retain_rate=0.1, tsp_rate=0.2),
+               dict(max_capacity_prompt=1000, tsp_layer=True, tsp_length=999),
+               dict(max_capacity_prompt=128, tsp_layer=True, tsp_length=1000)):
+        a, b = FastKVCluster(**kw), OracleFastKVCluster(**kw)
+        ka, va, ta = a.update_kv(kd, qd, vd, None, 4, 0)
+        kb, vb, tb = b.update_kv(k, q, v, None, 4, 0)
+        assert torch.equal(ka.cpu(), kb) and torch.equal(va.cpu(), vb)
+        assert (ta is None) == (tb is None) and (ta is None or torch.equal(ta.cpu(), tb))
+        assert a.max_capacity_prompt == b.max_capacity_prompt and a.tsp_length == b.tsp_length
+    c = FastKVCluster(max_capacity_prompt=2048)
+    ka, va, ta = c.update_kv(kd, qd, vd, None, 4, 0)
+    assert ka is kd and va is vd and ta is None                     # utils.py:89-91 returns the input objects
+
+
+def test_determinism(dev):
+    from fastkv_amd import ops
+    q, k, v = make_qkv(33, 1, 32, 8, 8192, 128, 8)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    outs = [ops.update_kv(qd, kd, vd, 8, 7, "maxpool", 1024, 2048, "score", return_indices=True, return_scores=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
+def test_bad_arguments_raise(dev):
+    from fastkv_amd import FastKVCluster, ops
+    from fastkv_amd._lib import FastKVNativeError
+    q, k, v = make_qkv(1, 1, 4, 2, 600, 128, 8)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    with pytest.raises(ValueError, match="Pooling method not supported"):
+        FastKVCluster(max_capacity_prompt=64, pooling="l2pool").update_kv(kd, qd, vd, None, 2, 0)
+    with pytest.raises(FastKVNativeError):
+        ops.update_kv(qd, kd, vd, 8, 6, "avgpool", 64)            # even kernel size
+    with pytest.raises(RuntimeError):
+        ops.update_kv(q, k, v, 8, 7, "avgpool", 64)               # CPU tensors: no fallback

@@ -1,0 +1,108 @@
+"""CPU-side checks: host logic of the drop-in cluster against the reference's recorded behaviour
+(tests/golden/meta.json "host"), the C-ABI library's exported symbols, and the no-fallback rule."""
+import ctypes
+import os
+import re
+import types
+
+import pytest
+import torch
+
+from golden_cases import HOST_CASES
+from helpers import ROOT, load_meta
+
+
+def test_plan_matches_reference_host_behaviour():
+    from fastkv_amd import FastKVCluster
+    host = load_meta()["host"]
+    for name, hc in HOST_CASES["update_kv_host"].items():
+        cl = FastKVCluster(window_size=8, max_capacity_prompt=hc["cap"], kernel_size=7, pooling="avgpool",
+                           tsp_layer=hc["tsp_layer"], tsp_length=hc["tsp_len"], tsp_rate=hc.get("tsp_rate", 0.25),
+                           retain_rate=hc.get("retain_rate", 0.25), eviction_mode=hc.get("mode", "constant"))
+        plan = cl.plan(hc["S"])
+        want = host[name]
+        assert plan.early_out == want["same_k_object"], name
+        assert cl.max_capacity_prompt == want["max_capacity_prompt_after"], name
+        assert cl.tsp_length == want["tsp_length_after"], name
+        if not plan.early_out:
+            assert want["k_shape"][2] == plan.capacity, name
+            assert (plan.tsp_len == 0) == want["tsp_is_none"], name
+            if plan.tsp_len:
+                assert want["tsp_shape"][1] == plan.tsp_len, name
+
+
+def test_early_out_returns_same_objects_without_gpu():
+    from fastkv_amd import FastKVCluster
+    k = torch.zeros(1, 2, 100, 128, dtype=torch.float16)
+    q = torch.zeros(1, 4, 100, 128, dtype=torch.float16)
+    v = torch.zeros_like(k)
+    ko, vo, t = FastKVCluster(max_capacity_prompt=512).update_kv(k, q, v, None, 2, 0)
+    assert ko is k and vo is v and t is None
+    with pytest.raises(AssertionError):
+        FastKVCluster().update_kv(k[:, :, :50], q, v, None, 2, 0)          # utils.py:82
+
+
+def test_constructor_assertion_and_pooling_error():
+    from fastkv_amd import FastKVCluster
+    host = load_meta()["host"]
+    assert host["cap_le_window_error"] == ["AssertionError"]
+    with pytest.raises(AssertionError):
+        FastKVCluster(window_size=8, max_capacity_prompt=8)
+    assert host["bad_pooling_error"] == ["ValueError", "Pooling method not supported"]
+    with pytest.raises(ValueError, match="Pooling method not supported"):
+        FastKVCluster(max_capacity_prompt=64, pooling="l2pool").plan(600)
+
+
+def test_compress_fastkv_attribute_push_matches_reference():
+    from fastkv_amd import FastKVCluster, compress_fastkv
+    host = load_meta()["host"]
+    for name, a in HOST_CASES["compress_fastkv"].items():
+        layers = [types.SimpleNamespace(self_attn=types.SimpleNamespace(kv_cluster=FastKVCluster())) for _ in range(a["layers"])]
+        model = types.SimpleNamespace(model=types.SimpleNamespace(layers=layers))
+        args = types.SimpleNamespace(window_size=[a["window_size"]] * a["layers"], kernel_size=[a["kernel_size"]] * a["layers"],
+                                     pooling=a["pooling"], max_capacity_prompts=a["max_capacity_prompts"], tsp_len=a["tsp_len"],
+                                     tsp_rate=a["tsp_rate"], eviction_mode=a["eviction_mode"], tsp_idx=a["tsp_idx"],
+                                     retain_rate=a["retain_rate"])
+        compress_fastkv(model, args)
+        for i, want in enumerate(host["compress_" + name]):
+            got = vars(layers[i].self_attn.kv_cluster)
+            for key, val in want.items():
+                assert got[key] == val, (name, i, key)
+
+
+def test_capi_library_exports_every_declared_symbol():
+    """The C-ABI .so loads on a CPU-only machine and exports exactly what include/fastkv_hip.h declares."""
+    from fastkv_amd import _build, _lib
+    path = _build.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "fastkv_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fastkv_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    L = _lib.load()
+    assert L.fastkv_version().decode().startswith("fastkv-hip")
+    assert L.fastkv_strerror(-2).decode().startswith("workspace")
+    p = _lib.Problem(B=1, H=32, Hkv=8, S=32768, D=128, window=8, kernel=7, pooling=1, capacity=2048, tsp_len=2048, order=1, reserved=0)
+    nbytes = L.fastkv_workspace_bytes(ctypes.byref(p))
+    assert 16 * 2**20 < nbytes < 64 * 2**20                              # logits (16 MiB) dominate
+    p.D = 100
+    assert L.fastkv_workspace_bytes(ctypes.byref(p)) == 0                # unsupported head_dim
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under fastkv_amd/ or baselines/ may import, include or load it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|#include\s*[<\"][^>\"]*oracle|libfastkv_oracle|fastkv_oracle_", re.M)
+    for top in ("fastkv_amd", "baselines", "benchmark"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                    assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
+
+
+def test_cpu_tensors_are_rejected_not_emulated():
+    from fastkv_amd import ops
+    k = torch.zeros(1, 2, 600, 128, dtype=torch.float16)
+    q = torch.zeros(1, 4, 600, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.update_kv(q, k, k, 8, 7, "avgpool", 64)
