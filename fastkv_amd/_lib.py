@@ -21,7 +21,7 @@ class Problem(ctypes.Structure):
 
 
 EXPORTS = ["fastkv_workspace_bytes", "fastkv_update_kv_f16", "fastkv_score_f16", "fastkv_select_f16",
-           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_strerror", "fastkv_version"]
+           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_debug_contract", "fastkv_strerror", "fastkv_version"]
 
 _lib = None
 
@@ -54,6 +54,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_compact_f16.restype = ci
     L.fastkv_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp]
     L.fastkv_gather_rows.restype = ci
+    L.fastkv_debug_contract.argtypes = [ci, vp, vp, vp, vp, ci, vp]
+    L.fastkv_debug_contract.restype = ci
     L.fastkv_strerror.argtypes = [ci]
     L.fastkv_strerror.restype = ctypes.c_char_p
     L.fastkv_version.argtypes = []

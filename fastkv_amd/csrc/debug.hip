@@ -1,0 +1,33 @@
+// Test hook: evaluates the primitives of the arithmetic contract (fk_device.h) element-wise on the GPU so that
+// tests can compare them bit-for-bit with their twins in oracle/fastkv_oracle.c.  Not used by the product path.
+#include "fk_device.h"
+#include "fk_host.h"
+
+namespace fk {
+__global__ void debug_contract_kernel(int op, const float *a, const float *b, float *out, uint64_t *out64, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+    uint64_t r64 = 0;
+    switch (op) {
+    case 0: r = det_expf(x); break;
+    case 1: r = x / y; break;
+    case 2: r = h2f(f2h(x)); break;
+    case 3: { uint32_t hi, lo; exp_to_fix(x, hi, lo); r64 = ((uint64_t)hi << 24) + lo; r = fix_to_f32(r64); break; }
+    case 4: r = __builtin_fmaf(x, y, out[i]); break;
+    case 5: r = fix_to_f32(((uint64_t)f32_bits(x) << 32) | f32_bits(y)); break;
+    case 6: r = x * y; break;
+    case 7: r = x + y; break;
+    }
+    out[i] = r;
+    if (out64) out64[i] = r64;
+}
+}  // namespace fk
+
+extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream)
+{
+    if (!a || !out || n < 0 || op < 0 || op > 7) return FASTKV_EINVAL;
+    hipLaunchKernelGGL(fk::debug_contract_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, out64, n);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}

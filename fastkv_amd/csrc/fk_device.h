@@ -14,7 +14,14 @@
 namespace fk {
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// fp32 -> fp16, round to nearest even.  The empty asm makes the fp32 value opaque: without it the compiler folds
+// `(_Float16)(a * b)` into v_fma_mixlo_f16, which rounds the exact product ONCE to fp16, whereas the reference
+// (fp32 tensor, then .to(fp16)) and the oracle round twice -- a 1-ulp difference in ~1e-4 of the elements.
+__device__ __forceinline__ uint16_t f2h(float f)
+{
+    asm("" : "+v"(f));
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
 __device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 

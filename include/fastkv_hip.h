@@ -112,6 +112,13 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
                        const int64_t *idx, int64_t idx_batch_stride, int64_t batches, int64_t rows_out,
                        int64_t rows_in, int64_t row_bytes, void *dst, void *stream);
 
+/*
+ * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
+ * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
+ * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b) so tests can compare the GPU bit-for-bit with the CPU oracle.
+ */
+int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream);
+
 const char *fastkv_strerror(int code);
 /* "fastkv-hip <version> gfx950" */
 const char *fastkv_version(void);
