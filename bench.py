@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- FastKV hot path on MI355X: prefill hot-path throughput + per-kernel roofline + CPU baseline.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run, one rank per GPU).
+One STEP = the whole FastKV hot path of ONE Llama-3-8B prefill at 32k context (BASELINE.json configs[1]:
+TSP layer 15, budget 2048, window 8, kernel 7, maxpool, fp16):
+    layers 0..15   update_kv at S=32768 (score -> select -> compact), layer 15 also produces the TSP index
+    TSP propagation  hidden [1,32768,4096] -> [1,2048,4096] row gather (llama_model.py:252-259)
+    layers 16..31  update_kv at S=2048 (k == n permutation case)
+on synthetic fp16 Q/K/V (seeded torch.randn on the device, one distinct tensor set per layer so nothing is
+cache-resident across layers), inputs already in HBM.  `value` = prompt tokens / hot-path time, summed over ranks.
+N>1: every rank runs its own prompt (independent prompts shard with no exchange) -> weak scaling.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel (score_logits): algorithmic bytes (K once + Q window) / average launch duration
+                measured with HIP events on the launch stream during an instrumented replay of the same steps.
+  kernels       every kernel: launches per step, average microseconds (same instrumented replay).
+  compact       the KV gather/compact kernel: per-layer latency at this config and GB/s at the "roofline shape"
+                (same row geometry, 32 layers' worth in one launch, beyond the 256 MiB Infinity Cache).
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's update_kv) timed on this box's host cores on a
+                bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+CFG = dict(model="Llama-3-8B (geometry only)", H=32, Hkv=8, D=128, hidden=4096, layers=32, S=32768, window=8, kernel=7,
+           pooling="maxpool", budget=2048, tsp_len=2048, tsp_idx=15)
+HBM_PEAK_GBPS = 8000.0        # MI355X spec (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def make_layer_inputs(S, gen, dev):
+    """[B,S,H,D]-physical / [B,H,S,D]-logical fp16 tensors, as the attention module produces them."""
+    H, Hkv, D = CFG["H"], CFG["Hkv"], CFG["D"]
+    q = torch.randn(1, S, H, D, generator=gen, device=dev, dtype=torch.float16).transpose(1, 2)
+    k = torch.randn(1, S, Hkv, D, generator=gen, device=dev, dtype=torch.float16).transpose(1, 2)
+    v = torch.randn(1, S, Hkv, D, generator=gen, device=dev, dtype=torch.float16).transpose(1, 2)
+    return q, k, v
+
+
+class HotPathPrefill:
+    def __init__(self, dev, seed):
+        from fastkv_amd import FastKVCluster, compress_fastkv
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        L, S = CFG["layers"], CFG["S"]
+        self.layers_in = []
+        for i in range(L):
+            s_i = S if i <= CFG["tsp_idx"] else CFG["tsp_len"]
+            self.layers_in.append(make_layer_inputs(s_i, gen, dev))
+        self.hidden = torch.randn(1, S, CFG["hidden"], generator=gen, device=dev, dtype=torch.float16)
+        self.position_ids = torch.arange(S, device=dev)[None]
+        # configuration pushed exactly like benchmark/prefill.py -> set_model -> compress_fastkv (utils.py:25-46)
+        layers = [types.SimpleNamespace(self_attn=types.SimpleNamespace(kv_cluster=FastKVCluster())) for _ in range(L)]
+        self.model = types.SimpleNamespace(model=types.SimpleNamespace(layers=layers))
+        args = types.SimpleNamespace(window_size=[CFG["window"]] * L, kernel_size=[CFG["kernel"]] * L, pooling=CFG["pooling"],
+                                     max_capacity_prompts=CFG["budget"], tsp_len=CFG["tsp_len"], tsp_rate=0.2,
+                                     eviction_mode="constant", tsp_idx=CFG["tsp_idx"], retain_rate=0.1)
+        compress_fastkv(self.model, args)
+        self.clusters = [l.self_attn.kv_cluster for l in layers]
+
+    def step(self):
+        from fastkv_amd import ops
+        G = CFG["H"] // CFG["Hkv"]
+        cache = []
+        hidden = None
+        for i, (q, k, v) in enumerate(self.layers_in):
+            ko, vo, tsp = self.clusters[i].update_kv(k, q, v, None, G, i)
+            cache.append((ko, vo))
+            if self.clusters[i].tsp_layer and tsp is not None:
+                hidden = ops.gather_rows(self.hidden, tsp)                   # llama_model.py:255-257
+                _pos = torch.gather(self.position_ids, 1, tsp)               # llama_model.py:254 (16 KiB)
+        return cache, hidden
+
+
+def profile_read(lib):
+    n = lib.fastkv_profile_kernels()
+    counts = (ctypes.c_int64 * n)()
+    ms = (ctypes.c_double * n)()
+    rc = lib.fastkv_profile_read(counts, ms)
+    assert rc == 0
+    return {lib.fastkv_profile_kernel_name(i).decode(): (int(counts[i]), float(ms[i])) for i in range(n)}
+
+
+def compact_roofline_shape(lib, dev, steps):
+    """Same row geometry as the 32k config (256-B rows at 2 KiB pitch, 2040+8 rows per head) but 32 'layers' in one
+    launch: 2 x 2 GiB sources, 539 MB of algorithmic traffic, nothing served from the 256 MiB Infinity Cache."""
+    from fastkv_amd import ops
+    B, Hkv, S, D, W, cap = 32, CFG["Hkv"], CFG["S"], CFG["D"], CFG["window"], CFG["budget"]
+    k = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
+    v = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
+    sc = torch.rand(B * Hkv, S - W, device=dev).half()
+    idx = ops.select(sc, cap - W, "score").view(B, Hkv, cap - W).contiguous()     # realistic per-head index sets
+    for _ in range(2):
+        ops.compact(k, v, idx, W)
+    torch.cuda.synchronize()
+    profile_read(lib)
+    lib.fastkv_profile_enable(1)
+    for _ in range(steps):
+        ops.compact(k, v, idx, W)
+    torch.cuda.synchronize()
+    lib.fastkv_profile_enable(0)
+    cnt, ms = profile_read(lib)["compact_kv"]
+    nbytes = 2 * (2 * B * Hkv * cap * D * 2) + B * Hkv * (cap - W) * 8
+    us = ms / cnt * 1e3
+    del k, v
+    return {"shape": f"B={B} (32 layers stacked), Hkv={Hkv}, S={S}, D={D}, cap={cap}", "bytes": nbytes, "avg_us": round(us, 2),
+            "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1), "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def cpu_baseline(work: HotPathPrefill):
+    """CPU oracle (port of utils.py:80-134) on host cores: 2 pre-TSP layers + 2 post-TSP layers + the hidden gather,
+    scaled to the 16 + 16 layers of one step."""
+    from oracle import fastkv_oracle as O
+    from oracle.fastkv_oracle import OracleFastKVCluster
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    G = CFG["H"] // CFG["Hkv"]
+
+    def cpu_layer(i):
+        q, k, v = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[i])
+        c = work.clusters[i]
+        oc = OracleFastKVCluster(c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.tsp_layer, c.tsp_length,
+                                 c.tsp_rate, c.retain_rate, c.eviction_mode)
+        oc.update_kv(k, q, v, None, G, i)                                    # warm-up (page-in, thread pool)
+        t0 = time.perf_counter()
+        out = oc.update_kv(k, q, v, None, G, i)
+        return time.perf_counter() - t0, out
+
+    t_pre = [cpu_layer(i)[0] for i in (0, 1)]
+    t_tsp, out = cpu_layer(CFG["tsp_idx"])
+    t_post = [cpu_layer(i)[0] for i in (16, 17)]
+    hid = work.hidden[0].cpu()
+    t0 = time.perf_counter()
+    O.gather_rows(hid, out[2][0].contiguous())
+    t_g = time.perf_counter() - t0
+    step_s = 15 * (sum(t_pre) / 2) + t_tsp + 16 * (sum(t_post) / 2) + t_g
+    return {"value": round(CFG["S"] / step_s, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "ms_per_step": round(step_s * 1e3, 1),
+            "sample": "oracle update_kv: layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, 1 warm-up + 1 timed "
+                      "each, scaled to 15+1+16 layers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the instrumented replay / roofline-shape / CPU legs")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fastkv_amd._lib import load
+    lib = load()
+    work = HotPathPrefill(dev, seed=1000 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        work.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        work.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * CFG["S"] / (ms_per_step * 1e-3)
+
+    out = {"metric": "prefill_hotpath_tokens_per_s", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "FastKV hot path (score+select+compact, 32 layers + TSP gather) of one Llama-3-8B prefill, "
+                                  "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
+                      "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
+           "ttft_hotpath_ms": round(ms_per_step, 4)}
+
+    if not a.no_extras:
+        # instrumented replay of the same steps: per-kernel HIP-event durations on the launch stream
+        profile_read(lib)
+        lib.fastkv_profile_enable(1)
+        for _ in range(a.steps):
+            work.step()
+        torch.cuda.synchronize()
+        lib.fastkv_profile_enable(0)
+        prof = profile_read(lib)
+        kern = {n: {"launches_per_step": c / a.steps, "avg_us": round(ms / c * 1e3, 2), "us_per_step": round(ms / a.steps * 1e3, 1)}
+                for n, (c, ms) in prof.items() if c}
+        out["kernels"] = kern
+        # dominant kernel: score_logits at S=32768 (the 16 post-TSP launches stream only 4 MiB each -> time-weighted split)
+        S, Hkv, D, H, W = CFG["S"], CFG["Hkv"], CFG["D"], CFG["H"], CFG["window"]
+        if rank == 0:
+            lib.fastkv_profile_enable(1)
+            q, k, v = work.layers_in[0]
+            from fastkv_amd import ops
+            for i in range(8):
+                ops.scores(*work.layers_in[i][:2], W, CFG["kernel"], CFG["pooling"], want_tsp=False)
+            torch.cuda.synchronize()
+            lib.fastkv_profile_enable(0)
+            p2 = profile_read(lib)
+            c, ms = p2["score_logits"]
+            us = ms / c * 1e3
+            alg = Hkv * S * D * 2 + H * W * D * 2
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("score_logits_hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": "score_logits (S=32768 launches)", "bound": "hbm", "achieved": round(alg / (us * 1e-6) / 1e9, 1),
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
+                               "note": "fp32-FMA co-limited (no MFMA): 8192 flop per 256-B key row"}
+            cc, cms = prof["compact_kv"]
+            out["compact"] = {"per_layer_avg_us": round(cms / cc * 1e3, 2),
+                              "per_layer_algorithmic_bytes": 2 * (2 * Hkv * CFG["budget"] * D * 2) + Hkv * (CFG["budget"] - W) * 8,
+                              "roofline_shape": compact_roofline_shape(lib, dev, 10)}
+            if world == 1 and not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(work)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -21,7 +21,8 @@ class Problem(ctypes.Structure):
 
 
 EXPORTS = ["fastkv_workspace_bytes", "fastkv_update_kv_f16", "fastkv_score_f16", "fastkv_select_f16",
-           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_debug_contract", "fastkv_strerror", "fastkv_version"]
+           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_debug_contract", "fastkv_profile_enable",
+           "fastkv_profile_kernels", "fastkv_profile_kernel_name", "fastkv_profile_read", "fastkv_strerror", "fastkv_version"]
 
 _lib = None
 
@@ -56,6 +57,13 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_gather_rows.restype = ci
     L.fastkv_debug_contract.argtypes = [ci, vp, vp, vp, vp, ci, vp]
     L.fastkv_debug_contract.restype = ci
+    L.fastkv_profile_enable.argtypes = [ci]
+    L.fastkv_profile_enable.restype = None
+    L.fastkv_profile_kernels.restype = ci
+    L.fastkv_profile_kernel_name.argtypes = [ci]
+    L.fastkv_profile_kernel_name.restype = ctypes.c_char_p
+    L.fastkv_profile_read.argtypes = [vp, vp]
+    L.fastkv_profile_read.restype = ci
     L.fastkv_strerror.argtypes = [ci]
     L.fastkv_strerror.restype = ctypes.c_char_p
     L.fastkv_version.argtypes = []

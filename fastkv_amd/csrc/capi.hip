@@ -13,6 +13,8 @@ int check_problem(const fastkv_problem *p)
     if (p->B < 1 || p->Hkv < 1 || p->H < p->Hkv || (p->H % p->Hkv) != 0) return FASTKV_EINVAL;
     if (p->D != 64 && p->D != 128 && p->D != 256) return FASTKV_EUNSUPPORTED;
     if (p->window < 1 || p->window > 64 || p->S <= p->window) return FASTKV_EINVAL;
+    if ((p->H / p->Hkv) * p->window > 1024) return FASTKV_EUNSUPPORTED;
+    if ((p->reserved & 3) == 3 || (p->reserved & ~3)) return FASTKV_EINVAL;
     if (p->kernel < 1 || (p->kernel & 1) == 0 || p->kernel > 63) return FASTKV_EINVAL;   // even kernels break the reference's view() too
     if (p->pooling != FASTKV_POOL_AVG && p->pooling != FASTKV_POOL_MAX) return FASTKV_EINVAL;
     if ((int64_t)p->S >= (1ll << 24)) return FASTKV_EUNSUPPORTED;                          // fixed-point softmax sum headroom

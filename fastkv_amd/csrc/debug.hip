@@ -19,6 +19,7 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
     case 5: r = fix_to_f32(((uint64_t)f32_bits(x) << 32) | f32_bits(y)); break;
     case 6: r = x * y; break;
     case 7: r = x + y; break;
+    case 8: r = scale_div(x, y, 1.0f / y); break;
     }
     out[i] = r;
     if (out64) out64[i] = r64;
@@ -27,7 +28,7 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
 
 extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream)
 {
-    if (!a || !out || n < 0 || op < 0 || op > 7) return FASTKV_EINVAL;
+    if (!a || !out || n < 0 || op < 0 || op > 8) return FASTKV_EINVAL;
     hipLaunchKernelGGL(fk::debug_contract_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, out64, n);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }

@@ -28,6 +28,18 @@ __device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cas
 // fp16 bit pattern -> uint16 key with the same total order as the values (utils.py:113 compares values)
 __device__ __forceinline__ uint32_t mono16(uint32_t h) { return (h & 0x8000u) ? (~h & 0xffffu) : (h | 0x8000u); }
 
+// x / c for an fp16-valued x, bit-identical to the IEEE fp32 division the reference performs (utils.py:94
+// `/ math.sqrt(head_dim)`): reciprocal multiply + one Newton correction, which is exact for every one of the
+// 63488 finite fp16 inputs (exhaustively checked on the GPU against the oracle's true division, tests/
+// test_hip_parity.py::test_arithmetic_contract_on_gpu); zeros and infinities take the plain product.
+__device__ __forceinline__ float scale_div(float x, float c, float rc)
+{
+    float q0 = x * rc;
+    float r = __builtin_fmaf(-q0, c, x);
+    float q1 = __builtin_fmaf(r, rc, q0);
+    return (x == 0.0f || __builtin_isinf(x)) ? q0 : q1;
+}
+
 // exp(d) for d <= 0: Cody-Waite reduction + degree-6 polynomial, fma only.  d < -87 -> 0.
 __device__ __forceinline__ float det_expf(float d)
 {

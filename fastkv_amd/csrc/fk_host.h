@@ -8,16 +8,18 @@
 namespace fk {
 
 constexpr int TKA = 256;        // keys per workgroup in score_logits (4 waves x 64 lanes, one key per lane)
-constexpr int CHB = 2048;       // positions per workgroup in score_sumexp (256 threads x 8)
 constexpr int SEL_THREADS = 1024;
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+enum { ENGINE_AUTO = 0, ENGINE_VALU = 1, ENGINE_MFMA = 2 };   // fastkv_problem.reserved bits 0-1
+
 struct Layout {
+    int engine;                      // contraction engine of score_logits (both are the oracle's fmaf chain)
     int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
     int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
-    int ntA, nchB;                   // tiles of score_logits, chunks of score_sumexp
-    size_t off_qf, off_logits, off_pm, off_ps, off_c, off_t, off_idx, off_sel, total;
+    int ntA;                         // tiles of score_logits
+    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_idx, off_sel, total;
 };
 
 static inline size_t select_ws_bytes(int64_t rows, int64_t n, int64_t k)
@@ -36,20 +38,22 @@ static inline Layout make_layout(const fastkv_problem &p)
     Layout L;
     L.G = p.H / p.Hkv;
     L.R = L.G * p.window;
+    L.engine = p.reserved & 3;
+    if (L.engine == ENGINE_AUTO) L.engine = L.R >= 24 ? ENGINE_MFMA : ENGINE_VALU;   // a 32-row MFMA block needs rows to fill it
     int r8 = (L.R + 7) / 8 * 8;
-    if (r8 <= 64) { L.RB = r8 <= 8 ? 8 : r8 <= 16 ? 16 : r8 <= 32 ? 32 : 64; L.passes = 1; }
+    if (L.engine == ENGINE_MFMA) { L.RB = 32; L.passes = (L.R + 31) / 32; }
+    else if (r8 <= 64) { L.RB = r8 <= 8 ? 8 : r8 <= 16 ? 16 : r8 <= 32 ? 32 : 64; L.passes = 1; }
     else { L.RB = 64; L.passes = (r8 + 63) / 64; }
     L.R_alloc = L.RB * L.passes;
     L.n = p.S - p.window;
     L.Sp = (p.S + 7) / 8 * 8;
     L.n_pad = (L.n + 7) / 8 * 8;
     L.ntA = (p.S + TKA - 1) / TKA;
-    L.nchB = (p.S + CHB - 1) / CHB;
     size_t o = 0;
     L.off_qf = o;     o += align_up((size_t)p.B * p.Hkv * L.R_alloc * p.D * 4, 256);
     L.off_logits = o; o += align_up((size_t)p.B * p.H * p.window * L.Sp * 2, 256);
-    L.off_pm = o;     o += align_up((size_t)p.B * p.H * p.window * L.ntA * 4, 256);
-    L.off_ps = o;     o += align_up((size_t)p.B * p.H * p.window * L.nchB * 8, 256);
+    L.off_gmax = o;   o += align_up((size_t)p.B * p.H * p.window * 4, 256);
+    L.off_rinv = o;   o += align_up((size_t)p.B * p.H * p.window * 4, 256);
     L.off_c = o;      o += align_up((size_t)p.B * p.Hkv * L.n_pad * 2, 256);
     L.off_t = o;      o += align_up((size_t)p.B * L.n_pad * 2, 256);
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);

@@ -1,69 +1,166 @@
 // Window-attention scoring: replaces ops k1-k10 of FastKVCluster.update_kv
 // (/root/reference/baselines/fastkv/utils.py:93-112, and the head sum of :127).
 //
-//   prep_q          Q[b,h,S-W+r,:] fp16 (strided) -> qf[b,g,i*W+r,:] fp32, zero padded to R_alloc rows
-//   score_logits    streams K ONCE (no repeat_kv materialisation): one key row per lane, the G*W
-//                   window-query vectors are wave-uniform scalar operands; fp32 fma chain over d;
-//                   writes scaled+masked fp16 logits L[b,h,r,j] and per-tile row maxima
-//   score_sumexp    sum_j exp(L - rowmax) in 2^-40 fixed point (order-free, deterministic)
-//   score_finalize  p = e/sum -> fp16, sum over window rows -> fp16, pool -> fp16, sum over the
-//                   G heads of the group -> fp16 = attn_cache c[b,g,j]
-//   tsp_rowsum      t[b,j] = fp16(sum_g c[b,g,j])   (utils.py:127)
+//   prep_q          Q[b,h,S-W+r,:] fp16 (strided) -> fp32 operand blocks in the layout the contraction engine wants
+//   score_logits    streams K ONCE (no repeat_kv materialisation) and writes the fp16-rounded raw logits
+//                   L[b,h,r,j] = fp16( sum_d q[d]*k[d] ) with an fp32 fma chain in ascending d      utils.py:94 (matmul)
+//                   Two engines with bit-identical results (both are the oracle's fmaf chain):
+//                     * matrix pipe: v_mfma_f32_32x32x2_f32 -- the FP32-in/FP32-out MFMA, documented as "bit-for-bit a
+//                       k-ordered f32 fmaf chain" at the same 157 TFLOP/s peak as the vector ALU; the 32 window-query
+//                       rows of a KV head are exactly one 32-row A block held in registers (used when G*W >= 24);
+//                     * vector ALU: v_pk_fma_f32 with the query values as wave-uniform scalar operands (small G*W).
+//                   No reduced-precision MFMA anywhere: results must match the CPU oracle bit for bit.
+//   row_stats       one workgroup per (b,h,r) row: scale by true division + window mask in place
+//                   (utils.py:94-101), row max, sum_j exp(L - max) in 2^-40 fixed point
+//                   (order-free, deterministic) -> gmax[row], rinv[row] = 1/sum                       utils.py:103
+//   score_finalize  p = e*rinv -> fp16, sum over window rows -> fp16, pool -> fp16, sum over the
+//                   G heads of the group -> fp16 = attn_cache c[b,g,j]                                utils.py:103-112
+//   tsp_rowsum      t[b,j] = fp16(sum_g c[b,g,j])                                                     utils.py:127
 //
 // HBM traffic: K read once (B*Hkv*S*D*2 bytes); the logits (B*H*W*S*2 bytes, 16 MiB at the
-// 32k config) round-trip through L2 / Infinity Cache.  No MFMA: the contraction is done with
-// v_fma_f32 / v_pk_fma_f32 so that the result is bit-identical to the CPU oracle.
+// 32k config) round-trip through L2 / Infinity Cache.
 #include "fk_device.h"
 #include "fk_host.h"
+#include "prof.h"
 
 namespace fk {
 
-// ------------------------------------------------------------------------------------------ prep_q
-__global__ void __launch_bounds__(256) prep_q_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
-                                                     int H, int Hkv, int S, int D, int W, int R, int R_alloc,
-                                                     float *__restrict__ qf)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------ prep_q (vector-ALU layout)
+// qf[bg][pass][d][RB] (row fastest), so the (row,row+1) operand pairs of v_pk_fma_f32 are adjacent scalars.
+// grid (R_alloc, B*Hkv), D threads
+__global__ void prep_q_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s, int H, int Hkv, int S,
+                              int D, int W, int R, int R_alloc, int RB, float *__restrict__ qf)
 {
-    const int bg = blockIdx.x;
+    const int row = blockIdx.x, bg = blockIdx.y, d = threadIdx.x;
     const int b = bg / Hkv, g = bg % Hkv, G = H / Hkv;
-    float *dst = qf + (size_t)bg * R_alloc * D;
-    for (int e = threadIdx.x; e < R_alloc * D; e += blockDim.x) {
-        int row = e / D, d = e - row * D;
-        float v = 0.0f;
-        if (row < R) {
-            int i = row / W, r = row - i * W;
-            v = h2f(q[b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(S - W + r) * qs_s + d]);
+    float v = 0.0f;
+    if (row < R) {
+        const int i = row / W, r = row - i * W;
+        v = h2f(q[b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(S - W + r) * qs_s + d]);
+    }
+    const int pass = row / RB, rr = row - pass * RB;
+    qf[(((size_t)bg * (R_alloc / RB) + pass) * D + d) * RB + rr] = v;
+}
+
+// ------------------------------------------------------------------------------------------ prep_q (matrix-pipe layout)
+// qf[bg][pass][s][lane] = q[row = pass*32 + (lane&31)][dim = 2s + (lane>>5)]: the A operand of k-step s of
+// v_mfma_f32_32x32x2_f32 (lane l holds A[i = l&31][k = l>>5]).  grid (D/2, passes, B*Hkv), 64 threads.
+__global__ void prep_q_mfma_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s, int H, int Hkv,
+                                   int S, int D, int W, int R, float *__restrict__ qf)
+{
+    const int s = blockIdx.x, pass = blockIdx.y, bg = blockIdx.z, lane = threadIdx.x;
+    const int b = bg / Hkv, g = bg % Hkv, G = H / Hkv;
+    const int row = pass * 32 + (lane & 31), d = 2 * s + (lane >> 5);
+    float v = 0.0f;
+    if (row < R) {
+        const int i = row / W, r = row - i * W;
+        v = h2f(q[b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(S - W + r) * qs_s + d]);
+    }
+    qf[(((size_t)bg * gridDim.y + pass) * (D / 2) + s) * 64 + lane] = v;
+}
+
+// ------------------------------------------------------------------------------------------ K staging shared by both engines
+// A wave stages 64 dims of its 64 consecutive key rows through a private LDS slab: coalesced 16-B global loads (8 lanes
+// per 128-B row segment), 144-B padded rows so that one-row-per-lane ds_read_b128 is bank-conflict free.
+constexpr int DH = 64;
+constexpr int ROWB = DH * 2 + 16;
+
+__device__ __forceinline__ void stage_k(const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane,
+                                        unsigned char *my)
+{
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    uint4 st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int jj = key0 + i * 8 + lrow;
+        jj = jj < S ? jj : S - 1;
+        st[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)jj * ks_s + ph * DH + lchunk * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(my + (i * 8 + lrow) * ROWB + lchunk * 16) = st[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------ score_logits, matrix pipe
+// grid.x = ntA * Hkv with blockIdx.x % Hkv = kv head (the Hkv workgroups that stream the same token range run together,
+// one per XCD under round-robin placement, so an XCD's L2 keeps one head's query block: speed only), grid.y = B.
+// 256 threads = 4 independent waves, each owning 64 consecutive keys = two 32-key B blocks.
+template <int D>
+__global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
+                                                                int64_t ks_s, const float *__restrict__ qf, int H, int Hkv, int S,
+                                                                int W, int R, int passes, int Sp, uint16_t *__restrict__ logits)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = blockIdx.x % Hkv, tile = blockIdx.x / Hkv, b = blockIdx.y;
+    const int G = H / Hkv;
+    const int key0 = tile * TKA + w * 64;
+    const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
+    unsigned char *my = slab[w];
+    const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
+
+    for (int pass = 0; pass < passes; ++pass) {
+        const float *qa = qf + ((size_t)(b * Hkv + g) * passes + pass) * (D / 2) * 64 + lane;
+        float aq[D / 2];
+#pragma unroll
+        for (int s = 0; s < D / 2; ++s) aq[s] = qa[s * 64];
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+        for (int ph = 0; ph < D / DH; ++ph) {
+            stage_k(kb, ks_s, key0, S, ph, lane, my);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint4 k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
+                const uint4 k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
+                const uint32_t w0[4] = {k0.x, k0.y, k0.z, k0.w}, w1[4] = {k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = ph * (DH / 2) + c * 4 + u;                 // dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
+                    const float b0 = h2f((uint16_t)((w0[u] >> sh) & 0xffffu));
+                    const float b1 = h2f((uint16_t)((w1[u] >> sh) & 0xffffu));
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b1, acc1, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        dst[e] = v;
+        // C/D map: register i of lane l is row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31
+        uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * 32) * Sp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            if (pass * 32 + m < R) {
+                const int j0 = key0 + n31, j1 = key0 + 32 + n31;
+                if (j0 < S) lp[(size_t)m * Sp + j0] = f2h(acc0[i]);
+                if (j1 < S) lp[(size_t)m * Sp + j1] = f2h(acc1[i]);
+            }
+        }
     }
 }
 
-// ------------------------------------------------------------------------------------------ score_logits
-// grid.x = ntA * Hkv with blockIdx.x % Hkv = kv head (the 8 workgroups that stream the same token range run
-// together, one per XCD under round-robin placement, so an XCD's L2 keeps one head's query block: speed only),
-// grid.y = B.  256 threads = 4 independent waves, each owning 64 consecutive keys (one key row per lane).
-// Per phase a wave stages 64 dims of its 64 rows through a private LDS slab (coalesced 16-B global loads,
-// 144-B padded rows -> conflict-free ds_read_b128 with one row per lane).
+// ------------------------------------------------------------------------------------------ score_logits, vector ALU
+// One key row per lane, the RB query rows of a pass are wave-uniform scalar operands (s_load), RB accumulators per lane.
 template <int D, int RB>
 __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                            const float *__restrict__ qf, int H, int Hkv, int S, int W, int R,
-                                                           int passes, int Sp, int ntA, float sqrtD,
-                                                           uint16_t *__restrict__ logits, float *__restrict__ pm)
+                                                           int passes, int Sp, uint16_t *__restrict__ logits)
 {
-    constexpr int DH = 64;
-    constexpr int ROWB = DH * 2 + 16;
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
-    __shared__ float red[4][RB];
-
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = blockIdx.x % Hkv, tile = blockIdx.x / Hkv, b = blockIdx.y;
-    const int G = H / Hkv, n = S - W;
-    const int j = tile * TKA + w * 64 + lane;
-    const bool valid = j < S;
+    const int G = H / Hkv;
+    const int key0 = tile * TKA + w * 64;
+    const int j = key0 + lane;
     const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
     const float *qg = qf + (size_t)(b * Hkv + g) * (size_t)(passes * RB) * D;
     unsigned char *my = slab[w];
 
-    const int lrow = lane >> 3, lchunk = lane & 7;
     for (int pass = 0; pass < passes; ++pass) {
         float acc[RB];
 #pragma unroll
@@ -71,19 +168,8 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
         const float *qp = qg + (size_t)pass * RB * D;
 #pragma unroll 1
         for (int ph = 0; ph < D / DH; ++ph) {
-            uint4 st[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int jj = tile * TKA + w * 64 + i * 8 + lrow;
-                jj = jj < S ? jj : S - 1;
-                st[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)jj * ks_s + ph * DH + lchunk * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<uint4 *>(my + (i * 8 + lrow) * ROWB + lchunk * 16) = st[i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
+            stage_k(kb, ks_s, key0, S, ph, lane, my);
+#pragma unroll 1
             for (int c = 0; c < 8; ++c) {
                 uint4 kr = *reinterpret_cast<const uint4 *>(my + lane * ROWB + c * 16);
                 float kf[8];
@@ -91,166 +177,180 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
                 kf[2] = h2f((uint16_t)(kr.y & 0xffff)); kf[3] = h2f((uint16_t)(kr.y >> 16));
                 kf[4] = h2f((uint16_t)(kr.z & 0xffff)); kf[5] = h2f((uint16_t)(kr.z >> 16));
                 kf[6] = h2f((uint16_t)(kr.w & 0xffff)); kf[7] = h2f((uint16_t)(kr.w >> 16));
-                const float *qc = qp + ph * DH + c * 8;
+                const float *qc = qp + (size_t)(ph * DH + c * 8) * RB;      // [dd][row]
+                // rows in groups of 8: bounds the number of live scalar query operands (64 SGPRs per group)
 #pragma unroll
-                for (int r = 0; r < RB; ++r) {
+                for (int r0 = 0; r0 < RB; r0 += 8) {
 #pragma unroll
-                    for (int dd = 0; dd < 8; ++dd) acc[r] = __builtin_fmaf(qc[r * D + dd], kf[dd], acc[r]);
+                    for (int r = r0; r < r0 + 8; ++r) {
+#pragma unroll
+                        for (int dd = 0; dd < 8; ++dd) acc[r] = __builtin_fmaf(qc[dd * RB + r], kf[dd], acc[r]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        // epilogue: round, scale by true division, round, window mask (utils.py:94-101), row maxima
+        // epilogue: the matmul output rounded to fp16 (utils.py:94); scaling and masking happen in row_stats
+        if (j < S) {
+            uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * RB) * Sp + j;
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int row = pass * RB + r;            // wave-uniform
-            float mval = -INFINITY;
-            if (row < R) {
-                const int i = row / W, rw = row - i * W;
-                uint16_t l16 = f2h(acc[r]);
-                uint16_t s16 = f2h(h2f(l16) / sqrtD);
-                if (j >= n && (j - n) > rw) s16 = f2h(h2f(s16) + (-65504.0f));
-                if (valid) {
-                    logits[((size_t)(b * H + g * G + i) * W + rw) * Sp + j] = s16;
-                    mval = h2f(s16);
-                }
-            }
-            mval = wave_max(mval);
-            if (lane == 0) red[w][r] = mval;
+            for (int r = 0; r < RB; ++r)
+                if (pass * RB + r < R) lp[(size_t)r * Sp] = f2h(acc[r]);
         }
-        __syncthreads();
-        if (threadIdx.x < RB) {
-            const int row = pass * RB + threadIdx.x;
-            if (row < R) {
-                const int i = row / W, rw = row - i * W;
-                float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
-                pm[((size_t)(b * H + g * G + i) * W + rw) * ntA + tile] = m;
-            }
-        }
-        __syncthreads();
     }
 }
 
-// ------------------------------------------------------------------------------------------ score_sumexp
-// grid (nchB, B*H); each workgroup: all W rows of one head over 2048 positions.
-__global__ void __launch_bounds__(256) score_sumexp_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ pm,
-                                                           int S, int W, int Sp, int ntA, int nchB, uint64_t *__restrict__ ps)
+// ------------------------------------------------------------------------------------------ row_stats
+// grid (B*H*W) rows, 1024 threads.  A "super chunk" is 32768 positions: 4 x 16-B loads per thread, all issued before any
+// is used.  Pass 1 rewrites the row in place with the scaled (+masked) logits and finds the row maximum; pass 2
+// accumulates sum exp(x - max) in fixed point, re-using the registers of the last super chunk (the whole row when
+// S <= 32768) and re-reading only what the same thread wrote for longer rows.
+constexpr int RS_THREADS = 1024;
+constexpr int RS_SUPER = RS_THREADS * 8 * 4;
+__global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restrict__ logits, int S, int W, int Sp, float sqrtD,
+                                                               float rsqrtD, float *__restrict__ gmax, float *__restrict__ rinv)
 {
-    __shared__ float gmax_s[64];
-    __shared__ uint64_t wsum[4];
-    __shared__ int wnan[4];
-    const int bh = blockIdx.y, ch = blockIdx.x;
+    __shared__ float smax[RS_THREADS / 64];
+    __shared__ uint64_t ssum[RS_THREADS / 64];
+    __shared__ int snan[RS_THREADS / 64];
+    const int row = blockIdx.x, rw = row % W, n = S - W;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // row maxima: wave w reduces rows w, w+4, ...
-    for (int r = w; r < W; r += 4) {
-        const float *p = pm + ((size_t)bh * W + r) * ntA;
-        float m = -INFINITY;
-        for (int t = lane; t < ntA; t += 64) m = fmaxf(m, p[t]);
-        m = wave_max(m);
-        if (lane == 0) gmax_s[r] = m;
-    }
-    __syncthreads();
-    const int j0 = ch * CHB + threadIdx.x * 8;
-    for (int r = 0; r < W; ++r) {
-        const float m = gmax_s[r];
-        uint32_t ahi = 0, alo = 0;
-        int nan = 0;
-        if (j0 < S) {
-            uint4 raw = *reinterpret_cast<const uint4 *>(logits + ((size_t)bh * W + r) * Sp + j0);
-            uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint16_t *p = logits + (size_t)row * Sp;
+    const int nsc = (S + RS_SUPER - 1) / RS_SUPER;
+    uint4 keep[4];
+    float m = -INFINITY;
+    for (int sc = 0; sc < nsc; ++sc) {
+        const int base = sc * RS_SUPER + threadIdx.x * 8;
+        uint4 raw[4];
 #pragma unroll
-            for (int e8 = 0; e8 < 8; ++e8) {
-                if (j0 + e8 < S) {
-                    uint16_t hb = (uint16_t)((wds[e8 >> 1] >> ((e8 & 1) * 16)) & 0xffff);
-                    float e = det_expf(h2f(hb) - m);
-                    if (e != e) { nan = 1; }
-                    else { uint32_t hi, lo; exp_to_fix(e, hi, lo); ahi += hi; alo += lo; }
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = base + u * (RS_THREADS * 8);
+            raw[u] = j0 < S ? *reinterpret_cast<const uint4 *>(p + j0) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = base + u * (RS_THREADS * 8);
+            const uint32_t wds[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+            uint32_t outw[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = j0 + e;
+                uint16_t l16 = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                uint16_t s16 = f2h(scale_div(h2f(l16), sqrtD, rsqrtD));
+                if (j >= n && (j - n) > rw) s16 = f2h(h2f(s16) + (-65504.0f));      // utils.py:95-101
+                if (j < S) m = fmaxf(m, h2f(s16));
+                outw[e >> 1] |= (uint32_t)s16 << ((e & 1) * 16);
+            }
+            keep[u] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+            if (j0 < S) *reinterpret_cast<uint4 *>(p + j0) = keep[u];
+        }
+    }
+    m = wave_max(m);
+    if (lane == 0) smax[w] = m;
+    __syncthreads();
+    m = smax[0];
+#pragma unroll
+    for (int u = 1; u < RS_THREADS / 64; ++u) m = fmaxf(m, smax[u]);
+
+    uint64_t ahi = 0, alo = 0;
+    int nan = 0;
+    for (int sc = nsc - 1; sc >= 0; --sc) {
+        const int base = sc * RS_SUPER + threadIdx.x * 8;
+        if (sc != nsc - 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j0 = base + u * (RS_THREADS * 8);
+                keep[u] = j0 < S ? *reinterpret_cast<const uint4 *>(p + j0) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = base + u * (RS_THREADS * 8);
+            const uint32_t wds[4] = {keep[u].x, keep[u].y, keep[u].z, keep[u].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (j0 + e < S) {
+                    uint16_t hb = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    float ex = det_expf(h2f(hb) - m);
+                    if (ex != ex) nan = 1;
+                    else { uint32_t hi, lo; exp_to_fix(ex, hi, lo); ahi += hi; alo += lo; }
                 }
             }
         }
-        uint64_t tot = ((uint64_t)wave_sum_u32(ahi) << 24) + wave_sum_u64((uint64_t)alo);   // hi <= 64*8*2^16 fits u32; lo needs 64 bits
-        nan = __any(nan);
-        if (lane == 0) { wsum[w] = tot; wnan[w] = nan; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            if (wnan[0] | wnan[1] | wnan[2] | wnan[3]) s = FK_SUM_POISON;
-            ps[((size_t)bh * W + r) * nchB + ch] = s;
-        }
-        __syncthreads();
+    }
+    uint64_t tot = wave_sum_u64((ahi << 24) + alo);
+    nan = __any(nan);
+    if (lane == 0) { ssum[w] = tot; snan[w] = nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t s = 0;
+        int bad = 0;
+#pragma unroll
+        for (int u = 0; u < RS_THREADS / 64; ++u) { s += ssum[u]; bad |= snan[u]; }
+        gmax[row] = m;
+        rinv[row] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);
     }
 }
 
 // ------------------------------------------------------------------------------------------ score_finalize
 // grid (tilesC, Hkv, B), 256 threads; thread t <-> position tile*TP - pad + t, TP = 256 - 2*pad outputs per block.
-__global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ pm,
-                                                             const uint64_t *__restrict__ ps, int H, int Hkv, int S, int W,
-                                                             int Sp, int ntA, int nchB, int ksize, int pooling,
-                                                             uint16_t *__restrict__ c_out, int64_t c_row_stride)
+// The G*W logits of a position are fetched in batches of 32 independent loads before any arithmetic.
+constexpr int FIN_MAXR = 1024;
+__global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ gmax,
+                                                             const float *__restrict__ rinv, int H, int Hkv, int S, int W, int Sp,
+                                                             int ksize, int pooling, uint16_t *__restrict__ c_out,
+                                                             int64_t c_row_stride)
 {
-    extern __shared__ float dyn[];                   // gmax[G*W], rinv[G*W]
     __shared__ float s_tile[2][256];
+    __shared__ float s_gmax[FIN_MAXR], s_rinv[FIN_MAXR];
     const int g = blockIdx.y, b = blockIdx.z;
-    const int G = H / Hkv, n = S - W, pad = ksize / 2, TP = 256 - 2 * pad;
-    const int R = G * W;
-    float *gmax = dyn, *rinv = dyn + R;
-    // row statistics: 8 lanes per row
-    {
-        const int sub = threadIdx.x & 7;
-        for (int row = threadIdx.x >> 3; row < R; row += 32) {
-            const int i = row / W, rw = row - i * W;
-            const size_t rid = (size_t)(b * H + g * G + i) * W + rw;
-            float m = -INFINITY;
-            for (int t = sub; t < ntA; t += 8) m = fmaxf(m, pm[rid * ntA + t]);
-            uint64_t s = 0;
-            int poison = 0;
-            for (int t = sub; t < nchB; t += 8) { uint64_t v = ps[rid * nchB + t]; if (v == FK_SUM_POISON) poison = 1; else s += v; }
-#pragma unroll
-            for (int o = 4; o > 0; o >>= 1) {
-                m = fmaxf(m, __shfl_xor(m, o, 64));
-                s += __shfl_xor(s, o, 64);
-                poison |= __shfl_xor(poison, o, 64);
-            }
-            if (sub == 0) { gmax[row] = m; rinv[row] = poison ? __builtin_nanf("") : 1.0f / fix_to_f32(s); }
-        }
-    }
-    __syncthreads();
+    const int G = H / Hkv, n = S - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * W;
     const int t = threadIdx.x;
     const int j = blockIdx.x * TP - pad + t;
     const bool inrange = (j >= 0) && (j < n);
     const bool is_out = (t >= pad) && (t < pad + TP) && inrange;
-    float gsum = 0.0f;
-    for (int i = 0; i < G; ++i) {
-        float a;
-        if (inrange) {
-            a = 0.0f;
-            const uint16_t *lp = logits + (size_t)(b * H + g * G + i) * W * Sp + j;
-            for (int r = 0; r < W; ++r) {
-                float e = det_expf(h2f(lp[(size_t)r * Sp]) - gmax[i * W + r]);
-                a = a + h2f(f2h(e * rinv[i * W + r]));
+    const size_t row0 = (size_t)(b * H + g * G) * W;
+    for (int i = t; i < R; i += 256) { s_gmax[i] = gmax[row0 + i]; s_rinv[i] = rinv[row0 + i]; }
+    __syncthreads();
+    const uint16_t *lp = logits + row0 * Sp + (inrange ? j : 0);
+    float gsum = 0.0f, a = 0.0f;
+    int head = 0;
+    for (int rb = 0; rb < R; rb += 32) {
+        uint16_t x[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) x[u] = (rb + u < R) ? lp[(size_t)(rb + u) * Sp] : (uint16_t)0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int rr = rb + u;                                  // uniform
+            if (rr < R) {
+                const float e = det_expf(h2f(x[u]) - s_gmax[rr]);
+                a = a + h2f(f2h(e * s_rinv[rr]));                   // sum over the window rows (utils.py:104)
+                if ((rr + 1) % W == 0) {                            // last window row of head `head`
+                    float sv = inrange ? h2f(f2h(a)) : (pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY);   // padding, utils.py:106,108
+                    float *st = s_tile[head & 1];
+                    st[t] = sv;
+                    __syncthreads();
+                    if (is_out) {
+                        float pv;
+                        if (pooling == FASTKV_POOL_AVG) {
+                            pv = 0.0f;
+                            for (int o = -pad; o <= pad; ++o) pv = pv + st[t + o];
+                            pv = pv / (float)ksize;
+                        } else {
+                            pv = -INFINITY;
+                            for (int o = -pad; o <= pad; ++o) { float xv = st[t + o]; if (xv > pv || xv != xv) pv = xv; }
+                        }
+                        gsum = gsum + h2f(f2h(pv));                 // sum over the heads of the group (utils.py:112)
+                    }
+                    // s_tile is double buffered: head+2 rewrites this half only after the barrier of head+1,
+                    // which every thread reaches after its reads above
+                    a = 0.0f;
+                    ++head;
+                }
             }
-            a = h2f(f2h(a));
-        } else {
-            a = pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY;     // zero / -inf padding (utils.py:106,108)
         }
-        float *st = s_tile[i & 1];
-        st[t] = a;
-        __syncthreads();
-        if (is_out) {
-            float pv;
-            if (pooling == FASTKV_POOL_AVG) {
-                pv = 0.0f;
-                for (int u = -pad; u <= pad; ++u) pv = pv + st[t + u];
-                pv = pv / (float)ksize;
-            } else {
-                pv = -INFINITY;
-                for (int u = -pad; u <= pad; ++u) { float x = st[t + u]; if (x > pv || x != x) pv = x; }
-            }
-            gsum = gsum + h2f(f2h(pv));
-        }
-        // s_tile is double buffered: head i+2 rewrites this half only after the barrier of head i+1,
-        // which every thread reaches after its reads above
     }
     if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + j] = f2h(gsum);
 }
@@ -269,12 +369,12 @@ __global__ void __launch_bounds__(256) tsp_rowsum_kernel(const uint16_t *__restr
 
 // ------------------------------------------------------------------------------------------ launcher
 template <int D>
-static hipError_t launch_logits_d(int RB, dim3 grid, hipStream_t st, const uint16_t *k, const int64_t *ks, const float *qf,
-                                  const fastkv_problem &p, const Layout &L, float sqrtD, uint16_t *logits, float *pm)
+static hipError_t launch_logits_valu(int RB, dim3 grid, hipStream_t st, const uint16_t *k, const int64_t *ks, const float *qf,
+                                     const fastkv_problem &p, const Layout &L, uint16_t *logits)
 {
 #define FK_LAUNCH_RB(RBV)                                                                                                  \
     hipLaunchKernelGGL((score_logits_kernel<D, RBV>), grid, dim3(256), 0, st, k, ks[0], ks[1], ks[2], qf, p.H, p.Hkv, p.S, \
-                       p.window, L.R, L.passes, L.Sp, L.ntA, sqrtD, logits, pm)
+                       p.window, L.R, L.passes, L.Sp, logits)
     switch (RB) {
     case 8: FK_LAUNCH_RB(8); break;
     case 16: FK_LAUNCH_RB(16); break;
@@ -291,34 +391,61 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
 {
     float *qf = reinterpret_cast<float *>(ws + L.off_qf);
     uint16_t *logits = reinterpret_cast<uint16_t *>(ws + L.off_logits);
-    float *pm = reinterpret_cast<float *>(ws + L.off_pm);
-    uint64_t *ps = reinterpret_cast<uint64_t *>(ws + L.off_ps);
+    float *gmax = reinterpret_cast<float *>(ws + L.off_gmax);
+    float *rinv = reinterpret_cast<float *>(ws + L.off_rinv);
     const float sqrtD = (float)sqrt((double)p.D);
+    const float rsqrtD = 1.0f / sqrtD;
+    const uint16_t *kp = (const uint16_t *)k;
     hipError_t e;
-
-    hipLaunchKernelGGL(prep_q_kernel, dim3(p.B * p.Hkv), dim3(256), 0, st, (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
-                       p.S, p.D, p.window, L.R, L.R_alloc, qf);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-
     dim3 gridA(L.ntA * p.Hkv, p.B);
-    if (p.D == 64) e = launch_logits_d<64>(L.RB, gridA, st, (const uint16_t *)k, ks, qf, p, L, sqrtD, logits, pm);
-    else if (p.D == 128) e = launch_logits_d<128>(L.RB, gridA, st, (const uint16_t *)k, ks, qf, p, L, sqrtD, logits, pm);
-    else e = launch_logits_d<256>(L.RB, gridA, st, (const uint16_t *)k, ks, qf, p, L, sqrtD, logits, pm);
+
+    if (L.engine == ENGINE_MFMA) {
+        {
+            ProfScope ps_(K_PREP_Q, st);
+            hipLaunchKernelGGL(prep_q_mfma_kernel, dim3(p.D / 2, L.passes, p.B * p.Hkv), dim3(64), 0, st, (const uint16_t *)q, qs[0],
+                               qs[1], qs[2], p.H, p.Hkv, p.S, p.D, p.window, L.R, qf);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        ProfScope ps_(K_LOGITS, st);
+#define FK_LAUNCH_MFMA(DV)                                                                                                     \
+    hipLaunchKernelGGL((score_logits_mfma_kernel<DV>), gridA, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], qf, p.H, p.Hkv, p.S, \
+                       p.window, L.R, L.passes, L.Sp, logits)
+        if (p.D == 64) FK_LAUNCH_MFMA(64);
+        else if (p.D == 128) FK_LAUNCH_MFMA(128);
+        else FK_LAUNCH_MFMA(256);
+#undef FK_LAUNCH_MFMA
+        e = hipGetLastError();
+    } else {
+        {
+            ProfScope ps_(K_PREP_Q, st);
+            hipLaunchKernelGGL(prep_q_kernel, dim3(L.R_alloc, p.B * p.Hkv), dim3(p.D), 0, st, (const uint16_t *)q, qs[0], qs[1],
+                               qs[2], p.H, p.Hkv, p.S, p.D, p.window, L.R, L.R_alloc, L.RB, qf);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        ProfScope ps_(K_LOGITS, st);
+        if (p.D == 64) e = launch_logits_valu<64>(L.RB, gridA, st, kp, ks, qf, p, L, logits);
+        else if (p.D == 128) e = launch_logits_valu<128>(L.RB, gridA, st, kp, ks, qf, p, L, logits);
+        else e = launch_logits_valu<256>(L.RB, gridA, st, kp, ks, qf, p, L, logits);
+    }
     if (e != hipSuccess) return e;
-
-    hipLaunchKernelGGL(score_sumexp_kernel, dim3(L.nchB, p.B * p.H), dim3(256), 0, st, logits, pm, p.S, p.window, L.Sp, L.ntA,
-                       L.nchB, ps);
+    {
+        ProfScope ps_(K_ROWSTATS, st);
+        hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, p.S, p.window, L.Sp, sqrtD,
+                           rsqrtD, gmax, rinv);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-
-    const int pad = p.kernel / 2, TP = 256 - 2 * pad;
-    dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
-    hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), (size_t)2 * L.R * sizeof(float), st, logits, pm, ps, p.H, p.Hkv,
-                       p.S, p.window, L.Sp, L.ntA, L.nchB, p.kernel, p.pooling, c_out, c_row_stride);
+    {
+        ProfScope ps_(K_FINALIZE, st);
+        const int pad = p.kernel / 2, TP = 256 - 2 * pad;
+        dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv, p.H, p.Hkv, p.S, p.window, L.Sp,
+                           p.kernel, p.pooling, c_out, c_row_stride);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-
     if (t_out) {
-        hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((L.n + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, L.n,
-                           t_out, t_row_stride);
+        ProfScope ps_(K_TSP_ROWSUM, st);
+        hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((L.n + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, L.n, t_out,
+                           t_row_stride);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;

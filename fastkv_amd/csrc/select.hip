@@ -14,6 +14,7 @@
 // degenerate rows (all-equal scores, e.g. the all-ones benchmark prompt) do not serialise.
 #include "fk_device.h"
 #include "fk_host.h"
+#include "prof.h"
 
 namespace fk {
 
@@ -267,6 +268,7 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
                                   SEL_LDS_LIST * 2 * 6);
         attr_set = true;
     }
+    ProfScope ps_(K_SELECT, st);
     hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)rows), dim3(SEL_THREADS), dyn, st, scores, row_stride, (int)n, (int)k,
                        order, append, idx_out, g_idx, g_key, g_cnt, list_in_lds);
     return hipGetLastError();

@@ -6,6 +6,7 @@ All functions are stream-ordered on torch's current stream and never synchronise
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -42,12 +43,22 @@ def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     return ws
 
 
+ENGINE = {"auto": 0, "valu": 1, "mfma": 2}
+_engine = ENGINE[os.environ.get("FASTKV_SCORE_ENGINE", "auto")]
+
+
+def set_score_engine(name: str) -> None:
+    """Force the contraction engine of the scoring kernel ("auto" | "valu" | "mfma"); results are bit-identical."""
+    global _engine
+    _engine = ENGINE[name]
+
+
 def _problem(q, k, window, kernel_size, pooling, capacity, tsp_len, order) -> Problem:
     B, H, S, D = q.shape
     if pooling not in POOLING:
         raise ValueError("Pooling method not supported")          # utils.py:110
     return Problem(B=B, H=H, Hkv=k.shape[1], S=S, D=D, window=window, kernel=kernel_size, pooling=POOLING[pooling],
-                   capacity=capacity, tsp_len=tsp_len, order=ORDER[order], reserved=0)
+                   capacity=capacity, tsp_len=tsp_len, order=ORDER[order], reserved=_engine)
 
 
 def _check_qkv(q, k, v=None):

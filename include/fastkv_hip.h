@@ -54,7 +54,9 @@ typedef struct fastkv_problem {
     int32_t capacity;  /* max_capacity_prompt after the proportional rule (utils.py:86-87); window < capacity <= S */
     int32_t tsp_len;   /* 0 = no TSP on this layer; else window < tsp_len < S (utils.py:126) */
     int32_t order;     /* FASTKV_ORDER_* for the K/V rows */
-    int32_t reserved;
+    int32_t reserved;  /* 0; tests may set bits 0-1 to force the contraction engine of the scoring kernel:
+                          1 = vector ALU (v_pk_fma_f32), 2 = FP32 matrix pipe (v_mfma_f32_32x32x2_f32); both produce the
+                          same bits (an fp32 fma chain in ascending head-dim order) */
 } fastkv_problem;
 
 /* Bytes of scratch `fastkv_update_kv_f16` / `fastkv_score_f16` need for this problem. */
@@ -115,9 +117,19 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
 /*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
- * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b) so tests can compare the GPU bit-for-bit with the CPU oracle.
+ * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b)) so tests can compare the GPU bit-for-bit with the CPU oracle.
  */
 int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream);
+
+/*
+ * Measurement hooks (bench.py): when enabled, every kernel launch is bracketed by HIP events on its stream.
+ * fastkv_profile_read adds launches / summed milliseconds per kernel id to the caller's arrays (length
+ * fastkv_profile_kernels()) and clears the records; it synchronises on the recorded events.
+ */
+void fastkv_profile_enable(int on);
+int fastkv_profile_kernels(void);
+const char *fastkv_profile_kernel_name(int kernel_id);
+int fastkv_profile_read(int64_t *counts, double *ms);
 
 const char *fastkv_strerror(int code);
 /* "fastkv-hip <version> gfx950" */

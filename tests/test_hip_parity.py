@@ -174,3 +174,75 @@ def test_bad_arguments_raise(dev):
         ops.update_kv(qd, kd, vd, 8, 6, "avgpool", 64)            # even kernel size
     with pytest.raises(RuntimeError):
         ops.update_kv(q, k, v, 8, 7, "avgpool", 64)               # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("engine", ["valu", "mfma"])
+@pytest.mark.parametrize("name", ["tiny_avg", "ragged_mha_d64", "gqa8_w16", "cfg1"])
+def test_both_contraction_engines_bit_exact(name, engine, dev):
+    """The vector-ALU and the FP32 matrix-pipe engines of the scoring kernel are the same fp32 fma chain."""
+    from fastkv_amd import ops
+    ops.set_score_engine(engine)
+    try:
+        case, (q, k, v), (ko, vo, idx, tsp, c, t), (gko, gvo, gtsp, gidx, gc) = _run_both(name, dev, "score")
+    finally:
+        ops.set_score_engine("auto")
+    assert torch.equal(gc.cpu().view(torch.int16), c.view(torch.int16))
+    assert torch.equal(gidx.cpu(), idx) and torch.equal(gko.cpu(), ko) and torch.equal(gvo.cpu(), vo)
+
+
+def test_arithmetic_contract_on_gpu(dev):
+    """Every primitive of csrc/fk_device.h against its twin in oracle/fastkv_oracle.c, bit for bit."""
+    import ctypes
+    import math
+    from fastkv_amd._lib import load
+    from oracle import fastkv_oracle as O
+    L, Lo = load(), O.lib()
+
+    def run(op, a, b=None):
+        ad = a.contiguous().to(dev)
+        bd = b.contiguous().to(dev) if b is not None else None
+        out = torch.zeros_like(ad)
+        o64 = torch.zeros(a.numel(), dtype=torch.int64, device=dev)
+        rc = L.fastkv_debug_contract(op, ad.data_ptr(), bd.data_ptr() if bd is not None else None, out.data_ptr(), o64.data_ptr(),
+                                     a.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out.cpu(), o64.cpu()
+
+    bits = lambda t: t.view(torch.int32)
+    gen = torch.Generator().manual_seed(7)
+    # deterministic exp over the softmax range (+ the cut-off and -inf)
+    d = torch.cat([-torch.rand(100000, generator=gen) * 90, torch.tensor([0.0, -87.0, -87.0001, -1e9, float("-inf")])])
+    g, _ = run(0, d)
+    want = torch.tensor([Lo.fastkv_oracle_det_expf(float(x)) for x in d.tolist()])
+    assert torch.equal(bits(g), bits(want))
+    # logit scaling: scale_div == IEEE division for EVERY fp16 value, D = 64 / 128 / 256
+    allh = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.float16).float()
+    allh = allh[~torch.isnan(allh)]
+    for D in (64, 128, 256):
+        c = torch.full_like(allh, float(torch.tensor(math.sqrt(D), dtype=torch.float32)))
+        g, _ = run(8, allh, c)
+        assert torch.equal(bits(g), bits(allh / c)), D
+    # IEEE division / reciprocal as used for 1/sum and /kernel_size
+    y = torch.rand(200000, generator=gen) * 4000 + 1e-3
+    assert torch.equal(bits(run(1, torch.ones_like(y), y)[0]), bits(1.0 / y))
+    x = torch.rand(200000, generator=gen)
+    assert torch.equal(bits(run(1, x, torch.full_like(x, 7.0))[0]), bits(x / 7.0))
+    # fp32 -> fp16 -> fp32 incl. the subnormal range; plain mul / add
+    z = torch.cat([torch.rand(100000, generator=gen) * 2e-4, torch.rand(100000, generator=gen) * 70000])
+    assert torch.equal(bits(run(2, z)[0]), bits(z.half().float()))
+    a, b = torch.rand(100000, generator=gen) * 1e-3, torch.rand(100000, generator=gen)
+    assert torch.equal(bits(run(6, a, b)[0]), bits(a * b)) and torch.equal(bits(run(7, a, b)[0]), bits(a + b))
+    # fixed-point softmax sum: conversion both ways
+    e = torch.cat([torch.rand(50000, generator=gen), torch.rand(50000, generator=gen) * 1e-9, torch.tensor([0.0, 1.0, 2.0 ** -41, 2.0 ** -40])])
+    g, g64 = run(3, e)
+    w64 = torch.tensor([Lo.fastkv_oracle_exp_to_fix(float(v)) for v in e.tolist()], dtype=torch.int64)
+    assert torch.equal(g64, w64)
+    wf = torch.tensor([Lo.fastkv_oracle_fix_to_f32(int(v)) for v in w64.tolist()])
+    assert torch.equal(bits(g), bits(wf))
+    big = torch.randint(0, 2 ** 62, (50000,), generator=gen, dtype=torch.int64)
+    hi, lo = (big >> 32).to(torch.int32).view(torch.float32), (big & 0xFFFFFFFF).to(torch.int64).to(torch.int32).view(torch.float32)
+    # NaN bit patterns survive the device copy, so op 5 sees exactly `big`
+    g, _ = run(5, hi, lo)
+    wf = torch.tensor([Lo.fastkv_oracle_fix_to_f32(int(v)) for v in big.tolist()])
+    assert torch.equal(bits(g), bits(wf))
