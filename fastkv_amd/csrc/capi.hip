@@ -74,10 +74,20 @@ int fastkv_select_f16(const void *scores, int64_t rows, int64_t row_stride, int6
 {
     if (!scores || !idx_out || rows < 0 || n < 1 || k < 0 || k > n || append < 0 || row_stride < n) return FASTKV_EINVAL;
     if (order != FASTKV_ORDER_INDEX && order != FASTKV_ORDER_SCORE) return FASTKV_EINVAL;
-    if (n >= (1ll << 31) - 8192) return FASTKV_EUNSUPPORTED;
-    if (!workspace || workspace_bytes < select_ws_bytes(rows, n, k)) return FASTKV_EWORKSPACE;
-    hipError_t e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, order, append, idx_out, (char *)workspace,
-                                 (hipStream_t)stream);
+    if (order == FASTKV_ORDER_SCORE && append != 0) return FASTKV_EINVAL;      // the window union is defined on the ascending list
+    if (n >= (1ll << 31) - 65536 || k > 131064) return FASTKV_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (order == FASTKV_ORDER_INDEX) {
+        e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, append, idx_out, k + append, nullptr, 0, nullptr, st);
+    } else {
+        if (!workspace || workspace_bytes < select_ws_bytes(rows, n, k)) return FASTKV_EWORKSPACE;
+        const int64_t kal = (k + 7) & ~(int64_t)7;
+        int64_t *asc = reinterpret_cast<int64_t *>(workspace);
+        uint16_t *keys = reinterpret_cast<uint16_t *>((char *)workspace + align_up((size_t)rows * kal * sizeof(int64_t), 256));
+        e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, 0, asc, kal, keys, kal, nullptr, st);
+        if (e == hipSuccess) e = launch_rank_scatter(asc, kal, keys, kal, rows, k, idx_out, k, st);
+    }
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
@@ -91,7 +101,7 @@ int fastkv_compact_f16(const fastkv_problem *p, const void *k, const int64_t k_s
     if ((rc = check_strides(v, v_strides)) != FASTKV_OK) return rc;
     if (!idx || !k_out || !v_out) return FASTKV_EINVAL;
     if ((reinterpret_cast<uintptr_t>(k_out) & 15) || (reinterpret_cast<uintptr_t>(v_out) & 15)) return FASTKV_EINVAL;
-    hipError_t e = launch_compact(*p, k, k_strides, v, v_strides, idx, k_out, v_out, (hipStream_t)stream);
+    hipError_t e = launch_compact(*p, k, k_strides, v, v_strides, idx, nullptr, nullptr, k_out, v_out, (hipStream_t)stream);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
@@ -115,8 +125,13 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     hipStream_t st = (hipStream_t)stream;
     uint16_t *c = reinterpret_cast<uint16_t *>(ws + L.off_c);
     uint16_t *t = p->tsp_len ? reinterpret_cast<uint16_t *>(ws + L.off_t) : nullptr;
-    int64_t *idx = kv_idx_out ? kv_idx_out : reinterpret_cast<int64_t *>(ws + L.off_idx);
     const int kk = p->capacity - p->window;
+    if (kk > 131064) return FASTKV_EUNSUPPORTED;
+    const bool by_score = p->order == FASTKV_ORDER_SCORE;
+    // ascending-position winners: straight into the caller's tensor when that is the requested order
+    int64_t *idx_asc = (!by_score && kv_idx_out) ? kv_idx_out : reinterpret_cast<int64_t *>(ws + L.off_idx);
+    uint16_t *keys = by_score ? reinterpret_cast<uint16_t *>(ws + L.off_keys) : nullptr;
+    const int64_t kal = ((int64_t)kk + 7) & ~(int64_t)7;
 
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
@@ -125,14 +140,15 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
                              hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
-    e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, p->order, 0, idx, ws + L.off_sel, st);
+    e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
+                      reinterpret_cast<const uint32_t *>(ws + L.off_hist), st);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
     if (p->tsp_len) {
-        e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, FASTKV_ORDER_INDEX, p->window, tsp_idx_out,
-                          ws + L.off_sel, st);
+        e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
+                          reinterpret_cast<const uint32_t *>(ws + L.off_thist), st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
-    e = launch_compact(*p, k, k_strides, v, v_strides, idx, k_out, v_out, st);
+    e = launch_compact(*p, k, k_strides, v, v_strides, idx_asc, keys, by_score ? kv_idx_out : nullptr, k_out, v_out, st);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -10,6 +10,7 @@
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
+#include "rank.h"
 
 namespace fk {
 
@@ -21,7 +22,8 @@ namespace fk {
 template <int LPR>
 __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                          const uint16_t *__restrict__ v, int64_t vs_b, int64_t vs_h, int64_t vs_s,
-                                                         const int64_t *__restrict__ idx, int Hkv, int S, int W, int cap,
+                                                         const int64_t *__restrict__ idx, const uint16_t *__restrict__ keys,
+                                                         int64_t *__restrict__ idx_sorted, int Hkv, int S, int W, int cap,
                                                          uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out)
 {
     constexpr int RPB = 256 / LPR;
@@ -33,15 +35,31 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     const int kk = cap - W, n = S - W;
     const int sub = threadIdx.x % LPR;
     const int r = blockIdx.x * RPB + threadIdx.x / LPR;
-    if (r >= cap) return;
+    const int rc = r < cap ? r : cap - 1;
     // selected row, or one of the window rows appended after them (utils.py:118-121)
-    const int64_t srow = r < kk ? idx[(size_t)bg * kk + r] : (int64_t)(n + (r - kk));
+    const int64_t srow = rc < kk ? idx[(size_t)bg * kk + rc] : (int64_t)(n + (rc - kk));
     const uint4 val = *reinterpret_cast<const uint4 *>(src + srow * ss + sub * 8);
-    *reinterpret_cast<uint4 *>(dst + (size_t)r * (LPR * 8) + sub * 8) = val;
+    int d = rc;
+    if (keys) {
+        // ORDER_SCORE: the winner at ascending-position slot r goes to slot rank(r) (value descending, ties by position);
+        // the LPR lanes of the row share the comparison counting, which runs under the latency of the row load above
+        const int kal = (kk + 7) & ~7;
+        const uint16_t *kr = keys + (size_t)bg * kal;
+        const int pc = rc < kk ? rc : kk - 1;
+        uint32_t rk = rank_partial(kr, kk, pc, kr[pc], sub, LPR);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) rk += __shfl_xor((int)rk, o, 64);
+        if (rc < kk) {
+            d = (int)rk;
+            if (idx_sorted && !isv && sub == 0) idx_sorted[(size_t)bg * kk + d] = srow;
+        }
+    }
+    if (r < cap) *reinterpret_cast<uint4 *>(dst + (size_t)d * (LPR * 8) + sub * 8) = val;
 }
 
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
-                          const int64_t *idx, void *k_out, void *v_out, hipStream_t st)
+                          const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
+                          hipStream_t st)
 {
     const int lpr = p.D / 8;
     const int rows_per_block = 256 / lpr;
@@ -49,7 +67,8 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
     ProfScope ps_(K_COMPACT, st);
 #define FK_COMPACT(LPRV)                                                                                                   \
     hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],         \
-                       (const uint16_t *)v, vs[0], vs[1], vs[2], idx, p.Hkv, p.S, p.window, p.capacity, (uint16_t *)k_out,  \
+                       (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \
+                       p.capacity, (uint16_t *)k_out,                                                                      \
                        (uint16_t *)v_out)
     if (lpr == 8) FK_COMPACT(8);
     else if (lpr == 16) FK_COMPACT(16);

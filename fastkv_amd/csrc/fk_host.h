@@ -9,6 +9,7 @@ namespace fk {
 
 constexpr int TKA = 256;        // keys per workgroup in score_logits (4 waves x 64 lanes, one key per lane)
 constexpr int SEL_THREADS = 1024;
+constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -19,18 +20,15 @@ struct Layout {
     int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
     int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
     int ntA;                         // tiles of score_logits
-    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_idx, off_sel, total;
+    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_idx, off_keys, total;
 };
 
 static inline size_t select_ws_bytes(int64_t rows, int64_t n, int64_t k)
 {
     (void)n;
-    // global fallbacks of the stable radix sort (ping-pong (idx32,key16) lists + digit counters);
-    // only touched when the winner list does not fit LDS.  Must match launch_select().
+    // stand-alone select with ORDER_SCORE: ascending index list + key list for the rank scatter
     const size_t kal = ((size_t)k + 7) & ~(size_t)7;
-    const size_t iters = ((size_t)k + SEL_THREADS - 1) / SEL_THREADS;
-    return align_up((size_t)rows * 2 * kal * sizeof(uint32_t), 256) + align_up((size_t)rows * 2 * kal * sizeof(uint16_t), 256) +
-           align_up((size_t)rows * (iters ? iters : 1) * 256 * sizeof(uint32_t), 256);
+    return align_up((size_t)rows * kal * sizeof(int64_t), 256) + align_up((size_t)rows * kal * sizeof(uint16_t), 256);
 }
 
 static inline Layout make_layout(const fastkv_problem &p)
@@ -56,11 +54,14 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_rinv = o;   o += align_up((size_t)p.B * p.H * p.window * 4, 256);
     L.off_c = o;      o += align_up((size_t)p.B * p.Hkv * L.n_pad * 2, 256);
     L.off_t = o;      o += align_up((size_t)p.B * L.n_pad * 2, 256);
+    L.off_hist = o;   o += align_up((size_t)p.B * p.Hkv * HIST12 * 4, 256);     // 12-bit key histograms of the score rows
+    L.off_thist = o;  o += align_up((size_t)p.B * HIST12 * 4, 256);             // ... and of the TSP rows (adjacent: zeroed together)
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
-    L.off_sel = o;
-    int64_t kmax = p.capacity - p.window;
-    if (p.tsp_len - p.window > kmax) kmax = p.tsp_len - p.window;
-    o += select_ws_bytes((int64_t)p.B * p.Hkv, L.n, kmax > 0 ? kmax : 1);
+    L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
+    {
+        const size_t kk = p.capacity > p.window ? (size_t)(p.capacity - p.window) : 0;
+        o += align_up((size_t)p.B * p.Hkv * ((kk + 7) & ~(size_t)7) * 2, 256);
+    }
     L.total = o;
     return L;
 }
@@ -69,10 +70,16 @@ static inline Layout make_layout(const fastkv_problem &p)
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
                         char *ws, hipStream_t st);
-hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int order,
-                         int append, int64_t *idx_out, char *ws, hipStream_t st);
+hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
+                         int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
+                         const uint32_t *hist12, hipStream_t st);
+hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, const uint16_t *keys, int64_t key_row_stride,
+                               int64_t rows, int64_t k, int64_t *out, int64_t out_row_stride, hipStream_t st);
+// idx: ascending-position winners; keys != nullptr => rows are placed in ORDER_SCORE (rank by comparison counting) and
+// idx_sorted_out (optional) receives the indices in that order
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
-                          const int64_t *idx, void *k_out, void *v_out, hipStream_t st);
+                          const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
+                          hipStream_t st);
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
                               int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st);
 

@@ -1,7 +1,8 @@
 // Window-attention scoring: replaces ops k1-k10 of FastKVCluster.update_kv
 // (/root/reference/baselines/fastkv/utils.py:93-112, and the head sum of :127).
 //
-//   prep_q          Q[b,h,S-W+r,:] fp16 (strided) -> fp32 operand blocks in the layout the contraction engine wants
+//   prep_q          (vector-ALU engine only) Q[b,h,S-W+r,:] fp16 -> fp32 scalar-operand blocks; the matrix-pipe
+//                   kernel converts its A operand itself
 //   score_logits    streams K ONCE (no repeat_kv materialisation) and writes the fp16-rounded raw logits
 //                   L[b,h,r,j] = fp16( sum_d q[d]*k[d] ) with an fp32 fma chain in ascending d      utils.py:94 (matmul)
 //                   Two engines with bit-identical results (both are the oracle's fmaf chain):
@@ -44,23 +45,6 @@ __global__ void prep_q_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int6
     qf[(((size_t)bg * (R_alloc / RB) + pass) * D + d) * RB + rr] = v;
 }
 
-// ------------------------------------------------------------------------------------------ prep_q (matrix-pipe layout)
-// qf[bg][pass][s][lane] = q[row = pass*32 + (lane&31)][dim = 2s + (lane>>5)]: the A operand of k-step s of
-// v_mfma_f32_32x32x2_f32 (lane l holds A[i = l&31][k = l>>5]).  grid (D/2, passes, B*Hkv), 64 threads.
-__global__ void prep_q_mfma_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s, int H, int Hkv,
-                                   int S, int D, int W, int R, float *__restrict__ qf)
-{
-    const int s = blockIdx.x, pass = blockIdx.y, bg = blockIdx.z, lane = threadIdx.x;
-    const int b = bg / Hkv, g = bg % Hkv, G = H / Hkv;
-    const int row = pass * 32 + (lane & 31), d = 2 * s + (lane >> 5);
-    float v = 0.0f;
-    if (row < R) {
-        const int i = row / W, r = row - i * W;
-        v = h2f(q[b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(S - W + r) * qs_s + d]);
-    }
-    qf[(((size_t)bg * gridDim.y + pass) * (D / 2) + s) * 64 + lane] = v;
-}
-
 // ------------------------------------------------------------------------------------------ K staging shared by both engines
 // A wave stages 64 dims of its 64 consecutive key rows through a private LDS slab: coalesced 16-B global loads (8 lanes
 // per 128-B row segment), 144-B padded rows so that one-row-per-lane ds_read_b128 is bank-conflict free.
@@ -85,60 +69,118 @@ __device__ __forceinline__ void stage_k(const uint16_t *__restrict__ kb, int64_t
 }
 
 // ------------------------------------------------------------------------------------------ score_logits, matrix pipe
-// grid.x = ntA * Hkv with blockIdx.x % Hkv = kv head (the Hkv workgroups that stream the same token range run together,
-// one per XCD under round-robin placement, so an XCD's L2 keeps one head's query block: speed only), grid.y = B.
-// 256 threads = 4 independent waves, each owning 64 consecutive keys = two 32-key B blocks.
+// Persistent waves: grid.x = nblk * Hkv with blockIdx.x % Hkv = kv head (the Hkv workgroups that stream the same token
+// range run together, one per XCD under round-robin placement, so an XCD's L2 keeps one head's query block: speed only),
+// grid.y = B.  256 threads = 4 independent waves; a wave owns 64-key tiles (two 32-key B blocks) wt = wave id, wave id +
+// nwaves, ...  The A operand (the head's 32 query rows, all D/2 k-steps) is loaded into registers once per wave; the
+// K rows of the next phase/tile are fetched into registers while the matrix pipe works on the current LDS slab.
+// Eight named 16-B registers (an indexed local array carried across the tile loop ends up in scratch memory).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct KStage { u32x4 r0, r1, r2, r3, r4, r5, r6, r7; };
+
+__device__ __forceinline__ u32x4 k_load1(const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane, int i)
+{
+    int jj = key0 + i * 8 + (lane >> 3);
+    jj = jj < S ? jj : S - 1;
+    return *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
+}
+__device__ __forceinline__ void k_fetch(KStage &st, const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane)
+{
+    st.r0 = k_load1(kb, ks_s, key0, S, ph, lane, 0); st.r1 = k_load1(kb, ks_s, key0, S, ph, lane, 1);
+    st.r2 = k_load1(kb, ks_s, key0, S, ph, lane, 2); st.r3 = k_load1(kb, ks_s, key0, S, ph, lane, 3);
+    st.r4 = k_load1(kb, ks_s, key0, S, ph, lane, 4); st.r5 = k_load1(kb, ks_s, key0, S, ph, lane, 5);
+    st.r6 = k_load1(kb, ks_s, key0, S, ph, lane, 6); st.r7 = k_load1(kb, ks_s, key0, S, ph, lane, 7);
+}
+__device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned char *my)
+{
+    unsigned char *base = my + (lane >> 3) * ROWB + (lane & 7) * 16;
+    *reinterpret_cast<u32x4 *>(base + 0 * 8 * ROWB) = st.r0; *reinterpret_cast<u32x4 *>(base + 1 * 8 * ROWB) = st.r1;
+    *reinterpret_cast<u32x4 *>(base + 2 * 8 * ROWB) = st.r2; *reinterpret_cast<u32x4 *>(base + 3 * 8 * ROWB) = st.r3;
+    *reinterpret_cast<u32x4 *>(base + 4 * 8 * ROWB) = st.r4; *reinterpret_cast<u32x4 *>(base + 5 * 8 * ROWB) = st.r5;
+    *reinterpret_cast<u32x4 *>(base + 6 * 8 * ROWB) = st.r6; *reinterpret_cast<u32x4 *>(base + 7 * 8 * ROWB) = st.r7;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
-                                                                int64_t ks_s, const float *__restrict__ qf, int H, int Hkv, int S,
-                                                                int W, int R, int passes, int Sp, uint16_t *__restrict__ logits)
+                                                                int64_t ks_s, const uint16_t *__restrict__ q, int64_t qs_b,
+                                                                int64_t qs_h, int64_t qs_s, int H, int Hkv, int S, int W, int R,
+                                                                int passes, int Sp, uint16_t *__restrict__ logits)
 {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
+    __shared__ float As[(D / 2) * 64];                   // A operand of every k-step, shared by the 4 waves (same head)
+    constexpr int NPH = D / DH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g = blockIdx.x % Hkv, tile = blockIdx.x / Hkv, b = blockIdx.y;
+    const int g = blockIdx.x % Hkv, blk = blockIdx.x / Hkv, nblk = gridDim.x / Hkv, b = blockIdx.y;
     const int G = H / Hkv;
-    const int key0 = tile * TKA + w * 64;
+    const int nwt = (S + 63) / 64;                       // 64-key wave tiles of this head
+    const int wave_id = blk * 4 + w, nwaves = nblk * 4;
     const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
     unsigned char *my = slab[w];
     const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
 
     for (int pass = 0; pass < passes; ++pass) {
-        const float *qa = qf + ((size_t)(b * Hkv + g) * passes + pass) * (D / 2) * 64 + lane;
-        float aq[D / 2];
-#pragma unroll
-        for (int s = 0; s < D / 2; ++s) aq[s] = qa[s * 64];
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-#pragma unroll
-        for (int ph = 0; ph < D / DH; ++ph) {
-            stage_k(kb, ks_s, key0, S, ph, lane, my);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint4 k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
-                const uint4 k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
-                const uint32_t w0[4] = {k0.x, k0.y, k0.z, k0.w}, w1[4] = {k1.x, k1.y, k1.z, k1.w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = ph * (DH / 2) + c * 4 + u;                 // dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
-                    const float b0 = h2f((uint16_t)((w0[u] >> sh) & 0xffffu));
-                    const float b1 = h2f((uint16_t)((w1[u] >> sh) & 0xffffu));
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b1, acc1, 0, 0, 0);
-                }
+        KStage st;
+        k_fetch(st, kb, ks_s, (wave_id < nwt ? wave_id : 0) * 64, S, 0, lane);
+        // A image: As[s][l] = q[row = pass*32 + (l&31)][dim = 2s + (l>>5)] (lane l of k-step s holds A[i=l&31][k=l>>5]);
+        // rows are the group's G heads x W window rows, row = i*W + r  <->  Q[b, g*G+i, S-W+r, :]   (utils.py:94)
+        if (pass) __syncthreads();
+        for (int e = threadIdx.x; e < 32 * (D / 2); e += 256) {
+            const int rowl = e / (D / 2), dp = e - rowl * (D / 2);          // one fp16 pair (dims 2dp, 2dp+1) per item
+            const int row = pass * 32 + rowl;
+            uint32_t pr = 0;
+            if (row < R) {
+                const int i = row / W, r = row - i * W;
+                pr = *reinterpret_cast<const uint32_t *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(S - W + r) * qs_s + 2 * dp);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            As[dp * 64 + rowl] = h2f((uint16_t)(pr & 0xffffu));
+            As[dp * 64 + 32 + rowl] = h2f((uint16_t)(pr >> 16));
         }
-        // C/D map: register i of lane l is row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31
+        __syncthreads();
         uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * 32) * Sp;
+
+        for (int wt = wave_id; wt < nwt; wt += nwaves) {
+            const int key0 = wt * 64;
+            f32x16 acc0, acc1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
-            if (pass * 32 + m < R) {
-                const int j0 = key0 + n31, j1 = key0 + 32 + n31;
-                if (j0 < S) lp[(size_t)m * Sp + j0] = f2h(acc0[i]);
-                if (j1 < S) lp[(size_t)m * Sp + j1] = f2h(acc1[i]);
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+                k_commit(st, lane, my);
+                // prefetch the next phase (or the next tile's first phase) while the matrix pipe runs
+                // (always issued, so that `st` stays in registers: past the last tile it re-reads this tile)
+                {
+                    const int nkey = (ph + 1 < NPH) ? key0 : ((wt + nwaves < nwt) ? (wt + nwaves) * 64 : key0);
+                    k_fetch(st, kb, ks_s, nkey, S, (ph + 1) % NPH, lane);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint4 k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
+                    const uint4 k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
+                    const uint32_t w0[4] = {k0.x, k0.y, k0.z, k0.w}, w1[4] = {k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = ph * (DH / 2) + c * 4 + u;             // dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
+                        const float b0 = h2f((uint16_t)((w0[u] >> sh) & 0xffffu));
+                        const float b1 = h2f((uint16_t)((w1[u] >> sh) & 0xffffu));
+                        const float a = As[s * 64 + lane];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // C/D map: register i of lane l is row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31
+            const int j0 = key0 + n31, j1 = key0 + 32 + n31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                if (pass * 32 + m < R) {
+                    if (j0 < S) lp[(size_t)m * Sp + j0] = f2h(acc0[i]);
+                    if (j1 < S) lp[(size_t)m * Sp + j1] = f2h(acc1[i]);
+                }
             }
         }
     }
@@ -210,8 +252,15 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
 constexpr int RS_THREADS = 1024;
 constexpr int RS_SUPER = RS_THREADS * 8 * 4;
 __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restrict__ logits, int S, int W, int Sp, float sqrtD,
-                                                               float rsqrtD, float *__restrict__ gmax, float *__restrict__ rinv)
+                                                               float rsqrtD, float *__restrict__ gmax, float *__restrict__ rinv,
+                                                               uint32_t *__restrict__ hist_zero, int hist_words)
 {
+    // zero the key histograms that score_finalize / tsp_rowsum (the next kernels on the stream) accumulate into
+    {
+        const int per = (hist_words + gridDim.x - 1) / gridDim.x;
+        const int lo = blockIdx.x * per, hi = min(lo + per, hist_words);
+        for (int i = lo + threadIdx.x; i < hi; i += RS_THREADS) hist_zero[i] = 0;
+    }
     __shared__ float smax[RS_THREADS / 64];
     __shared__ uint64_t ssum[RS_THREADS / 64];
     __shared__ int snan[RS_THREADS / 64];
@@ -219,6 +268,7 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint16_t *p = logits + (size_t)row * Sp;
     const int nsc = (S + RS_SUPER - 1) / RS_SUPER;
+    const int jlast = ((S - 1) >> 3) << 3;
     uint4 keep[4];
     float m = -INFINITY;
     for (int sc = 0; sc < nsc; ++sc) {
@@ -226,8 +276,10 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
         uint4 raw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            // unconditional loads (a predicated load costs a branch and serialises the batch): out-of-row
+            // vectors re-read the row's last vector and are ignored below
             const int j0 = base + u * (RS_THREADS * 8);
-            raw[u] = j0 < S ? *reinterpret_cast<const uint4 *>(p + j0) : make_uint4(0, 0, 0, 0);
+            raw[u] = *reinterpret_cast<const uint4 *>(p + (j0 < S ? j0 : jlast));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -262,7 +314,7 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j0 = base + u * (RS_THREADS * 8);
-                keep[u] = j0 < S ? *reinterpret_cast<const uint4 *>(p + j0) : make_uint4(0, 0, 0, 0);
+                keep[u] = *reinterpret_cast<const uint4 *>(p + (j0 < S ? j0 : jlast));
             }
         }
 #pragma unroll
@@ -294,6 +346,20 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     }
 }
 
+// one LDS histogram update per lane; the lanes that agree with lane 0 are folded into a single atomic
+__device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool active, int lane)
+{
+    const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
+    const uint64_t same = __ballot(active && bin == first);
+    if (active) {
+        if (bin == first) {
+            if (lane == __builtin_ctzll(same)) atomicAdd(&hist[first], (uint32_t)__builtin_popcountll(same));
+        } else {
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ score_finalize
 // grid (tilesC, Hkv, B), 256 threads; thread t <-> position tile*TP - pad + t, TP = 256 - 2*pad outputs per block.
 // The G*W logits of a position are fetched in batches of 32 independent loads before any arithmetic.
@@ -301,10 +367,11 @@ constexpr int FIN_MAXR = 1024;
 __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ gmax,
                                                              const float *__restrict__ rinv, int H, int Hkv, int S, int W, int Sp,
                                                              int ksize, int pooling, uint16_t *__restrict__ c_out,
-                                                             int64_t c_row_stride)
+                                                             int64_t c_row_stride, uint32_t *__restrict__ hist12)
 {
     __shared__ float s_tile[2][256];
     __shared__ float s_gmax[FIN_MAXR], s_rinv[FIN_MAXR];
+    __shared__ uint32_t s_hist[HIST12];
     const int g = blockIdx.y, b = blockIdx.z;
     const int G = H / Hkv, n = S - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * W;
     const int t = threadIdx.x;
@@ -312,22 +379,26 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
     const bool inrange = (j >= 0) && (j < n);
     const bool is_out = (t >= pad) && (t < pad + TP) && inrange;
     const size_t row0 = (size_t)(b * H + g * G) * W;
-    for (int i = t; i < R; i += 256) { s_gmax[i] = gmax[row0 + i]; s_rinv[i] = rinv[row0 + i]; }
-    __syncthreads();
     const uint16_t *lp = logits + row0 * Sp + (inrange ? j : 0);
+    for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
     float gsum = 0.0f, a = 0.0f;
-    int head = 0;
+    int head = 0, rw = 0;
     for (int rb = 0; rb < R; rb += 32) {
         uint16_t x[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) x[u] = (rb + u < R) ? lp[(size_t)(rb + u) * Sp] : (uint16_t)0;
+        for (int u = 0; u < 32; ++u) x[u] = lp[(size_t)(rb + u < R ? rb + u : R - 1) * Sp];     // unconditional (clamped) loads
+        if (rb == 0) {                                              // row statistics, fetched under the logit loads
+            for (int i = t; i < R; i += 256) { s_gmax[i] = gmax[row0 + i]; s_rinv[i] = rinv[row0 + i]; }
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             const int rr = rb + u;                                  // uniform
             if (rr < R) {
                 const float e = det_expf(h2f(x[u]) - s_gmax[rr]);
                 a = a + h2f(f2h(e * s_rinv[rr]));                   // sum over the window rows (utils.py:104)
-                if ((rr + 1) % W == 0) {                            // last window row of head `head`
+                if (++rw == W) {                                    // last window row of head `head`
+                    rw = 0;
                     float sv = inrange ? h2f(f2h(a)) : (pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY);   // padding, utils.py:106,108
                     float *st = s_tile[head & 1];
                     st[t] = sv;
@@ -352,19 +423,37 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
             }
         }
     }
-    if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + j] = f2h(gsum);
+    const uint16_t c16 = f2h(gsum);
+    if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + j] = c16;
+    // high-12-bit key histogram of this row for the selection kernel: block-local first, then one global atomic per
+    // non-empty bin (integer atomics: the counts do not depend on arrival order)
+    hist12_add(s_hist, mono16(c16) >> 4, is_out, t & 63);
+    __syncthreads();
+    uint32_t *gh = hist12 + (size_t)(b * Hkv + g) * HIST12;
+    for (int i = t; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&gh[i], v); }
 }
 
 // ------------------------------------------------------------------------------------------ tsp_rowsum
 __global__ void __launch_bounds__(256) tsp_rowsum_kernel(const uint16_t *__restrict__ c, int64_t c_row_stride, int Hkv, int n,
-                                                         uint16_t *__restrict__ t_out, int64_t t_row_stride)
+                                                         uint16_t *__restrict__ t_out, int64_t t_row_stride,
+                                                         uint32_t *__restrict__ thist)
 {
+    __shared__ uint32_t s_hist[HIST12];
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+    for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
+    __syncthreads();
     float a = 0.0f;
-    for (int g = 0; g < Hkv; ++g) a = a + h2f(c[(size_t)(b * Hkv + g) * c_row_stride + j]);
-    t_out[(size_t)b * t_row_stride + j] = f2h(a);
+    const int jc = j < n ? j : n - 1;
+    for (int g = 0; g < Hkv; ++g) a = a + h2f(c[(size_t)(b * Hkv + g) * c_row_stride + jc]);
+    const uint16_t t16 = f2h(a);
+    if (j < n) t_out[(size_t)b * t_row_stride + j] = t16;
+    if (thist) {
+        hist12_add(s_hist, mono16(t16) >> 4, j < n, threadIdx.x & 63);
+        __syncthreads();
+        uint32_t *gh = thist + (size_t)b * HIST12;
+        for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&gh[i], v); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ launcher
@@ -393,6 +482,7 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     uint16_t *logits = reinterpret_cast<uint16_t *>(ws + L.off_logits);
     float *gmax = reinterpret_cast<float *>(ws + L.off_gmax);
     float *rinv = reinterpret_cast<float *>(ws + L.off_rinv);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.off_hist);      // [B*Hkv + B][HIST12], TSP rows last
     const float sqrtD = (float)sqrt((double)p.D);
     const float rsqrtD = 1.0f / sqrtD;
     const uint16_t *kp = (const uint16_t *)k;
@@ -400,16 +490,18 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     dim3 gridA(L.ntA * p.Hkv, p.B);
 
     if (L.engine == ENGINE_MFMA) {
-        {
-            ProfScope ps_(K_PREP_Q, st);
-            hipLaunchKernelGGL(prep_q_mfma_kernel, dim3(p.D / 2, L.passes, p.B * p.Hkv), dim3(64), 0, st, (const uint16_t *)q, qs[0],
-                               qs[1], qs[2], p.H, p.Hkv, p.S, p.D, p.window, L.R, qf);
-        }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
         ProfScope ps_(K_LOGITS, st);
+        // persistent grid: 2 workgroups per CU (8 waves/CU at <=256 VGPRs), balanced over the 64-key wave tiles
+        const int nwt = (p.S + 63) / 64;
+        int nblk = (2 * 256) / (p.Hkv * p.B);
+        if (nblk < 1) nblk = 1;
+        if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
+        const int per = (nwt + nblk * 4 - 1) / (nblk * 4);           // tiles per wave
+        nblk = (nwt + per * 4 - 1) / (per * 4);                      // fewest workgroups with that many tiles per wave
+        dim3 gridM(nblk * p.Hkv, p.B);
 #define FK_LAUNCH_MFMA(DV)                                                                                                     \
-    hipLaunchKernelGGL((score_logits_mfma_kernel<DV>), gridA, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], qf, p.H, p.Hkv, p.S, \
-                       p.window, L.R, L.passes, L.Sp, logits)
+    hipLaunchKernelGGL((score_logits_mfma_kernel<DV>), gridM, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], (const uint16_t *)q, \
+                       qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, p.window, L.R, L.passes, L.Sp, logits)
         if (p.D == 64) FK_LAUNCH_MFMA(64);
         else if (p.D == 128) FK_LAUNCH_MFMA(128);
         else FK_LAUNCH_MFMA(256);
@@ -431,7 +523,7 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     {
         ProfScope ps_(K_ROWSTATS, st);
         hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, p.S, p.window, L.Sp, sqrtD,
-                           rsqrtD, gmax, rinv);
+                           rsqrtD, gmax, rinv, hist, p.B * (p.Hkv + 1) * HIST12);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     {
@@ -439,13 +531,13 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
         hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv, p.H, p.Hkv, p.S, p.window, L.Sp,
-                           p.kernel, p.pooling, c_out, c_row_stride);
+                           p.kernel, p.pooling, c_out, c_row_stride, hist);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
         ProfScope ps_(K_TSP_ROWSUM, st);
         hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((L.n + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, L.n, t_out,
-                           t_row_stride);
+                           t_row_stride, hist + (size_t)p.B * p.Hkv * HIST12);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;

@@ -4,273 +4,290 @@
 //
 // One 1024-thread workgroup per score row (rows are <= a few hundred KiB and L2 resident; the
 // stage is latency bound by design).  Exact radix select on the 16-bit order-preserving key:
-//   pass 1  256-bin histogram of the high byte      -> threshold byte, #above
-//   pass 2  256-bin histogram of the low byte among elements in the threshold byte -> k-th value
-//   pass 3  ordered compaction (ballot-free block scan): every element above the k-th value plus
-//           the first `quota` elements equal to it in ascending position  => canonical tie rule
-//   ORDER_SCORE additionally sorts the k winners by descending value with a stable 4-pass LSD
-//   radix sort (4-bit digits, wave-ballot ranking), so equal values keep ascending position.
-// Histograms are privatised 8x by lane and a wave whose lanes agree issues one LDS atomic, so
-// degenerate rows (all-equal scores, e.g. the all-ones benchmark prompt) do not serialise.
+//   pass 1  4096-bin histogram of the high 12 key bits -> threshold prefix, #above.  In the fused operator the
+//           histogram arrives ready-made: score_finalize / tsp_rowsum (1000+ workgroups) build it while they write
+//           the scores, so this single workgroup does not have to
+//   pass 2  16-bin histogram of the low 4 bits among the (few) elements carrying the threshold prefix -> k-th value
+//   pass 3  ordered compaction (one block scan per 32768 positions): every element above the k-th
+//           value plus the first `quota` elements equal to it in ascending position => canonical tie rule
+// The winners leave this kernel in ascending position together with their 16-bit keys.  ORDER_SCORE (value
+// descending, equal values in ascending position) is NOT produced by sorting here (a 4-pass radix sort on one CU
+// cost 13 us): every winner's destination slot is obtained by comparison counting over the k keys
+// (fk::rank_partial), in rank_scatter for the stand-alone API and inside the gather/compact kernel for the fused
+// operator, which spreads the k*k comparisons over the whole chip (packed 16-bit compares, ~1.5 instr per pair).
+// A row of up to 32768 positions is read ONCE (4 unconditional 16-B loads per thread, all in flight
+// together) and stays in registers for the passes; longer rows are streamed per pass.
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
+#include "rank.h"
 
 namespace fk {
 
-constexpr int SEL_LDS_LIST = 10240;   // winners kept in LDS for the sort (2 x (2+4) B each = 120 KiB)
-constexpr int SEL_MAXIT_LDS = 16;     // radix-sort iterations whose counters fit the static LDS table
+constexpr int SEL_SUPER = SEL_THREADS * 8 * 4;
 
 struct SelShared {
-    uint32_t hist[256 * 8];
-    uint32_t wtot[16];
+    uint32_t h12[HIST12];
+    uint32_t h4[16 * 8];
+    uint32_t wtot[4][16];
     uint32_t bcast[4];
-    uint32_t cnt[SEL_MAXIT_LDS * 256];
 };
 
-__device__ __forceinline__ void load8(const uint16_t *row, int j0, int n, bool vec, uint32_t key[8], bool ok[8])
+// 4 x 8 consecutive keys per thread of super chunk `sc`: vector u covers positions sc*32768 + u*8192 + tid*8 ...
+// Loads are unconditional (a predicated load costs a branch and serialises the batch): `vec` rows are 16-B aligned
+// with a padded stride, so the vector that straddles n is readable; vectors wholly past n re-read the row's last one.
+__device__ __forceinline__ void load_super(const uint16_t *row, int sc, int n, bool vec, uint4 (&raw)[4])
 {
-    if (vec && j0 + 8 <= n) {
-        uint4 raw = *reinterpret_cast<const uint4 *>(row + j0);
-        uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    const int jl = ((n - 1) >> 3) << 3;
+    if (vec) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { key[e] = mono16((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu); ok[e] = true; }
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = sc * SEL_SUPER + u * (SEL_THREADS * 8) + threadIdx.x * 8;
+            raw[u] = *reinterpret_cast<const uint4 *>(row + (j0 < n ? j0 : jl));
+        }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ok[e] = (j0 + e) < n;
-            key[e] = ok[e] ? mono16(row[j0 + e]) : 0u;
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = sc * SEL_SUPER + u * (SEL_THREADS * 8) + threadIdx.x * 8;
+            uint32_t wds[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const int ja = j0 + e < n ? j0 + e : n - 1, jb = j0 + e + 1 < n ? j0 + e + 1 : n - 1;
+                wds[e >> 1] = (uint32_t)row[ja] | ((uint32_t)row[jb] << 16);
+            }
+            raw[u] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
     }
 }
+__device__ __forceinline__ uint32_t key_of(const uint4 &v, int e)
+{
+    const uint32_t w = e < 2 ? v.x : e < 4 ? v.y : e < 6 ? v.z : v.w;
+    return mono16((w >> ((e & 1) * 16)) & 0xffffu);
+}
 
-// one histogram update per lane with wave-level agreement shortcut
+// one histogram update per lane; the lanes that agree with lane 0 are folded into a single LDS atomic
 __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool active, int lane)
 {
-    uint64_t act = __ballot(active);
-    if (act == 0) return;
-    int leader = __builtin_ctzll(act);
-    uint32_t first = __shfl((int)bin, leader, 64);
-    uint64_t same = __ballot(active && bin == first);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
+    const uint64_t same = __ballot(active && bin == first);
     if (active) {
         if (bin == first) {
-            if (lane == leader) atomicAdd(&hist[first * 8 + (lane & 7)], (uint32_t)__builtin_popcountll(same));
+            if (lane == __builtin_ctzll(same)) atomicAdd(&hist[first], (uint32_t)__builtin_popcountll(same));
         } else {
-            atomicAdd(&hist[bin * 8 + (lane & 7)], 1u);
+            atomicAdd(&hist[bin], 1u);
         }
     }
 }
 
-// after a histogram pass: find the bin holding the kk-th largest element.  Executed by wave 0.
-// out: bcast[0] = bin, bcast[1] = number of elements in bins above it
-__device__ __forceinline__ void find_bin(SelShared &sh, uint32_t kk, int lane)
-{
-    // lane l owns bins 255-4l .. 252-4l (descending)
-    uint32_t c[4], loc = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        int bin = 255 - 4 * lane - u;
-        uint32_t s = 0;
-#pragma unroll
-        for (int cp = 0; cp < 8; ++cp) s += sh.hist[bin * 8 + cp];
-        c[u] = s;
-        loc += s;
-    }
-    uint32_t inc = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t v = __shfl_up((int)inc, o, 64);
-        if (lane >= o) inc += v;
-    }
-    uint32_t above = inc - loc;   // elements in bins owned by lower lanes (= higher bins)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (above < kk && kk <= above + c[u]) { sh.bcast[0] = 255 - 4 * lane - u; sh.bcast[1] = above; }
-        above += c[u];
-    }
-}
-
-// exclusive scan of arr[0..M) in place by the whole block (M <= 1024 * per, any M)
-__device__ void block_exclusive_scan(uint32_t *arr, int M, SelShared &sh)
+// Find the 12-bit bin holding the kk-th largest element: thread t owns bins 4095-4t .. 4092-4t (descending).
+// out: bcast[0] = bin, bcast[1] = number of elements in bins above it.  Whole block, ends with a barrier.
+__device__ __forceinline__ void find_bin12(SelShared &sh, uint32_t kk)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int per = (M + SEL_THREADS - 1) / SEL_THREADS;
-    const int lo = tid * per, hi = min(lo + per, M);
-    uint32_t loc = 0;
-    for (int i = lo; i < hi; ++i) loc += arr[i];
+    uint32_t c[4], loc = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { c[u] = sh.h12[HIST12 - 1 - 4 * tid - u]; loc += c[u]; }
     uint32_t inc = loc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         uint32_t v = __shfl_up((int)inc, o, 64);
         if (lane >= o) inc += v;
     }
-    if (lane == 63) sh.wtot[w] = inc;
+    if (lane == 63) sh.wtot[0][w] = inc;
     __syncthreads();
-    uint32_t base = 0;
-    for (int u = 0; u < w; ++u) base += sh.wtot[u];
-    uint32_t run = base + inc - loc;
-    for (int i = lo; i < hi; ++i) { uint32_t v = arr[i]; arr[i] = run; run += v; }
+    uint32_t above = inc - loc;
+    for (int u = 0; u < w; ++u) above += sh.wtot[0][u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (above < kk && kk <= above + c[u]) { sh.bcast[0] = HIST12 - 1 - 4 * tid - u; sh.bcast[1] = above; }
+        above += c[u];
+    }
     __syncthreads();
+}
+
+// Same for the 16-bin low-nibble histogram (8 privatised copies); executed by wave 0 only.
+__device__ __forceinline__ void find_bin4(SelShared &sh, uint32_t kk, int lane)
+{
+    uint32_t c = 0;
+    if (lane < 16) {
+#pragma unroll
+        for (int cp = 0; cp < 8; ++cp) c += sh.h4[(15 - lane) * 8 + cp];      // lane l owns nibble 15-l (descending)
+    }
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        uint32_t v = __shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    const uint32_t above = inc - c;
+    if (lane < 16 && above < kk && kk <= above + c) { sh.bcast[2] = 15 - lane; sh.bcast[3] = above; }
 }
 
 __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint16_t *__restrict__ scores, int64_t row_stride, int n,
-                                                                  int k, int order, int append, int64_t *__restrict__ idx_out,
-                                                                  uint32_t *__restrict__ g_idx, uint16_t *__restrict__ g_key,
-                                                                  uint32_t *__restrict__ g_cnt, int list_in_lds)
+                                                                  int k, int append, int64_t *__restrict__ idx_out,
+                                                                  int64_t idx_row_stride, uint16_t *__restrict__ key_out,
+                                                                  int64_t key_row_stride, const uint32_t *__restrict__ hist12)
 {
     __shared__ SelShared sh;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rowi = blockIdx.x;
     const uint16_t *row = scores + (size_t)rowi * row_stride;
-    int64_t *out = idx_out + (size_t)rowi * (size_t)(k + append);
-    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
-    const int nchunks = (n + 8191) / 8192;
+    int64_t *out = idx_out + (size_t)rowi * idx_row_stride;
+    uint16_t *kout = key_out ? key_out + (size_t)rowi * key_row_stride : nullptr;
+    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) && (row_stride >= (((int64_t)n + 7) & ~(int64_t)7));
+    const int nsuper = (n + SEL_SUPER - 1) / SEL_SUPER;
 
-    for (int a = tid; a < append; a += SEL_THREADS) out[k + a] = (int64_t)n + a;
+    for (int a = tid; a < append; a += SEL_THREADS) out[k + a] = (int64_t)n + a;     // the window positions (utils.py:128-129)
     if (k == 0) return;
 
-    // ---------------- pass 1: high byte
-    for (int i = tid; i < 256 * 8; i += SEL_THREADS) sh.hist[i] = 0;
-    __syncthreads();
-    for (int it = 0; it < nchunks; ++it) {
-        uint32_t key[8]; bool ok[8];
-        load8(row, it * 8192 + tid * 8, n, vec, key, ok);
+    uint4 raw[4];
+    load_super(row, 0, n, vec, raw);                       // the whole row when n <= 32768
+    // ---------------- pass 1: histogram of the high 12 key bits (ready-made in the fused operator)
+    if (hist12) {
+        const uint32_t *gh = hist12 + (size_t)rowi * HIST12;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hist_add(sh.hist, key[e] >> 8, ok[e], lane);
-    }
-    __syncthreads();
-    if (w == 0) find_bin(sh, (uint32_t)k, lane);
-    __syncthreads();
-    const uint32_t thr_hi = sh.bcast[0], above_hi = sh.bcast[1];
-    __syncthreads();
-    // ---------------- pass 2: low byte inside the threshold byte
-    for (int i = tid; i < 256 * 8; i += SEL_THREADS) sh.hist[i] = 0;
-    __syncthreads();
-    for (int it = 0; it < nchunks; ++it) {
-        uint32_t key[8]; bool ok[8];
-        load8(row, it * 8192 + tid * 8, n, vec, key, ok);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hist_add(sh.hist, key[e] & 0xffu, ok[e] && (key[e] >> 8) == thr_hi, lane);
-    }
-    __syncthreads();
-    if (w == 0) find_bin(sh, (uint32_t)k - above_hi, lane);
-    __syncthreads();
-    const uint32_t thr = (thr_hi << 8) | sh.bcast[0];
-    const uint32_t quota = (uint32_t)k - (above_hi + sh.bcast[1]);   // elements equal to thr that are kept
-    __syncthreads();
-
-    // winner lists for ORDER_SCORE (ping-pong A/B)
-    const int kal = (k + 7) & ~7;
-    uint32_t *idxA, *idxB; uint16_t *keyA, *keyB;
-    if (list_in_lds) {
-        idxA = reinterpret_cast<uint32_t *>(dyn); idxB = idxA + kal;
-        keyA = reinterpret_cast<uint16_t *>(idxB + kal); keyB = keyA + kal;
+        for (int u = 0; u < 4; ++u) sh.h12[u * SEL_THREADS + tid] = gh[u * SEL_THREADS + tid];
     } else {
-        idxA = g_idx + (size_t)rowi * 2 * kal; idxB = idxA + kal;
-        keyA = g_key + (size_t)rowi * 2 * kal; keyB = keyA + kal;
-    }
-
-    // ---------------- pass 3: ordered compaction
-    uint32_t gt_base = 0, eq_base = 0;
-    for (int it = 0; it < nchunks; ++it) {
-        uint32_t key[8]; bool ok[8];
-        const int j0 = it * 8192 + tid * 8;
-        load8(row, j0, n, vec, key, ok);
-        uint32_t cg = 0, ce = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { cg += (ok[e] && key[e] > thr); ce += (ok[e] && key[e] == thr); }
-        uint32_t pk = cg | (ce << 16), inc = pk;
+        for (int u = 0; u < 4; ++u) sh.h12[u * SEL_THREADS + tid] = 0;
+        __syncthreads();
+        for (int sc = 0; sc < nsuper; ++sc) {
+            if (sc) load_super(row, sc, n, vec, raw);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j0 = sc * SEL_SUPER + u * (SEL_THREADS * 8) + tid * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hist_add(sh.h12, key_of(raw[u], e) >> 4, j0 + e < n, lane);
+            }
+        }
+    }
+    if (tid < 16 * 8) sh.h4[tid] = 0;
+    __syncthreads();
+    find_bin12(sh, (uint32_t)k);
+    const uint32_t thr12 = sh.bcast[0], above12 = sh.bcast[1];
+    // ---------------- pass 2: low nibble among the elements carrying the threshold prefix
+    for (int sc = 0; sc < nsuper; ++sc) {
+        if (nsuper > 1) load_super(row, sc, n, vec, raw);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = sc * SEL_SUPER + u * (SEL_THREADS * 8) + tid * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t key = key_of(raw[u], e);
+                if ((j0 + e < n) && (key >> 4) == thr12) atomicAdd(&sh.h4[(key & 15u) * 8 + (lane & 7)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (w == 0) find_bin4(sh, (uint32_t)k - above12, lane);
+    __syncthreads();
+    const uint32_t thr = (thr12 << 4) | sh.bcast[2];
+    const uint32_t quota = (uint32_t)k - (above12 + sh.bcast[3]);   // elements equal to thr that are kept
+
+    // ---------------- pass 3: ordered compaction, one block scan per super chunk
+    uint32_t gt_base = 0, eq_base = 0;
+    for (int sc = 0; sc < nsuper; ++sc) {
+        if (nsuper > 1) load_super(row, sc, n, vec, raw);
+        uint32_t pk[4], inc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = sc * SEL_SUPER + u * (SEL_THREADS * 8) + tid * 8;
+            uint32_t cg = 0, ce = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t key = key_of(raw[u], e);
+                const bool ok = j0 + e < n;
+                cg += (ok && key > thr);
+                ce += (ok && key == thr);
+            }
+            pk[u] = cg | (ce << 16);
+            inc[u] = pk[u];
+        }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t v = __shfl_up((int)inc, o, 64);
-            if (lane >= o) inc += v;
-        }
-        if (lane == 63) sh.wtot[w] = inc;
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-        for (int u = 0; u < 16; ++u) { uint32_t v = sh.wtot[u]; if (u < w) base += v; total += v; }
-        uint32_t ex = base + inc - pk;
-        uint32_t gt_before = gt_base + (ex & 0xffffu), eq_before = eq_base + (ex >> 16);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (!ok[e]) continue;
-            int pos = -1;
-            if (key[e] > thr) { pos = (int)(gt_before + min(eq_before, quota)); gt_before++; }
-            else if (key[e] == thr) { if (eq_before < quota) pos = (int)(gt_before + eq_before); eq_before++; }
-            if (pos >= 0) {
-                if (order == FASTKV_ORDER_INDEX) out[pos] = (int64_t)(j0 + e);
-                else { idxA[pos] = (uint32_t)(j0 + e); keyA[pos] = (uint16_t)(0xffffu - key[e]); }
+            for (int u = 0; u < 4; ++u) {
+                uint32_t v = __shfl_up((int)inc[u], o, 64);
+                if (lane >= o) inc[u] += v;
+            }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sh.wtot[u][w] = inc[u];
+        }
+        __syncthreads();
+        // packed totals of everything before (u, w) in (u, w) order: lane l of every wave scans entry l of the 4x16 table
+        const uint32_t tv = sh.wtot[lane >> 4][lane & 15];
+        uint32_t tinc = tv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up((int)tinc, o, 64);
+            if (lane >= o) tinc += v;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)tinc, 63, 64);
+        const uint32_t texc = tinc - tv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = sc * SEL_SUPER + u * (SEL_THREADS * 8) + tid * 8;
+            const uint32_t ex = (uint32_t)__shfl((int)texc, u * 16 + w, 64) + inc[u] - pk[u];
+            uint32_t gt_before = gt_base + (ex & 0xffffu), eq_before = eq_base + (ex >> 16);
+            if (pk[u]) {                                      // most vectors hold no winner
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t key = key_of(raw[u], e);
+                    if (j0 + e < n) {
+                        int pos = -1;
+                        if (key > thr) { pos = (int)(gt_before + min(eq_before, quota)); gt_before++; }
+                        else if (key == thr) { if (eq_before < quota) pos = (int)(gt_before + eq_before); eq_before++; }
+                        if (pos >= 0) {
+                            out[pos] = (int64_t)(j0 + e);
+                            if (kout) kout[pos] = (uint16_t)key;
+                        }
+                    }
+                }
             }
         }
         gt_base += total & 0xffffu;
         eq_base += total >> 16;
         __syncthreads();
     }
-    if (order == FASTKV_ORDER_INDEX) return;
-
-    // ---------------- ORDER_SCORE: stable LSD radix sort of (inverted key, idx), ascending
-    const int iters = (k + SEL_THREADS - 1) / SEL_THREADS;
-    uint32_t *cnt = (iters <= SEL_MAXIT_LDS) ? sh.cnt : (g_cnt + (size_t)rowi * iters * 256);
-    const int M = iters * 256;
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = pass * 4;
-        for (int i = tid; i < M; i += SEL_THREADS) cnt[i] = 0;
-        __syncthreads();
-        for (int it = 0; it < iters; ++it) {
-            const int item = it * SEL_THREADS + tid;
-            const bool act = item < k;
-            const uint32_t d = act ? ((keyA[item] >> shift) & 15u) : 16u;
-            uint64_t mine = 0;
-#pragma unroll
-            for (uint32_t v = 0; v < 16; ++v) { uint64_t m = __ballot(d == v); if (d == v) mine = m; }
-            if (act && (mine & lt_mask) == 0) cnt[(d * iters + it) * 16 + w] = (uint32_t)__builtin_popcountll(mine);
-        }
-        __syncthreads();
-        block_exclusive_scan(cnt, M, sh);
-        for (int it = 0; it < iters; ++it) {
-            const int item = it * SEL_THREADS + tid;
-            const bool act = item < k;
-            const uint32_t kv = act ? keyA[item] : 0u;
-            const uint32_t d = act ? ((kv >> shift) & 15u) : 16u;
-            uint64_t mine = 0;
-#pragma unroll
-            for (uint32_t v = 0; v < 16; ++v) { uint64_t m = __ballot(d == v); if (d == v) mine = m; }
-            if (act) {
-                uint32_t pos = cnt[(d * iters + it) * 16 + w] + (uint32_t)__builtin_popcountll(mine & lt_mask);
-                keyB[pos] = (uint16_t)kv;
-                idxB[pos] = idxA[item];
-            }
-        }
-        __syncthreads();
-        uint32_t *ti = idxA; idxA = idxB; idxB = ti;
-        uint16_t *tk = keyA; keyA = keyB; keyB = tk;
-    }
-    for (int i = tid; i < k; i += SEL_THREADS) out[i] = (int64_t)idxA[i];
+    // pad the key list to a multiple of 8 with the smallest key (rank_partial reads whole vectors)
+    if (kout) for (int i = k + tid; i < ((k + 7) & ~7); i += SEL_THREADS) kout[i] = 0;
 }
 
-hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int order,
-                         int append, int64_t *idx_out, char *ws, hipStream_t st)
+// Stand-alone ORDER_SCORE: out[r, rank(p)] = idx_asc[r, p].  grid (ceil(k/16), rows), 256 threads = 16 winners x 16 lanes.
+__global__ void __launch_bounds__(256) rank_scatter_kernel(const int64_t *__restrict__ idx_asc, int64_t asc_row_stride,
+                                                           const uint16_t *__restrict__ keys, int64_t key_row_stride, int k,
+                                                           int64_t *__restrict__ out, int64_t out_row_stride)
+{
+    const int rowi = blockIdx.y, sub = threadIdx.x & 15;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const uint16_t *kr = keys + (size_t)rowi * key_row_stride;
+    const int pc = p < k ? p : k - 1;
+    uint32_t r = rank_partial(kr, k, pc, kr[pc], sub, 16);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) r += __shfl_xor((int)r, o, 64);
+    if (p < k && sub == 0) out[(size_t)rowi * out_row_stride + r] = idx_asc[(size_t)rowi * asc_row_stride + p];
+}
+
+hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
+                         int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
+                         const uint32_t *hist12, hipStream_t st)
 {
     if (rows == 0) return hipSuccess;
-    const int64_t kal = (k + 7) & ~(int64_t)7;
-    const int list_in_lds = (order == FASTKV_ORDER_SCORE && kal <= SEL_LDS_LIST) ? 1 : 0;
-    size_t dyn = list_in_lds ? (size_t)kal * 2 * (sizeof(uint32_t) + sizeof(uint16_t)) : 0;
-    // global fallbacks (only touched when the lists / counters do not fit LDS)
-    uint32_t *g_idx = reinterpret_cast<uint32_t *>(ws);
-    uint16_t *g_key = reinterpret_cast<uint16_t *>(ws + align_up((size_t)rows * 2 * kal * sizeof(uint32_t), 256));
-    uint32_t *g_cnt = reinterpret_cast<uint32_t *>(ws + align_up((size_t)rows * 2 * kal * sizeof(uint32_t), 256) +
-                                                   align_up((size_t)rows * 2 * kal * sizeof(uint16_t), 256));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  SEL_LDS_LIST * 2 * 6);
-        attr_set = true;
-    }
     ProfScope ps_(K_SELECT, st);
-    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)rows), dim3(SEL_THREADS), dyn, st, scores, row_stride, (int)n, (int)k,
-                       order, append, idx_out, g_idx, g_key, g_cnt, list_in_lds);
+    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)rows), dim3(SEL_THREADS), 0, st, scores, row_stride, (int)n, (int)k,
+                       append, idx_out, idx_row_stride, key_out, key_row_stride, hist12);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, const uint16_t *keys, int64_t key_row_stride,
+                               int64_t rows, int64_t k, int64_t *out, int64_t out_row_stride, hipStream_t st)
+{
+    if (rows == 0 || k == 0) return hipSuccess;
+    ProfScope ps_(K_RANK, st);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3((unsigned)((k + 15) / 16), (unsigned)rows), dim3(256), 0, st, idx_asc,
+                       asc_row_stride, keys, key_row_stride, (int)k, out, out_row_stride);
     return hipGetLastError();
 }
 
