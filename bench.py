@@ -126,9 +126,21 @@ def cpu_baseline(work: HotPathPrefill):
     scaled to the 16 + 16 layers of one step."""
     from oracle import fastkv_oracle as O
     from oracle.fastkv_oracle import OracleFastKVCluster
-    cores = os.cpu_count() or 1
-    O.set_threads(cores)
     G = CFG["H"] // CFG["Hkv"]
+    # pick the OpenMP thread count that is fastest on this host (hyper-threads / all 256 logical CPUs are slower)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q0, k0, v0 = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[0])
+    best = (None, 1e9)
+    for nt in sorted({min(ncpu, x) for x in (16, 32, 64, 128)}):
+        O.set_threads(nt)
+        O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
+        t0 = time.perf_counter()
+        O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
+        dt = time.perf_counter() - t0
+        if dt < best[1]:
+            best = (nt, dt)
+    cores = best[0]
+    O.set_threads(cores)
 
     def cpu_layer(i):
         q, k, v = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[i])
@@ -151,7 +163,7 @@ def cpu_baseline(work: HotPathPrefill):
     return {"value": round(CFG["S"] / step_s, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
             "ms_per_step": round(step_s * 1e3, 1),
             "sample": "oracle update_kv: layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, 1 warm-up + 1 timed "
-                      "each, scaled to 15+1+16 layers"}
+                      f"each, scaled to 15+1+16 layers; OpenMP threads auto-picked from 16/32/64/128 on {ncpu} logical CPUs"}
 
 
 def main():
@@ -240,7 +252,7 @@ def main():
             out["roofline"] = {"kernel": "score_logits (S=32768 launches)", "bound": "hbm", "achieved": round(alg / (us * 1e-6) / 1e9, 1),
                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
-                               "note": "fp32-FMA co-limited (no MFMA): 8192 flop per 256-B key row"}
+                               "note": "co-limited by the FP32 matrix pipe (v_mfma_f32_32x32x2_f32, bit-exact fma chain, same 157 TFLOP/s peak as the vector ALU): 8192 flop per 256-B key row = 2.15 GFLOP per launch"}
             cc, cms = prof["compact_kv"]
             out["compact"] = {"per_layer_avg_us": round(cms / cc * 1e3, 2),
                               "per_layer_algorithmic_bytes": 2 * (2 * Hkv * CFG["budget"] * D * 2) + Hkv * (CFG["budget"] - W) * 8,

@@ -14,7 +14,8 @@
 
 namespace fk {
 
-// grid (ceil(cap / RPB), B*Hkv, 2 {K,V}); LPR = lanes per row = D*2/16, RPB = 256/LPR rows per workgroup.
+// grid (ceil(cap / RPB), B*Hkv); LPR = lanes per row = D*2/16, RPB = 256/LPR rows per workgroup; a lane moves the
+// same 16-B piece of the K row and of the V row.
 // ONE row per thread group and many small workgroups: measured on MI355X (tools/probes/compact_probe.hip) this shape
 // moves the 32k-config layer in 4.4 us and reaches 5.2 TB/s (65 % of the 8 TB/s HBM peak) at the 539 MB roofline
 // shape, whereas 2-4 rows per thread (fewer, fatter workgroups) dropped to 0.9 TB/s at one layer: the gather is a
@@ -24,37 +25,52 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
                                                          const uint16_t *__restrict__ v, int64_t vs_b, int64_t vs_h, int64_t vs_s,
                                                          const int64_t *__restrict__ idx, const uint16_t *__restrict__ keys,
                                                          int64_t *__restrict__ idx_sorted, int Hkv, int S, int W, int cap,
-                                                         uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out)
+                                                         int keys_in_lds, uint16_t *__restrict__ k_out,
+                                                         uint16_t *__restrict__ v_out)
 {
     constexpr int RPB = 256 / LPR;
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_keys[];   // winner keys for the ranking (dynamic: 0 B when unused)
     const int bg = blockIdx.y, b = bg / Hkv, g = bg % Hkv;
-    const bool isv = blockIdx.z != 0;
-    const uint16_t *src = isv ? v + b * vs_b + (int64_t)g * vs_h : k + b * ks_b + (int64_t)g * ks_h;
-    const int64_t ss = isv ? vs_s : ks_s;
-    uint16_t *dst = (isv ? v_out : k_out) + (size_t)bg * cap * (LPR * 8);
+    const uint16_t *ksrc = k + b * ks_b + (int64_t)g * ks_h;
+    const uint16_t *vsrc = v + b * vs_b + (int64_t)g * vs_h;
+    uint16_t *kdst = k_out + (size_t)bg * cap * (LPR * 8);
+    uint16_t *vdst = v_out + (size_t)bg * cap * (LPR * 8);
     const int kk = cap - W, n = S - W;
     const int sub = threadIdx.x % LPR;
     const int r = blockIdx.x * RPB + threadIdx.x / LPR;
     const int rc = r < cap ? r : cap - 1;
-    // selected row, or one of the window rows appended after them (utils.py:118-121)
+    // selected row, or one of the window rows appended after them (utils.py:118-121); K and V rows of the same
+    // position are fetched together (two independent 16-B loads per lane in flight)
     const int64_t srow = rc < kk ? idx[(size_t)bg * kk + rc] : (int64_t)(n + (rc - kk));
-    const uint4 val = *reinterpret_cast<const uint4 *>(src + srow * ss + sub * 8);
+    const uint4 kval = *reinterpret_cast<const uint4 *>(ksrc + srow * ks_s + sub * 8);
+    const uint4 vval = *reinterpret_cast<const uint4 *>(vsrc + srow * vs_s + sub * 8);
     int d = rc;
     if (keys) {
         // ORDER_SCORE: the winner at ascending-position slot r goes to slot rank(r) (value descending, ties by position);
-        // the LPR lanes of the row share the comparison counting, which runs under the latency of the row load above
+        // the LPR lanes of the row share the comparison counting, which runs under the latency of the row loads above
         const int kal = (kk + 7) & ~7;
         const uint16_t *kr = keys + (size_t)bg * kal;
         const int pc = rc < kk ? rc : kk - 1;
-        uint32_t rk = rank_partial(kr, kk, pc, kr[pc], sub, LPR);
+        uint32_t rk;
+        if (keys_in_lds) {                                    // one 16-B load per thread instead of kal/8/LPR dependent L2 trips
+            for (int i = threadIdx.x * 8; i < kal; i += 256 * 8)
+                *reinterpret_cast<uint4 *>(s_keys + i) = *reinterpret_cast<const uint4 *>(kr + i);
+            __syncthreads();
+            rk = rank_partial(s_keys, kk, pc, s_keys[pc], sub, LPR);
+        } else {
+            rk = rank_partial(kr, kk, pc, kr[pc], sub, LPR);
+        }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) rk += __shfl_xor((int)rk, o, 64);
         if (rc < kk) {
             d = (int)rk;
-            if (idx_sorted && !isv && sub == 0) idx_sorted[(size_t)bg * kk + d] = srow;
+            if (idx_sorted && sub == 0) idx_sorted[(size_t)bg * kk + d] = srow;
         }
     }
-    if (r < cap) *reinterpret_cast<uint4 *>(dst + (size_t)d * (LPR * 8) + sub * 8) = val;
+    if (r < cap) {
+        *reinterpret_cast<uint4 *>(kdst + (size_t)d * (LPR * 8) + sub * 8) = kval;
+        *reinterpret_cast<uint4 *>(vdst + (size_t)d * (LPR * 8) + sub * 8) = vval;
+    }
 }
 
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
@@ -63,13 +79,15 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
 {
     const int lpr = p.D / 8;
     const int rows_per_block = 256 / lpr;
-    dim3 grid((p.capacity + rows_per_block - 1) / rows_per_block, p.B * p.Hkv, 2);
+    dim3 grid((p.capacity + rows_per_block - 1) / rows_per_block, p.B * p.Hkv);
     ProfScope ps_(K_COMPACT, st);
+    const size_t kal = ((size_t)(p.capacity - p.window) + 7) & ~(size_t)7;
+    const int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                // 32 KiB of LDS at most
+    const size_t dyn = keys_in_lds ? kal * sizeof(uint16_t) : 0;
 #define FK_COMPACT(LPRV)                                                                                                   \
-    hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],         \
+    hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), dyn, st, (const uint16_t *)k, ks[0], ks[1], ks[2],       \
                        (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \
-                       p.capacity, (uint16_t *)k_out,                                                                      \
-                       (uint16_t *)v_out)
+                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out)
     if (lpr == 8) FK_COMPACT(8);
     else if (lpr == 16) FK_COMPACT(16);
     else FK_COMPACT(32);

@@ -20,26 +20,41 @@ __device__ __forceinline__ uint32_t pk_gt(uint32_t w, uint32_t t)
 // keys: 16-B aligned list of k order-preserving 16-bit keys, zero padded to a multiple of 8.
 __device__ __forceinline__ uint32_t rank_partial(const uint16_t *__restrict__ keys, int k, int p, uint32_t kp, int sub, int nsub)
 {
-    const int nv = (k + 7) >> 3, pv = p >> 3;
-    const uint32_t t_hi = kp * 0x00010001u;                       // j > p:  key_j >  kp
-    const uint32_t t_lo = (kp - 1u) * 0x00010001u;                // j < p:  key_j >= kp  <=>  key_j > kp - 1   (kp > 0)
-    uint32_t acc = 0, extra = 0;
-    for (int v = sub; v < nv; v += nsub) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(keys + v * 8);
-        if (v == pv || kp == 0) {                                 // the vector that holds p (or the degenerate key 0): element-wise
-            const uint32_t wds[4] = {x.x, x.y, x.z, x.w};
+    const int nv = (k + 7) >> 3, pv = p >> 3, pe = p & 7;
+    if (kp == 0) {                                                // degenerate smallest key (a NaN score): plain counting
+        uint32_t cnt = 0;
+        for (int j = sub; j < k; j += nsub) { const uint32_t kj = keys[j]; cnt += (kj > kp) || (kj == kp && j < p); }
+        return cnt;
+    }
+    // branch-free packed counting: per 16-bit half, 1 if key_j > threshold_j with
+    //   threshold_j = kp - 1 for j < p (key_j >= kp), kp for j >= p (key_j > kp; j == p itself never counts),
+    //   0xffff for vectors past the list (nothing counts; the zero padding inside the last vector never exceeds kp >= 1)
+    const uint32_t t_hi = kp * 0x00010001u, t_lo = (kp - 1u) * 0x00010001u;
+    uint32_t tm[4];                                               // thresholds of the vector that holds p
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t kj = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                const int j = v * 8 + e;
-                extra += (j < k) && ((kj > kp) || (kj == kp && j < p));
-            }
-        } else {
-            const uint32_t t = v < pv ? t_lo : t_hi;
-            acc += pk_gt(x.x, t) + pk_gt(x.y, t) + pk_gt(x.z, t) + pk_gt(x.w, t);      // halves stay < 65536: k <= 131064
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = (2 * i < pe) ? kp - 1u : kp, hi = (2 * i + 1 < pe) ? kp - 1u : kp;
+        tm[i] = lo | (hi << 16);
+    }
+    uint32_t acc = 0;
+    // 4 key vectors per step, loaded together (a one-vector loop is a chain of dependent round trips)
+    for (int v0 = sub; v0 < nv; v0 += 4 * nsub) {
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = v0 + u * nsub;
+            x[u] = *reinterpret_cast<const uint4 *>(keys + (v < nv ? v : nv - 1) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = v0 + u * nsub;
+            const uint32_t tside = v >= nv ? 0xffffffffu : (v < pv ? t_lo : t_hi);
+            const bool mid = (v == pv);
+            acc += pk_gt(x[u].x, mid ? tm[0] : tside) + pk_gt(x[u].y, mid ? tm[1] : tside) +
+                   pk_gt(x[u].z, mid ? tm[2] : tside) + pk_gt(x[u].w, mid ? tm[3] : tside);      // halves stay < 65536: k <= 131064
         }
     }
-    return (acc & 0xffffu) + (acc >> 16) + extra;
+    return (acc & 0xffffu) + (acc >> 16);
 }
 
 }  // namespace fk

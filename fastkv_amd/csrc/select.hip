@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint16_t
             }
             pk[u] = cg | (ce << 16);
             inc[u] = pk[u];
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint16_t
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);               // keep the four vectors' code apart (register pressure)
         }
         gt_base += total & 0xffffu;
         eq_base += total >> 16;

@@ -114,19 +114,15 @@ static inline float fix_to_f32(uint64_t s)
 
 /* ---------------------------------------------------------------- stage 1: logits */
 
-/* L[b,h,r,j] = fp16( fp32(fp16(q_r . k_j)) / sqrtD ) (+ window mask), utils.py:93-101 */
-static void logits_bh(const uint16_t *q, int64_t qs_s, const uint16_t *k, int64_t ks_s,
-                      int S, int D, int W, float sqrtD, uint16_t *L /* [W][S] */)
+/* L[r][j] = fp16( fp32(fp16(q_r . k_j)) / sqrtD ) (+ window mask) for keys j in [j_lo, j_hi), utils.py:93-101 */
+static void logits_chunk(const float *qf /* [W][D] */, const uint16_t *k, int64_t ks_s, int S, int D, int W, float sqrtD,
+                         int j_lo, int j_hi, uint16_t *L /* [W][S] */)
 {
     enum { TJ = 64 };
-    float *qf = (float *)malloc(sizeof(float) * (size_t)W * D);
     float *kT = (float *)aligned_alloc(64, sizeof(float) * (size_t)D * TJ);
     float acc[TJ] __attribute__((aligned(64)));
-    for (int r = 0; r < W; r++)
-        for (int d = 0; d < D; d++)
-            qf[r * D + d] = h2f(q[(int64_t)(S - W + r) * qs_s + d]);
-    for (int j0 = 0; j0 < S; j0 += TJ) {
-        int tj = S - j0 < TJ ? S - j0 : TJ;
+    for (int j0 = j_lo; j0 < j_hi; j0 += TJ) {
+        int tj = j_hi - j0 < TJ ? j_hi - j0 : TJ;
         for (int jj = 0; jj < TJ; jj++) {
             const uint16_t *kr = k + (int64_t)(j0 + (jj < tj ? jj : 0)) * ks_s;
             for (int d = 0; d < D; d++) kT[d * TJ + jj] = h2f(kr[d]);
@@ -149,34 +145,33 @@ static void logits_bh(const uint16_t *q, int64_t qs_s, const uint16_t *k, int64_
             }
         }
     }
-    free(qf); free(kT);
+    free(kT);
 }
 
-/* ---------------------------------------------------------------- stage 2: softmax -> row sums */
+/* ---------------------------------------------------------------- stage 2: softmax statistics per row */
 
-/* s[j] = fp16( sum_r fp32( fp16( softmax_row_r(L)[j] ) ) ), j < n = S-W.  utils.py:103-104 */
-static void softmax_rowsum_h(const uint16_t *L, int S, int W, uint16_t *s_out)
+/* rmax = max_j L[j]; rinv = 1 / sum_j det_exp(L[j] - rmax) (fixed-point sum), NaN if the row holds a NaN.  utils.py:103 */
+static void row_stats(const uint16_t *row, int S, float *rmax, float *rinv)
 {
-    int n = S - W;
-    float *rmax = (float *)malloc(sizeof(float) * W);
-    float *rinv = (float *)malloc(sizeof(float) * W);
-    for (int r = 0; r < W; r++) {
-        const uint16_t *row = L + (int64_t)r * S;
-        float m = -INFINITY; int has_nan = 0;
-        for (int j = 0; j < S; j++) { float x = h2f(row[j]); if (x != x) has_nan = 1; if (x > m) m = x; }
-        uint64_t acc_hi = 0, acc_lo = 0;
-        for (int j = 0; j < S; j++) {
-            uint32_t hi, lo;
-            float e = det_expf(h2f(row[j]) - m);
-            if (e != e) { has_nan = 1; continue; }
-            exp_to_fix(e, &hi, &lo);
-            acc_hi += hi; acc_lo += lo;
-        }
-        float sum = fix_to_f32((acc_hi << 24) + acc_lo);
-        rmax[r] = m;
-        rinv[r] = has_nan ? NAN : 1.0f / sum;
+    float m = -INFINITY; int has_nan = 0;
+    for (int j = 0; j < S; j++) { float x = h2f(row[j]); if (x != x) has_nan = 1; if (x > m) m = x; }
+    uint64_t acc_hi = 0, acc_lo = 0;
+    for (int j = 0; j < S; j++) {
+        uint32_t hi, lo;
+        float e = det_expf(h2f(row[j]) - m);
+        if (e != e) { has_nan = 1; continue; }
+        exp_to_fix(e, &hi, &lo);
+        acc_hi += hi; acc_lo += lo;
     }
-    for (int j = 0; j < n; j++) {
+    float sum = fix_to_f32((acc_hi << 24) + acc_lo);
+    *rmax = m;
+    *rinv = has_nan ? NAN : 1.0f / sum;
+}
+
+/* s[j] = fp16( sum_r fp32( fp16( softmax_row_r(L)[j] ) ) ) for j in [j_lo, j_hi).  utils.py:103-104 */
+static void rowsum_chunk(const uint16_t *L, int S, int W, const float *rmax, const float *rinv, int j_lo, int j_hi, uint16_t *s_out)
+{
+    for (int j = j_lo; j < j_hi; j++) {
         float a = 0.0f;
         for (int r = 0; r < W; r++) {
             float e = det_expf(h2f(L[(int64_t)r * S + j]) - rmax[r]);
@@ -184,25 +179,24 @@ static void softmax_rowsum_h(const uint16_t *L, int S, int W, uint16_t *s_out)
         }
         s_out[j] = f2h(a);
     }
-    free(rmax); free(rinv);
 }
 
 /* ---------------------------------------------------------------- stage 3: pooling */
 
-/* utils.py:105-108; pooling 0 = avgpool, 1 = maxpool; kernel odd, pad = kernel/2, stride 1 */
-static void pool_row(const uint16_t *s, int n, int ksize, int pooling, uint16_t *out)
+/* utils.py:105-108; pooling 0 = avgpool, 1 = maxpool; kernel odd, pad = kernel/2, stride 1; outputs j in [j_lo, j_hi) */
+static void pool_chunk(const uint16_t *s, int n, int ksize, int pooling, int j_lo, int j_hi, uint16_t *out)
 {
     int pad = ksize / 2;
     if (pooling == 0) {
         float div = (float)ksize;
-        for (int j = 0; j < n; j++) {
+        for (int j = j_lo; j < j_hi; j++) {
             float a = 0.0f;
             for (int t = j - pad; t <= j + pad; t++)
                 if (t >= 0 && t < n) a = a + h2f(s[t]);
             out[j] = f2h(a / div);
         }
     } else {
-        for (int j = 0; j < n; j++) {
+        for (int j = j_lo; j < j_hi; j++) {
             float a = -INFINITY;
             for (int t = j - pad; t <= j + pad; t++)
                 if (t >= 0 && t < n) { float x = h2f(s[t]); if (x > a || x != x) a = x; }
@@ -214,7 +208,8 @@ static void pool_row(const uint16_t *s, int n, int ksize, int pooling, uint16_t 
 /* ---------------------------------------------------------------- scores */
 
 /* c[b,g,j] (utils.py:93-112) and optionally t[b,j] = fp16(sum_g c[b,g,j]) (utils.py:127).
- * logits_out (optional): [B,H,W,S] fp16 scaled+masked logits, for kernel-level tests. */
+ * logits_out (optional): [B,H,W,S] fp16 scaled+masked logits, for kernel-level tests.
+ * Every stage is parallel over (row, chunk of positions) so that the CPU baseline uses all host cores. */
 int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
                              int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
                              uint16_t *c_out, uint16_t *t_out, uint16_t *logits_out)
@@ -222,42 +217,73 @@ int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_
     if (!q || !k || !c_out || B < 1 || Hkv < 1 || H < Hkv || H % Hkv || D < 1 || W < 1 || S <= W) return FK_EINVAL;
     if (ksize < 1 || !(ksize & 1) || (pooling != 0 && pooling != 1)) return FK_EINVAL;
     if (qs[3] != 1 || ks[3] != 1) return FK_EINVAL;
-    const int G = H / Hkv, n = S - W;
+    enum { CH = 2048 };
+    const int G = H / Hkv, n = S - W, BH = B * H;
+    const int nchS = (S + CH - 1) / CH, nchN = (n + CH - 1) / CH;
     const float sqrtD = (float)sqrt((double)D);
-    uint16_t *pooled = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B * H * n);
-    if (!pooled) return FK_ENOMEM;
-    int err = 0;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int bh = 0; bh < B * H; bh++) {
-        int b = bh / H, h = bh % H, g = h / G;
-        uint16_t *L = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)W * S);
-        uint16_t *srow = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n);
-        if (!L || !srow) { err = 1; free(L); free(srow); continue; }
-        logits_bh(q + b * qs[0] + h * qs[1], qs[2], k + b * ks[0] + g * ks[1], ks[2], S, D, W, sqrtD, L);
-        if (logits_out) memcpy(logits_out + (int64_t)bh * W * S, L, sizeof(uint16_t) * (size_t)W * S);
-        softmax_rowsum_h(L, S, W, srow);
-        pool_row(srow, n, ksize, pooling, pooled + (int64_t)bh * n);
-        free(L); free(srow);
+    uint16_t *L = logits_out ? logits_out : (uint16_t *)malloc(sizeof(uint16_t) * (size_t)BH * W * S);
+    uint16_t *srow = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)BH * n);
+    uint16_t *pooled = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)BH * n);
+    float *qf = (float *)malloc(sizeof(float) * (size_t)BH * W * D);
+    float *rmax = (float *)malloc(sizeof(float) * (size_t)BH * W), *rinv = (float *)malloc(sizeof(float) * (size_t)BH * W);
+    if (!L || !srow || !pooled || !qf || !rmax || !rinv) {
+        if (!logits_out) free(L);
+        free(srow); free(pooled); free(qf); free(rmax); free(rinv);
+        return FK_ENOMEM;
     }
-    if (err) { free(pooled); return FK_ENOMEM; }
-#pragma omp parallel for schedule(static)
-    for (int bg = 0; bg < B * Hkv; bg++) {
-        int b = bg / Hkv, g = bg % Hkv;
-        for (int j = 0; j < n; j++) {
-            float a = 0.0f;
-            for (int i = 0; i < G; i++) a = a + h2f(pooled[((int64_t)b * H + g * G + i) * n + j]);
-            c_out[(int64_t)bg * n + j] = f2h(a);
+    for (int bh = 0; bh < BH; bh++) {
+        int b = bh / H, h = bh % H;
+        for (int r = 0; r < W; r++)
+            for (int d = 0; d < D; d++)
+                qf[((size_t)bh * W + r) * D + d] = h2f(q[b * qs[0] + h * qs[1] + (int64_t)(S - W + r) * qs[2] + d]);
+    }
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int bh = 0; bh < BH; bh++)
+        for (int c = 0; c < nchS; c++) {
+            int b = bh / H, h = bh % H, g = h / G;
+            int lo = c * CH, hi = lo + CH < S ? lo + CH : S;
+            logits_chunk(qf + (size_t)bh * W * D, k + b * ks[0] + g * ks[1], ks[2], S, D, W, sqrtD, lo, hi,
+                         L + (size_t)bh * W * S);
         }
-    }
-    if (t_out) {
-        for (int b = 0; b < B; b++)
-            for (int j = 0; j < n; j++) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int row = 0; row < BH * W; row++) row_stats(L + (size_t)row * S, S, &rmax[row], &rinv[row]);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int bh = 0; bh < BH; bh++)
+        for (int c = 0; c < nchN; c++) {
+            int lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+            rowsum_chunk(L + (size_t)bh * W * S, S, W, rmax + (size_t)bh * W, rinv + (size_t)bh * W, lo, hi, srow + (size_t)bh * n);
+        }
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int bh = 0; bh < BH; bh++)
+        for (int c = 0; c < nchN; c++) {
+            int lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+            pool_chunk(srow + (size_t)bh * n, n, ksize, pooling, lo, hi, pooled + (size_t)bh * n);
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bg = 0; bg < B * Hkv; bg++)
+        for (int c = 0; c < nchN; c++) {
+            int b = bg / Hkv, g = bg % Hkv;
+            int lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+            for (int j = lo; j < hi; j++) {
                 float a = 0.0f;
-                for (int g = 0; g < Hkv; g++) a = a + h2f(c_out[((int64_t)b * Hkv + g) * n + j]);
-                t_out[(int64_t)b * n + j] = f2h(a);
+                for (int i = 0; i < G; i++) a = a + h2f(pooled[((int64_t)b * H + g * G + i) * n + j]);
+                c_out[(int64_t)bg * n + j] = f2h(a);
+            }
+        }
+    if (t_out) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; b++)
+            for (int c = 0; c < nchN; c++) {
+                int lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+                for (int j = lo; j < hi; j++) {
+                    float a = 0.0f;
+                    for (int g = 0; g < Hkv; g++) a = a + h2f(c_out[((int64_t)b * Hkv + g) * n + j]);
+                    t_out[(int64_t)b * n + j] = f2h(a);
+                }
             }
     }
-    free(pooled);
+    if (!logits_out) free(L);
+    free(srow); free(pooled); free(qf); free(rmax); free(rinv);
     return FK_OK;
 }
 
@@ -347,11 +373,13 @@ int fastkv_oracle_update_kv_f16(const uint16_t *q, const int64_t *qs, const uint
     if (!c || !idx || (tsp_len && !t)) return FK_ENOMEM;
     int rc = fastkv_oracle_scores_f16(q, qs, k, ks, B, H, Hkv, S, D, W, ksize, pooling, c, t, NULL);
     if (rc == FK_OK) {
-        for (int bg = 0; bg < B * Hkv && rc == FK_OK; bg++) {
+        int rcs = FK_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int bg = 0; bg < B * Hkv; bg++) {
             int b = bg / Hkv, g = bg % Hkv;
             int64_t *ib = idx + (int64_t)bg * kk;
-            rc = fastkv_oracle_topk_f16(c + (int64_t)bg * n, n, kk, order, ib);
-            if (rc != FK_OK) break;
+            int r1 = fastkv_oracle_topk_f16(c + (int64_t)bg * n, n, kk, order, ib);
+            if (r1 != FK_OK) { rcs = r1; continue; }
             const uint16_t *ksrc = k + b * ks[0] + g * ks[1], *vsrc = v + b * vs[0] + g * vs[1];
             uint16_t *kd = k_out + (int64_t)bg * cap * D, *vd = v_out + (int64_t)bg * cap * D;
             fastkv_oracle_gather_rows(ksrc, ks[2] * 2, ib, kk, (int64_t)D * 2, kd, (int64_t)D * 2);
@@ -361,6 +389,7 @@ int fastkv_oracle_update_kv_f16(const uint16_t *q, const int64_t *qs, const uint
                 memcpy(vd + (int64_t)(kk + w) * D, vsrc + (int64_t)(n + w) * vs[2], (size_t)D * 2);
             }
         }
+        rc = rcs;
         if (rc == FK_OK && tsp_len) {
             for (int b = 0; b < B && rc == FK_OK; b++) {
                 int64_t *tb = tsp_idx_out + (int64_t)b * tsp_len;
