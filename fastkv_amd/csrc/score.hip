@@ -149,11 +149,8 @@ __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *
             for (int ph = 0; ph < NPH; ++ph) {
                 k_commit(st, lane, my);
                 // prefetch the next phase (or the next tile's first phase) while the matrix pipe runs
-                // (always issued, so that `st` stays in registers: past the last tile it re-reads this tile)
-                {
-                    const int nkey = (ph + 1 < NPH) ? key0 : ((wt + nwaves < nwt) ? (wt + nwaves) * 64 : key0);
-                    k_fetch(st, kb, ks_s, nkey, S, (ph + 1) % NPH, lane);
-                }
+                if (ph + 1 < NPH) k_fetch(st, kb, ks_s, key0, S, ph + 1, lane);
+                else if (wt + nwaves < nwt) k_fetch(st, kb, ks_s, (wt + nwaves) * 64, S, 0, lane);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const uint4 k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
