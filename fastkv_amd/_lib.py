@@ -20,8 +20,14 @@ class Problem(ctypes.Structure):
                                               "tsp_len", "order", "reserved")]
 
 
+class SPWindow(ctypes.Structure):
+    """struct fastkv_sp_window (include/fastkv_hip.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("ncols", "pos0", "own_lo", "own_hi", "S_glob", "Sp")]
+
+
 EXPORTS = ["fastkv_workspace_bytes", "fastkv_update_kv_f16", "fastkv_score_f16", "fastkv_select_f16",
-           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_debug_contract", "fastkv_profile_enable",
+           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
+           "fastkv_sp_scores_f16", "fastkv_debug_contract", "fastkv_profile_enable",
            "fastkv_profile_kernels", "fastkv_profile_kernel_name", "fastkv_profile_read", "fastkv_strerror", "fastkv_version"]
 
 _lib = None
@@ -55,6 +61,17 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_compact_f16.restype = ci
     L.fastkv_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp]
     L.fastkv_gather_rows.restype = ci
+    wp = ctypes.POINTER(SPWindow)
+    L.fastkv_sp_workspace_bytes.argtypes = [pp]
+    L.fastkv_sp_workspace_bytes.restype = sz
+    L.fastkv_sp_logits_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, i64, i64, vp, sz, vp]
+    L.fastkv_sp_logits_f16.restype = ci
+    L.fastkv_sp_rowmax_f16.argtypes = [pp, vp, wp, vp, vp]
+    L.fastkv_sp_rowmax_f16.restype = ci
+    L.fastkv_sp_rowsum_f16.argtypes = [pp, vp, wp, vp, vp, vp]
+    L.fastkv_sp_rowsum_f16.restype = ci
+    L.fastkv_sp_scores_f16.argtypes = [pp, vp, wp, vp, vp, vp, vp, vp, sz, vp]
+    L.fastkv_sp_scores_f16.restype = ci
     L.fastkv_debug_contract.argtypes = [ci, vp, vp, vp, vp, ci, vp]
     L.fastkv_debug_contract.restype = ci
     L.fastkv_profile_enable.argtypes = [ci]

@@ -96,7 +96,8 @@ int fastkv_compact_f16(const fastkv_problem *p, const void *k, const int64_t k_s
 {
     int rc;
     if ((rc = check_problem(p)) != FASTKV_OK) return rc;
-    if ((rc = check_select(p)) != FASTKV_OK) return rc;
+    // the caller's indices define the rows (repeats allowed), so capacity may exceed S here; only the window must fit
+    if (p->capacity <= p->window || p->window > p->S) return FASTKV_EINVAL;
     if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
     if ((rc = check_strides(v, v_strides)) != FASTKV_OK) return rc;
     if (!idx || !k_out || !v_out) return FASTKV_EINVAL;
@@ -162,6 +163,84 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
         return FASTKV_EINVAL;
     hipError_t e = launch_gather_rows(src, src_batch_stride_bytes, src_row_stride_bytes, idx, idx_batch_stride, batches, rows_out,
                                       rows_in, row_bytes, dst, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+// ---- sequence-sharded stages -------------------------------------------------------------------------------
+static size_t sp_qf_bytes(const fastkv_problem *p)
+{
+    fastkv_problem pp = *p;
+    pp.capacity = pp.S;
+    const Layout L = make_layout(pp);
+    return align_up((size_t)p->B * p->Hkv * L.R_alloc * p->D * 4, 256);
+}
+
+size_t fastkv_sp_workspace_bytes(const fastkv_problem *p)
+{
+    if (check_problem(p) != FASTKV_OK) return 0;
+    return sp_qf_bytes(p) + align_up((size_t)p->B * p->H * p->window * 4, 256);
+}
+
+static int check_window(const fastkv_problem *p, const fastkv_sp_window *w)
+{
+    if (!w || w->ncols < 1 || w->own_lo < 0 || w->own_hi > w->ncols || w->own_lo > w->own_hi) return FASTKV_EINVAL;
+    if (w->Sp < w->ncols || (w->Sp & 7) || w->S_glob <= p->window || (int64_t)w->S_glob >= (1ll << 24)) return FASTKV_EINVAL;
+    return FASTKV_OK;
+}
+
+int fastkv_sp_logits_f16(const fastkv_problem *p, const void *q_win, const int64_t q_strides[4], const void *k,
+                         const int64_t k_strides[4], void *logits, int64_t Sp, int64_t col_off, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    if (!p || p->S < 1) return FASTKV_EINVAL;
+    fastkv_problem pp = *p;
+    pp.S = p->S + p->window;                                  // shape checks only (a local call may hold few keys)
+    int rc;
+    if ((rc = check_problem(&pp)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(q_win, q_strides)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
+    if (!logits || !workspace || workspace_bytes < fastkv_sp_workspace_bytes(&pp) || (Sp & 7) || col_off < 0 || col_off + p->S > Sp)
+        return FASTKV_EINVAL;
+    hipError_t e = launch_sp_logits(*p, q_win, q_strides, k, k_strides, (uint16_t *)logits, (int)Sp, (int)col_off,
+                                    (float *)workspace, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_sp_rowmax_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, float *local_max, void *stream)
+{
+    if (!p || !logits || !local_max) return FASTKV_EINVAL;
+    int rc;
+    if ((rc = check_window(p, w)) != FASTKV_OK) return rc;
+    hipError_t e = launch_sp_rowstats(*p, (uint16_t *)logits, *w, 1, local_max, nullptr, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_sp_rowsum_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, const float *global_max,
+                         int64_t *local_sum, void *stream)
+{
+    if (!p || !logits || !global_max || !local_sum) return FASTKV_EINVAL;
+    int rc;
+    if ((rc = check_window(p, w)) != FASTKV_OK) return rc;
+    hipError_t e = launch_sp_rowstats(*p, (uint16_t *)logits, *w, 2, const_cast<float *>(global_max), local_sum, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_sp_scores_f16(const fastkv_problem *p, const void *logits, const fastkv_sp_window *w, const float *global_max,
+                         const int64_t *global_sum, void *c_out, void *t_out, void *workspace, size_t workspace_bytes,
+                         void *stream)
+{
+    if (!p || !logits || !global_max || !global_sum || !workspace) return FASTKV_EINVAL;
+    int rc;
+    if ((rc = check_window(p, w)) != FASTKV_OK) return rc;
+    if (p->kernel < 1 || (p->kernel & 1) == 0 || p->kernel > 63) return FASTKV_EINVAL;
+    if (workspace_bytes < fastkv_sp_workspace_bytes(p)) return FASTKV_EWORKSPACE;
+    const int n_glob = w->S_glob - p->window;
+    int hi = w->own_hi < n_glob - w->pos0 ? w->own_hi : n_glob - w->pos0;
+    const int n_own = hi - w->own_lo;
+    if (n_own > 0 && !c_out) return FASTKV_EINVAL;
+    float *rinv = reinterpret_cast<float *>((char *)workspace + sp_qf_bytes(p));
+    hipError_t e = launch_sp_scores(*p, (const uint16_t *)logits, *w, global_max, global_sum, rinv, (uint16_t *)c_out, n_own,
+                                    (uint16_t *)t_out, n_own, n_own, (hipStream_t)stream);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

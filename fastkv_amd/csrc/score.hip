@@ -28,6 +28,16 @@ namespace fk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// A rank's view of a logits row.  Column x holds global prompt position pos0 + x.  One GPU: ncols = S, pos0 = 0,
+// own = [0, S).  Sequence sharding (fastkv_amd/dist.py): the row holds the rank's positions plus `pad` halo columns on
+// either side (needed by the pooling window); statistics and outputs cover the owned columns only.
+struct ColWin {
+    int ncols;            // columns present in the row
+    int pos0;             // global position of column 0 (negative when the left halo precedes position 0)
+    int own_lo, own_hi;   // owned columns
+    int S_glob;           // global prompt length (window = its last W positions)
+};
+
 // ------------------------------------------------------------------------------------------ prep_q (vector-ALU layout)
 // qf[bg][pass][d][RB] (row fastest), so the (row,row+1) operand pairs of v_pk_fma_f32 are adjacent scalars.
 // grid (R_alloc, B*Hkv), D threads
@@ -105,8 +115,9 @@ __device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned ch
 template <int D>
 __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
                                                                 int64_t ks_s, const uint16_t *__restrict__ q, int64_t qs_b,
-                                                                int64_t qs_h, int64_t qs_s, int H, int Hkv, int S, int W, int R,
-                                                                int passes, int Sp, uint16_t *__restrict__ logits)
+                                                                int64_t qs_h, int64_t qs_s, int q_row0, int H, int Hkv, int S,
+                                                                int W, int R, int passes, int Sp, int col_off,
+                                                                uint16_t *__restrict__ logits)
 {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
     __shared__ float As[(D / 2) * 64];                   // A operand of every k-step, shared by the 4 waves (same head)
@@ -132,13 +143,13 @@ __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *
             uint32_t pr = 0;
             if (row < R) {
                 const int i = row / W, r = row - i * W;
-                pr = *reinterpret_cast<const uint32_t *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(S - W + r) * qs_s + 2 * dp);
+                pr = *reinterpret_cast<const uint32_t *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(q_row0 + r) * qs_s + 2 * dp);
             }
             As[dp * 64 + rowl] = h2f((uint16_t)(pr & 0xffffu));
             As[dp * 64 + 32 + rowl] = h2f((uint16_t)(pr >> 16));
         }
         __syncthreads();
-        uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * 32) * Sp;
+        uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * 32) * Sp + col_off;
 
         for (int wt = wave_id; wt < nwt; wt += nwaves) {
             const int key0 = wt * 64;
@@ -188,7 +199,7 @@ __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *
 template <int D, int RB>
 __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                            const float *__restrict__ qf, int H, int Hkv, int S, int W, int R,
-                                                           int passes, int Sp, uint16_t *__restrict__ logits)
+                                                           int passes, int Sp, int col_off, uint16_t *__restrict__ logits)
 {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -233,7 +244,7 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
         }
         // epilogue: the matmul output rounded to fp16 (utils.py:94); scaling and masking happen in row_stats
         if (j < S) {
-            uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * RB) * Sp + j;
+            uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * RB) * Sp + col_off + j;
 #pragma unroll
             for (int r = 0; r < RB; ++r)
                 if (pass * RB + r < R) lp[(size_t)r * Sp] = f2h(acc[r]);
@@ -248,12 +259,15 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
 // S <= 32768) and re-reading only what the same thread wrote for longer rows.
 constexpr int RS_THREADS = 1024;
 constexpr int RS_SUPER = RS_THREADS * 8 * 4;
-__global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restrict__ logits, int S, int W, int Sp, float sqrtD,
-                                                               float rsqrtD, float *__restrict__ gmax, float *__restrict__ rinv,
+// mode 0 (one GPU): scale+mask, max, sum -> gmax, rinv.  Sequence sharding splits it around the two all-reduces:
+// mode 1: scale+mask, local max -> gmax[row];  mode 2: sum given the global max in gmax[row] -> sums[row] (2^-40 fixed point).
+__global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restrict__ logits, ColWin cw, int W, int Sp, float sqrtD,
+                                                               float rsqrtD, int mode, float *__restrict__ gmax,
+                                                               float *__restrict__ rinv, uint64_t *__restrict__ sums,
                                                                uint32_t *__restrict__ hist_zero, int hist_words)
 {
     // zero the key histograms that score_finalize / tsp_rowsum (the next kernels on the stream) accumulate into
-    {
+    if (hist_zero) {
         const int per = (hist_words + gridDim.x - 1) / gridDim.x;
         const int lo = blockIdx.x * per, hi = min(lo + per, hist_words);
         for (int i = lo + threadIdx.x; i < hi; i += RS_THREADS) hist_zero[i] = 0;
@@ -261,14 +275,15 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     __shared__ float smax[RS_THREADS / 64];
     __shared__ uint64_t ssum[RS_THREADS / 64];
     __shared__ int snan[RS_THREADS / 64];
-    const int row = blockIdx.x, rw = row % W, n = S - W;
+    const int row = blockIdx.x, rw = row % W, n = cw.S_glob - W, S = cw.ncols;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint16_t *p = logits + (size_t)row * Sp;
     const int nsc = (S + RS_SUPER - 1) / RS_SUPER;
     const int jlast = ((S - 1) >> 3) << 3;
     uint4 keep[4];
     float m = -INFINITY;
-    for (int sc = 0; sc < nsc; ++sc) {
+    int sawnan = 0;
+    for (int sc = 0; sc < (mode == 2 ? 0 : nsc); ++sc) {
         const int base = sc * RS_SUPER + threadIdx.x * 8;
         uint4 raw[4];
 #pragma unroll
@@ -285,11 +300,11 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
             uint32_t outw[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int j = j0 + e;
+                const int j = j0 + e, jg = cw.pos0 + j;                              // column, global position
                 uint16_t l16 = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
                 uint16_t s16 = f2h(scale_div(h2f(l16), sqrtD, rsqrtD));
-                if (j >= n && (j - n) > rw) s16 = f2h(h2f(s16) + (-65504.0f));      // utils.py:95-101
-                if (j < S) m = fmaxf(m, h2f(s16));
+                if (jg >= n && (jg - n) > rw) s16 = f2h(h2f(s16) + (-65504.0f));    // utils.py:95-101
+                if (j >= cw.own_lo && j < cw.own_hi) { const float xs = h2f(s16); m = fmaxf(m, xs); sawnan |= (xs != xs); }
                 outw[e >> 1] |= (uint32_t)s16 << ((e & 1) * 16);
             }
             keep[u] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
@@ -302,12 +317,18 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     m = smax[0];
 #pragma unroll
     for (int u = 1; u < RS_THREADS / 64; ++u) m = fmaxf(m, smax[u]);
+    if (mode == 1) {                                           // gmax[rows + row] = 1 if the owned columns hold a NaN
+        sawnan = __syncthreads_or(sawnan);
+        if (threadIdx.x == 0) { gmax[row] = m; gmax[gridDim.x + row] = sawnan ? 1.0f : 0.0f; }
+        return;
+    }
+    if (mode == 2) m = gmax[row];
 
     uint64_t ahi = 0, alo = 0;
     int nan = 0;
     for (int sc = nsc - 1; sc >= 0; --sc) {
         const int base = sc * RS_SUPER + threadIdx.x * 8;
-        if (sc != nsc - 1) {
+        if (sc != nsc - 1 || mode == 2) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j0 = base + u * (RS_THREADS * 8);
@@ -320,7 +341,7 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
             const uint32_t wds[4] = {keep[u].x, keep[u].y, keep[u].z, keep[u].w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (j0 + e < S) {
+                if (j0 + e >= cw.own_lo && j0 + e < cw.own_hi) {
                     uint16_t hb = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
                     float ex = det_expf(h2f(hb) - m);
                     if (ex != ex) nan = 1;
@@ -338,9 +359,22 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
         int bad = 0;
 #pragma unroll
         for (int u = 0; u < RS_THREADS / 64; ++u) { s += ssum[u]; bad |= snan[u]; }
-        gmax[row] = m;
-        rinv[row] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);
+        if (mode == 2) {
+            sums[row] = bad ? FK_SUM_POISON : s;
+        } else {
+            gmax[row] = m;
+            rinv[row] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);
+        }
     }
+}
+
+// rinv = 1 / sum for globally reduced fixed-point sums (sequence sharding); nanflag (max-reduced over the ranks) marks
+// rows that hold a NaN somewhere in the prompt: their probabilities are NaN, as on one GPU.
+__global__ void stats_finish_kernel(const int64_t *__restrict__ sums, const float *__restrict__ nanflag, int rows,
+                                    float *__restrict__ rinv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) rinv[i] = (nanflag[i] != 0.0f || sums[i] < 0) ? __builtin_nanf("") : 1.0f / fix_to_f32((uint64_t)sums[i]);
 }
 
 // one LDS histogram update per lane; the lanes that agree with lane 0 are folded into a single atomic
@@ -362,19 +396,19 @@ __device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool ac
 // The G*W logits of a position are fetched in batches of 32 independent loads before any arithmetic.
 constexpr int FIN_MAXR = 1024;
 __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ gmax,
-                                                             const float *__restrict__ rinv, int H, int Hkv, int S, int W, int Sp,
-                                                             int ksize, int pooling, uint16_t *__restrict__ c_out,
+                                                             const float *__restrict__ rinv, int H, int Hkv, ColWin cw, int W,
+                                                             int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
                                                              int64_t c_row_stride, uint32_t *__restrict__ hist12)
 {
     __shared__ float s_tile[2][256];
     __shared__ float s_gmax[FIN_MAXR], s_rinv[FIN_MAXR];
     __shared__ uint32_t s_hist[HIST12];
     const int g = blockIdx.y, b = blockIdx.z;
-    const int G = H / Hkv, n = S - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * W;
+    const int G = H / Hkv, n = cw.S_glob - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * W;
     const int t = threadIdx.x;
-    const int j = blockIdx.x * TP - pad + t;
-    const bool inrange = (j >= 0) && (j < n);
-    const bool is_out = (t >= pad) && (t < pad + TP) && inrange;
+    const int j = cw.own_lo + blockIdx.x * TP - pad + t;            // column; global candidate position pos0 + j
+    const bool inrange = (j >= 0) && (j < cw.ncols) && (cw.pos0 + j >= 0) && (cw.pos0 + j < n);
+    const bool is_out = (t >= pad) && (t < pad + TP) && inrange && (j >= cw.own_lo) && (j < cw.own_hi);
     const size_t row0 = (size_t)(b * H + g * G) * W;
     const uint16_t *lp = logits + row0 * Sp + (inrange ? j : 0);
     for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
@@ -421,9 +455,10 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
         }
     }
     const uint16_t c16 = f2h(gsum);
-    if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + j] = c16;
+    if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + (j - cw.own_lo)] = c16;
     // high-12-bit key histogram of this row for the selection kernel: block-local first, then one global atomic per
     // non-empty bin (integer atomics: the counts do not depend on arrival order)
+    if (!hist12) return;
     hist12_add(s_hist, mono16(c16) >> 4, is_out, t & 63);
     __syncthreads();
     uint32_t *gh = hist12 + (size_t)(b * Hkv + g) * HIST12;
@@ -453,21 +488,57 @@ __global__ void __launch_bounds__(256) tsp_rowsum_kernel(const uint16_t *__restr
     }
 }
 
-// ------------------------------------------------------------------------------------------ launcher
-template <int D>
-static hipError_t launch_logits_valu(int RB, dim3 grid, hipStream_t st, const uint16_t *k, const int64_t *ks, const float *qf,
-                                     const fastkv_problem &p, const Layout &L, uint16_t *logits)
+// ------------------------------------------------------------------------------------------ launchers
+// K streaming + contraction: logits[b,h,r, col_off + j] = fp16(q_r . k_j) for the p.S keys of `k` (raw, unscaled).
+// q rows are q[b, h, q_row0 + r, :].  `qf` = fp32 scratch of the vector-ALU engine (unused by the matrix-pipe engine).
+static hipError_t launch_logits(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, int q_row0,
+                                const void *k, const int64_t *ks, float *qf, uint16_t *logits, int Sp, int col_off, hipStream_t st)
 {
-#define FK_LAUNCH_RB(RBV)                                                                                                  \
-    hipLaunchKernelGGL((score_logits_kernel<D, RBV>), grid, dim3(256), 0, st, k, ks[0], ks[1], ks[2], qf, p.H, p.Hkv, p.S, \
-                       p.window, L.R, L.passes, L.Sp, logits)
-    switch (RB) {
-    case 8: FK_LAUNCH_RB(8); break;
-    case 16: FK_LAUNCH_RB(16); break;
-    case 32: FK_LAUNCH_RB(32); break;
-    default: FK_LAUNCH_RB(64); break;
+    const uint16_t *kp = (const uint16_t *)k;
+    hipError_t e;
+    if (L.engine == ENGINE_MFMA) {
+        ProfScope ps_(K_LOGITS, st);
+        // persistent grid: 2 workgroups per CU (8 waves/CU at <=256 VGPRs), balanced over the 64-key wave tiles
+        const int nwt = (p.S + 63) / 64;
+        int nblk = (2 * 256) / (p.Hkv * p.B);
+        if (nblk < 1) nblk = 1;
+        if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
+        const int per = (nwt + nblk * 4 - 1) / (nblk * 4);           // tiles per wave
+        nblk = (nwt + per * 4 - 1) / (per * 4);                      // fewest workgroups with that many tiles per wave
+        dim3 gridM(nblk * p.Hkv, p.B);
+#define FK_LAUNCH_MFMA(DV)                                                                                                     \
+    hipLaunchKernelGGL((score_logits_mfma_kernel<DV>), gridM, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], (const uint16_t *)q, \
+                       qs[0], qs[1], qs[2], q_row0, p.H, p.Hkv, p.S, p.window, L.R, L.passes, Sp, col_off, logits)
+        if (p.D == 64) FK_LAUNCH_MFMA(64);
+        else if (p.D == 128) FK_LAUNCH_MFMA(128);
+        else FK_LAUNCH_MFMA(256);
+#undef FK_LAUNCH_MFMA
+        return hipGetLastError();
     }
-#undef FK_LAUNCH_RB
+    {
+        ProfScope ps_(K_PREP_Q, st);
+        // prep_q indexes the query rows as (S - W + r): pass S = q_row0 + W
+        hipLaunchKernelGGL(prep_q_kernel, dim3(L.R_alloc, p.B * p.Hkv), dim3(p.D), 0, st, (const uint16_t *)q, qs[0], qs[1], qs[2],
+                           p.H, p.Hkv, q_row0 + p.window, p.D, p.window, L.R, L.R_alloc, L.RB, qf);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    ProfScope ps_(K_LOGITS, st);
+    dim3 gridA(((p.S + TKA - 1) / TKA) * p.Hkv, p.B);
+#define FK_LAUNCH_VALU(DV, RBV)                                                                                              \
+    hipLaunchKernelGGL((score_logits_kernel<DV, RBV>), gridA, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], qf, p.H, p.Hkv, p.S, \
+                       p.window, L.R, L.passes, Sp, col_off, logits)
+#define FK_LAUNCH_VALU_D(DV)                                                                \
+    switch (L.RB) {                                                                         \
+    case 8: FK_LAUNCH_VALU(DV, 8); break;                                                   \
+    case 16: FK_LAUNCH_VALU(DV, 16); break;                                                 \
+    case 32: FK_LAUNCH_VALU(DV, 32); break;                                                 \
+    default: FK_LAUNCH_VALU(DV, 64); break;                                                 \
+    }
+    if (p.D == 64) { FK_LAUNCH_VALU_D(64) }
+    else if (p.D == 128) { FK_LAUNCH_VALU_D(128) }
+    else { FK_LAUNCH_VALU_D(256) }
+#undef FK_LAUNCH_VALU_D
+#undef FK_LAUNCH_VALU
     return hipGetLastError();
 }
 
@@ -482,52 +553,21 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.off_hist);      // [B*Hkv + B][HIST12], TSP rows last
     const float sqrtD = (float)sqrt((double)p.D);
     const float rsqrtD = 1.0f / sqrtD;
-    const uint16_t *kp = (const uint16_t *)k;
+    const ColWin cw = {p.S, 0, 0, p.S, p.S};
     hipError_t e;
-    dim3 gridA(L.ntA * p.Hkv, p.B);
 
-    if (L.engine == ENGINE_MFMA) {
-        ProfScope ps_(K_LOGITS, st);
-        // persistent grid: 2 workgroups per CU (8 waves/CU at <=256 VGPRs), balanced over the 64-key wave tiles
-        const int nwt = (p.S + 63) / 64;
-        int nblk = (2 * 256) / (p.Hkv * p.B);
-        if (nblk < 1) nblk = 1;
-        if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
-        const int per = (nwt + nblk * 4 - 1) / (nblk * 4);           // tiles per wave
-        nblk = (nwt + per * 4 - 1) / (per * 4);                      // fewest workgroups with that many tiles per wave
-        dim3 gridM(nblk * p.Hkv, p.B);
-#define FK_LAUNCH_MFMA(DV)                                                                                                     \
-    hipLaunchKernelGGL((score_logits_mfma_kernel<DV>), gridM, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], (const uint16_t *)q, \
-                       qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, p.window, L.R, L.passes, L.Sp, logits)
-        if (p.D == 64) FK_LAUNCH_MFMA(64);
-        else if (p.D == 128) FK_LAUNCH_MFMA(128);
-        else FK_LAUNCH_MFMA(256);
-#undef FK_LAUNCH_MFMA
-        e = hipGetLastError();
-    } else {
-        {
-            ProfScope ps_(K_PREP_Q, st);
-            hipLaunchKernelGGL(prep_q_kernel, dim3(L.R_alloc, p.B * p.Hkv), dim3(p.D), 0, st, (const uint16_t *)q, qs[0], qs[1],
-                               qs[2], p.H, p.Hkv, p.S, p.D, p.window, L.R, L.R_alloc, L.RB, qf);
-        }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        ProfScope ps_(K_LOGITS, st);
-        if (p.D == 64) e = launch_logits_valu<64>(L.RB, gridA, st, kp, ks, qf, p, L, logits);
-        else if (p.D == 128) e = launch_logits_valu<128>(L.RB, gridA, st, kp, ks, qf, p, L, logits);
-        else e = launch_logits_valu<256>(L.RB, gridA, st, kp, ks, qf, p, L, logits);
-    }
-    if (e != hipSuccess) return e;
+    if ((e = launch_logits(p, L, q, qs, p.S - p.window, k, ks, qf, logits, L.Sp, 0, st)) != hipSuccess) return e;
     {
         ProfScope ps_(K_ROWSTATS, st);
-        hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, p.S, p.window, L.Sp, sqrtD,
-                           rsqrtD, gmax, rinv, hist, p.B * (p.Hkv + 1) * HIST12);
+        hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, cw, p.window, L.Sp, sqrtD,
+                           rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, p.B * (p.Hkv + 1) * HIST12);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     {
         ProfScope ps_(K_FINALIZE, st);
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
-        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv, p.H, p.Hkv, p.S, p.window, L.Sp,
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv, p.H, p.Hkv, cw, p.window, L.Sp,
                            p.kernel, p.pooling, c_out, c_row_stride, hist);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -535,6 +575,55 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         ProfScope ps_(K_TSP_ROWSUM, st);
         hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((L.n + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, L.n, t_out,
                            t_row_stride, hist + (size_t)p.B * p.Hkv * HIST12);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------ sequence-sharded stages
+// (fastkv_amd/dist.py; include/fastkv_hip.h "fastkv_sp_*").  `p` describes the rank-local call: p.S = keys in `k`.
+hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
+                            uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st)
+{
+    fastkv_problem pp = p;
+    pp.capacity = pp.S;
+    const Layout L = make_layout(pp);
+    return launch_logits(pp, L, q_win, qs, 0, k, ks, qf_scratch, logits, Sp, col_off, st);
+}
+
+hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,
+                              int64_t *sums, hipStream_t st)
+{
+    const float sqrtD = (float)sqrt((double)p.D);
+    const ColWin cw = {w.ncols, w.pos0, w.own_lo, w.own_hi, w.S_glob};
+    ProfScope ps_(K_ROWSTATS, st);
+    hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, cw, p.window, w.Sp, sqrtD,
+                       1.0f / sqrtD, mode, gmax, (float *)nullptr, (uint64_t *)sums, (uint32_t *)nullptr, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_sp_scores(const fastkv_problem &p, const uint16_t *logits, const fastkv_sp_window &w, const float *gmax,
+                            const int64_t *sums, float *rinv_scratch, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out,
+                            int64_t t_row_stride, int n_own, hipStream_t st)
+{
+    const ColWin cw = {w.ncols, w.pos0, w.own_lo, w.own_hi, w.S_glob};
+    const int rows = p.B * p.H * p.window;
+    hipError_t e;
+    hipLaunchKernelGGL(stats_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, sums, gmax + rows, rows, rinv_scratch);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (n_own <= 0) return hipSuccess;
+    {
+        ProfScope ps_(K_FINALIZE, st);
+        const int pad = p.kernel / 2, TP = 256 - 2 * pad;
+        dim3 gridC((n_own + TP - 1) / TP, p.Hkv, p.B);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv_scratch, p.H, p.Hkv, cw, p.window,
+                           w.Sp, p.kernel, p.pooling, c_out, c_row_stride, (uint32_t *)nullptr);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (t_out) {
+        ProfScope ps_(K_TSP_ROWSUM, st);
+        hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((n_own + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, n_own,
+                           t_out, t_row_stride, (uint32_t *)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;

@@ -115,6 +115,40 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
                        int64_t rows_in, int64_t row_bytes, void *dst, void *stream);
 
 /*
+ * ---- Sequence-sharded building blocks (one prompt split over P GPUs on the sequence axis; fastkv_amd/dist.py) ----
+ * The reference has no multi-GPU path; these stages let P ranks reproduce the single-GPU result bit for bit:
+ * scores are local per position, the only global quantities are the per-row softmax max / sum (two tiny all-reduces;
+ * the sum is 2^-40 fixed point, i.e. exact and order-free) and the top-k threshold (one all-gather of candidates).
+ *
+ * A rank's logits row has `ncols` columns; column x holds global position pos0 + x.  [own_lo, own_hi) are the columns
+ * the rank owns; the `kernel/2` columns on either side are halo positions owned by the neighbours (their K rows are
+ * exchanged up front) that the pooling window needs.  Sp = row stride in elements (multiple of 8).
+ */
+typedef struct fastkv_sp_window {
+    int32_t ncols, pos0, own_lo, own_hi, S_glob, Sp;
+} fastkv_sp_window;
+
+/* scratch for the calls below: fp32 query block (vector-ALU engine) + B*H*window floats */
+size_t fastkv_sp_workspace_bytes(const fastkv_problem *p);
+/* raw fp16 logits of the p->S keys in `k` against the window queries q_win [B,H,window,D] (utils.py:94 matmul),
+ * written to logits[b,h,r, col_off + j], rows of stride Sp */
+int fastkv_sp_logits_f16(const fastkv_problem *p, const void *q_win, const int64_t q_strides[4], const void *k,
+                         const int64_t k_strides[4], void *logits, int64_t Sp, int64_t col_off, void *workspace,
+                         size_t workspace_bytes, void *stream);
+/* in place: scale by sqrt(D) + window mask on all columns (utils.py:94-101); local_max[2*B*H*window]: the maxima over the
+ * owned columns, followed by one NaN flag (0/1) per row -- all-reduce the whole buffer with MAX */
+int fastkv_sp_rowmax_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, float *local_max, void *stream);
+/* local_sum[B*H*window] (int64, 2^-40 fixed point) = sum over owned columns of exp(x - global_max); all-reduce with SUM */
+int fastkv_sp_rowsum_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, const float *global_max,
+                         int64_t *local_sum, void *stream);
+/* scores of the owned candidate positions: c_out [B,Hkv,n_own] (utils.py:103-112), t_out [B,n_own] optional (utils.py:127);
+ * n_own = min(own_hi, S_glob - window - pos0) - own_lo */
+/* global_max: the MAX-reduced buffer of fastkv_sp_rowmax_f16 (maxima + NaN flags) */
+int fastkv_sp_scores_f16(const fastkv_problem *p, const void *logits, const fastkv_sp_window *w, const float *global_max,
+                         const int64_t *global_sum, void *c_out, void *t_out, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
  * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b)) so tests can compare the GPU bit-for-bit with the CPU oracle.

@@ -404,6 +404,142 @@ int fastkv_oracle_update_kv_f16(const uint16_t *q, const int64_t *qs, const uint
     return rc;
 }
 
+/* ---------------------------------------------------------------- sequence-sharded stages (tests of fastkv_amd/dist.py)
+ *
+ * CPU twins of the fastkv_sp_* stages of include/fastkv_hip.h: a rank's logits rows have `ncols` columns, column x holds
+ * global position pos0 + x, the rank owns columns [own_lo, own_hi).  Same arithmetic as above, split at the two
+ * all-reduces (row max, fixed-point row sum). */
+
+/* raw fp16 logits (utils.py:94 matmul only) of the S keys of `k` against q_win [B,H,W,D], into columns col_off.. */
+int fastkv_oracle_sp_logits(const uint16_t *q_win, const int64_t *qs, const uint16_t *k, const int64_t *ks, int B, int H, int Hkv,
+                            int S, int D, int W, uint16_t *logits, int64_t Sp, int64_t col_off)
+{
+    if (!q_win || !k || !logits || H % Hkv || qs[3] != 1 || ks[3] != 1) return FK_EINVAL;
+    const int G = H / Hkv;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bh = 0; bh < B * H; bh++) {
+        int b = bh / H, h = bh % H, g = h / G;
+        const uint16_t *kb = k + b * ks[0] + g * ks[1];
+        for (int r = 0; r < W; r++) {
+            const uint16_t *qr = q_win + b * qs[0] + h * qs[1] + (int64_t)r * qs[2];
+            uint16_t *row = logits + ((int64_t)bh * W + r) * Sp + col_off;
+            for (int j = 0; j < S; j++) {
+                float acc = 0.0f;
+                const uint16_t *kr = kb + (int64_t)j * ks[2];
+                for (int d = 0; d < D; d++) acc = fmaf(h2f(qr[d]), h2f(kr[d]), acc);
+                row[j] = f2h(acc);
+            }
+        }
+    }
+    return FK_OK;
+}
+
+/* in place scale + window mask of every column; out[row] = max over owned columns, out[rows + row] = NaN flag */
+int fastkv_oracle_sp_rowmax(uint16_t *logits, int rows, int W, int D, int ncols, int pos0, int own_lo, int own_hi, int S_glob,
+                            int64_t Sp, float *out)
+{
+    const float sqrtD = (float)sqrt((double)D);
+    const int n = S_glob - W;
+#pragma omp parallel for schedule(static)
+    for (int row = 0; row < rows; row++) {
+        uint16_t *p = logits + (int64_t)row * Sp;
+        int rw = row % W, sawnan = 0;
+        float m = -INFINITY;
+        for (int x = 0; x < ncols; x++) {
+            int jg = pos0 + x;
+            uint16_t s16 = f2h(h2f(p[x]) / sqrtD);
+            if (jg >= n && (jg - n) > rw) s16 = f2h(h2f(s16) + (-65504.0f));
+            p[x] = s16;
+            if (x >= own_lo && x < own_hi) { float v = h2f(s16); if (v != v) sawnan = 1; if (v > m) m = v; }
+        }
+        out[row] = m;
+        out[rows + row] = sawnan ? 1.0f : 0.0f;
+    }
+    return FK_OK;
+}
+
+int fastkv_oracle_sp_rowsum(const uint16_t *logits, int rows, int own_lo, int own_hi, int64_t Sp, const float *gmax, int64_t *sums)
+{
+#pragma omp parallel for schedule(static)
+    for (int row = 0; row < rows; row++) {
+        const uint16_t *p = logits + (int64_t)row * Sp;
+        uint64_t acc_hi = 0, acc_lo = 0;
+        for (int x = own_lo; x < own_hi; x++) {
+            uint32_t hi, lo;
+            float e = det_expf(h2f(p[x]) - gmax[row]);
+            if (e != e) continue;
+            exp_to_fix(e, &hi, &lo);
+            acc_hi += hi; acc_lo += lo;
+        }
+        sums[row] = (int64_t)((acc_hi << 24) + acc_lo);
+    }
+    return FK_OK;
+}
+
+/* c_out [B,Hkv,n_own], t_out [B,n_own] (optional) for the owned candidate columns; gmax = maxima followed by NaN flags */
+int fastkv_oracle_sp_scores(const uint16_t *logits, int B, int H, int Hkv, int W, int ksize, int pooling, int ncols, int pos0,
+                            int own_lo, int own_hi, int S_glob, int64_t Sp, const float *gmax, const int64_t *gsum,
+                            uint16_t *c_out, uint16_t *t_out)
+{
+    const int G = H / Hkv, n = S_glob - W, pad = ksize / 2, rows = B * H * W;
+    int hi = own_hi < n - pos0 ? own_hi : n - pos0;
+    const int n_own = hi - own_lo;
+    if (n_own <= 0) return FK_OK;
+    float *rinv = (float *)malloc(sizeof(float) * rows);
+    uint16_t *srow = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B * H * ncols);
+    uint16_t *pooled = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B * H * n_own);
+    if (!rinv || !srow || !pooled) { free(rinv); free(srow); free(pooled); return FK_ENOMEM; }
+    for (int i = 0; i < rows; i++) rinv[i] = (gmax[rows + i] != 0.0f || gsum[i] < 0) ? NAN : 1.0f / fix_to_f32((uint64_t)gsum[i]);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bh = 0; bh < B * H; bh++) {
+        /* s-values of every column (halo columns included), then the pooled value of the owned candidates; columns whose
+         * global position is outside [0, n) are padding (zero for avg, -inf for max), utils.py:106,108 */
+        for (int x = 0; x < ncols; x++) {
+            float a = 0.0f;
+            for (int r = 0; r < W; r++) {
+                float e = det_expf(h2f(logits[((int64_t)bh * W + r) * Sp + x]) - gmax[bh * W + r]);
+                a = a + h2f(f2h(e * rinv[bh * W + r]));
+            }
+            srow[(int64_t)bh * ncols + x] = f2h(a);
+        }
+        for (int x = own_lo; x < hi; x++) {
+            float a;
+            if (pooling == 0) {
+                a = 0.0f;
+                for (int t = x - pad; t <= x + pad; t++) {
+                    int jg = pos0 + t;
+                    if (t >= 0 && t < ncols && jg >= 0 && jg < n) a = a + h2f(srow[(int64_t)bh * ncols + t]);
+                }
+                pooled[(int64_t)bh * n_own + (x - own_lo)] = f2h(a / (float)ksize);
+            } else {
+                a = -INFINITY;
+                for (int t = x - pad; t <= x + pad; t++) {
+                    int jg = pos0 + t;
+                    if (t >= 0 && t < ncols && jg >= 0 && jg < n) { float v = h2f(srow[(int64_t)bh * ncols + t]); if (v > a || v != v) a = v; }
+                }
+                pooled[(int64_t)bh * n_own + (x - own_lo)] = f2h(a);
+            }
+        }
+    }
+    for (int bg = 0; bg < B * Hkv; bg++) {
+        int b = bg / Hkv, g = bg % Hkv;
+        for (int j = 0; j < n_own; j++) {
+            float a = 0.0f;
+            for (int i = 0; i < G; i++) a = a + h2f(pooled[((int64_t)b * H + g * G + i) * n_own + j]);
+            c_out[(int64_t)bg * n_own + j] = f2h(a);
+        }
+    }
+    if (t_out)
+        for (int b = 0; b < B; b++)
+            for (int j = 0; j < n_own; j++) {
+                float a = 0.0f;
+                for (int g = 0; g < Hkv; g++) a = a + h2f(c_out[((int64_t)b * Hkv + g) * n_own + j]);
+                t_out[(int64_t)b * n_own + j] = f2h(a);
+            }
+    free(rinv); free(srow); free(pooled);
+    return FK_OK;
+}
+
 /* exposed scalar helpers so the tests can pin the arithmetic contract element-wise */
 float fastkv_oracle_det_expf(float d) { return det_expf(d); }
 float fastkv_oracle_fix_to_f32(uint64_t s) { return fix_to_f32(s); }

@@ -1,0 +1,76 @@
+"""World-size-2/3 gloo tests (CPU) of the sequence-sharded operator: the distributed control flow of fastkv_amd/dist.py
+with oracle-backed local stages must reproduce the single-process oracle BIT FOR BIT (scores are position-local, the
+softmax statistics are exact integer/float reductions, the candidate all-gather preserves the canonical tie rule)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, lens, q_out):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastkv_amd.dist import sp_update_kv
+        from gen_inputs import make_qkv
+        from oracle import fastkv_oracle as O
+        from sp_oracle_ops import OracleLocalOps
+        O.set_threads(2)
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], full_q=True)
+        lo, hi = sum(lens[:rank]), sum(lens[:rank + 1])
+        out = sp_update_kv(k[:, :, lo:hi], q[:, :, lo:hi], v[:, :, lo:hi], window_size=case["W"], kernel_size=case["ks"],
+                           pooling=case["pooling"], capacity=case["cap"], tsp_len=case["tsp_len"], order=case["order"],
+                           local_ops=OracleLocalOps(), shard_lengths=None if case.get("discover") else lens)
+        want = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], case["order"])
+        ok = torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and torch.equal(out[3], want[2])
+        ok = ok and ((out[2] is None and want[3] is None) or torch.equal(out[2], want[3]))
+        q_out.put((rank, bool(ok)))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q_out.put((rank, "EXC " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    # two even shards, avgpool, TSP on, reference row order
+    (dict(seed=41, B=1, H=8, Hkv=2, S=512, D=128, W=8, ks=7, pooling="avgpool", cap=96, tsp_len=160, order="score"), [256, 256]),
+    # three ragged shards, maxpool (plateaus straddle shard borders), B=2, index order, lengths discovered by all-gather
+    (dict(seed=42, B=2, H=4, Hkv=2, S=700, D=64, W=8, ks=5, pooling="maxpool", cap=128, tsp_len=0, order="index", discover=True),
+     [300, 150, 250]),
+    # budget larger than a shard: the last rank contributes fewer candidates than k
+    (dict(seed=43, B=1, H=8, Hkv=1, S=400, D=128, W=8, ks=7, pooling="maxpool", cap=300, tsp_len=350, order="score"), [350, 50]),
+]
+
+
+@pytest.mark.parametrize("case,lens", CASES)
+def test_sequence_sharded_matches_single_process_oracle(case, lens):
+    world = len(lens)
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, lens, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] is True for r in res), res
