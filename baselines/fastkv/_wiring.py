@@ -1,0 +1,117 @@
+"""FastKV model wiring shared by the Llama and Mistral patches, written against the INSTALLED transformers (5.x:
+`Attention.forward(hidden_states, position_embeddings, attention_mask, past_key_values, **kw)`, decoder layers return a
+bare tensor, `DynamicCache(config=...)`).  What is FastKV-specific mirrors the reference:
+
+  * prefill (q_len > 1): `kv_cluster.update_kv(K, Q, V, mask, groups, layer_idx)`; the cache receives the COMPRESSED
+    K/V while attention runs over the full current K/V          (/root/reference/baselines/fastkv/llama_model.py:136-145)
+  * TSP layer: hidden states and position ids are gathered by `tsp_idx` AFTER the MLP residual    (llama_model.py:252-259)
+  * the model loop adopts `new_position_ids` and refreshes the rotary tables                      (llama_model.py:368-371)
+  * only the last token's hidden state reaches `lm_head`                                          (llama_model.py:392)
+"""
+from __future__ import annotations
+
+import torch
+from transformers.cache_utils import DynamicCache
+from transformers.modeling_outputs import BaseModelOutputWithPast
+
+from fastkv_amd import ops
+from fastkv_amd.cluster import init_fastkv
+
+
+def make_attention_class(base_cls, modeling, extra_attn_kwargs):
+    """Subclass of the stock attention whose prefill routes K/V through FastKVCluster.update_kv."""
+
+    class FastKVAttention(base_cls):
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            init_fastkv(self)                                     # utils.py:137-138
+            self.tsp_idx = None
+
+        def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+            input_shape = hidden_states.shape[:-1]
+            hidden_shape = (*input_shape, -1, self.head_dim)
+            q_len = input_shape[1]
+            query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+            key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+            value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+            cos, sin = position_embeddings
+            query_states, key_states = modeling.apply_rotary_pos_emb(query_states, key_states, cos, sin)
+
+            if past_key_values is not None:
+                if q_len > 1:                                     # prefill: compress what goes into the cache
+                    k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
+                                                                       self.num_key_value_groups, self.layer_idx)
+                    past_key_values.update(k_c, v_c, self.layer_idx)
+                else:                                             # decode: plain append
+                    key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
+                    self.tsp_idx = None
+
+            attention_interface = modeling.ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation,
+                                                                                modeling.eager_attention_forward)
+            attn_output, attn_weights = attention_interface(
+                self, query_states, key_states, value_states, attention_mask,
+                dropout=0.0 if not self.training else self.attention_dropout, scaling=self.scaling,
+                **extra_attn_kwargs(self), **kwargs)
+            attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+            return self.o_proj(attn_output), attn_weights
+
+    return FastKVAttention
+
+
+def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None,
+                                use_cache=False, position_embeddings=None, **kwargs):
+    residual = hidden_states
+    hidden_states = self.input_layernorm(hidden_states)
+    hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                      past_key_values=past_key_values, use_cache=use_cache,
+                                      position_embeddings=position_embeddings, **kwargs)
+    hidden_states = residual + hidden_states
+    residual = hidden_states
+    hidden_states = self.post_attention_layernorm(hidden_states)
+    hidden_states = self.mlp(hidden_states)
+    hidden_states = residual + hidden_states
+    # [FastKV] token-selective propagation: keep only the selected tokens from this layer on
+    tsp_idx = getattr(self.self_attn, "tsp_idx", None)
+    if self.self_attn.kv_cluster.tsp_layer and tsp_idx is not None:
+        self.new_position_ids = torch.gather(position_ids, dim=1, index=tsp_idx)
+        if hidden_states.is_cuda:
+            hidden_states = ops.gather_rows(hidden_states.contiguous(), tsp_idx)          # HIP row gather
+        else:
+            hidden_states = torch.gather(hidden_states, 1, tsp_idx.unsqueeze(-1).expand(-1, -1, hidden_states.size(2)))
+    else:
+        self.new_position_ids = None
+    return hidden_states
+
+
+def make_model_forward(modeling, mask_fn_for):
+    def model_forward_fastkv(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                             inputs_embeds=None, use_cache=None, **kwargs):
+        if (input_ids is None) ^ (inputs_embeds is not None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        use_cache = use_cache if use_cache is not None else self.config.use_cache
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids)
+        if use_cache and past_key_values is None:
+            past_key_values = DynamicCache(config=self.config)
+        if position_ids is None:
+            past_seen = past_key_values.get_seq_length() if past_key_values is not None else 0
+            position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + past_seen).unsqueeze(0)
+            position_ids = position_ids.expand(inputs_embeds.shape[0], -1)
+        causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                                               past_key_values=past_key_values, position_ids=position_ids)
+        hidden_states = inputs_embeds
+        position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
+        for decoder_layer in self.layers[: self.config.num_hidden_layers]:
+            hidden_states = decoder_layer(hidden_states, attention_mask=causal_mask, position_embeddings=position_embeddings,
+                                          position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,
+                                          **kwargs)
+            new_position_ids = getattr(decoder_layer, "new_position_ids", None)
+            if new_position_ids is not None:                      # after the TSP layer: fewer tokens, new rotary tables
+                position_ids = new_position_ids
+                position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
+                causal_mask = None                                # unpadded prompts only, as in the reference
+        hidden_states = self.norm(hidden_states)
+        hidden_states = hidden_states[:, -1:, :]                  # only the last token feeds lm_head
+        return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
+
+    return model_forward_fastkv

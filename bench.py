@@ -180,12 +180,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback for the product path)"
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo": two ranks on one GPU (test boxes with a single device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fastkv_amd._lib import load
     lib = load()
@@ -259,6 +264,36 @@ def main():
                               "roofline_shape": compact_roofline_shape(lib, dev, 10)}
             if world == 1 and not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(work)
+    if dist is not None and not a.no_extras:
+        # The path with a real exchange step: ONE prompt of world*32768 tokens sharded on the sequence axis (rank r holds
+        # positions [r*S, (r+1)*S)), pre-TSP layers only (after TSP the 2048 surviving tokens fit one GPU).  Per layer:
+        # window-query/K-halo all-gather, MAX and fixed-point SUM all-reduces, the candidate (index) all-gather, and the
+        # all-reduce that replicates the compacted K/V rows.  Results are bit-identical to one GPU (tests/test_dist_*).
+        from fastkv_amd.dist import HipLocalOps, sp_update_kv
+        lo = HipLocalOps()
+        lens = [CFG["S"]] * world
+
+        def seq_step():
+            for i in range(CFG["tsp_idx"] + 1):
+                q, k, v = work.layers_in[i]
+                sp_update_kv(k, q, v, window_size=CFG["window"], kernel_size=CFG["kernel"], pooling=CFG["pooling"],
+                             capacity=CFG["budget"], tsp_len=CFG["tsp_len"] if i == CFG["tsp_idx"] else 0, order="score",
+                             local_ops=lo, shard_lengths=lens)
+        for _ in range(2):
+            seq_step()
+        barrier()
+        t0 = time.perf_counter()
+        nseq = max(3, a.steps // 4)
+        for _ in range(nseq):
+            seq_step()
+        barrier()
+        dts = time.perf_counter() - t0
+        tt = torch.tensor([dts], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_seq = float(tt.item()) / nseq * 1e3
+        out["seq_sharded"] = {"prompt_tokens": world * CFG["S"], "layers": CFG["tsp_idx"] + 1, "ms_per_step": round(ms_seq, 3),
+                              "tokens_per_s": round(world * CFG["S"] / (ms_seq * 1e-3), 1), "collectives_per_layer": 5,
+                              "note": "one prompt sharded on the sequence axis; bit-identical to single GPU"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

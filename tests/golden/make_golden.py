@@ -26,9 +26,10 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.dont_write_bytecode = True
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, ROOT)
+# the reference's `baselines` package must win over this repository's drop-in package of the same name
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, "/root/reference")
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
 
 import numpy as np
 import torch
@@ -158,6 +159,40 @@ def main():
     except AssertionError:
         host["cap_le_window_error"] = ["AssertionError"]
     meta["host"] = host
+
+    # ---- decoder-layer TSP propagation (llama_model.py:252-259), captured from the reference function itself.
+    # Import-time shims only (flash_attn is not installed, the class layout is transformers-4.45): nothing is executed from them.
+    from transformers.models.llama import modeling_llama
+    fa = types.ModuleType("flash_attn")
+    fa.flash_attn_func = fa.flash_attn_varlen_func = None
+    sys.modules["flash_attn"] = fa
+    modeling_llama.LlamaFlashAttention2 = modeling_llama.LlamaAttention
+    import transformers.utils as tu
+    tu.is_flash_attn_greater_or_equal_2_10 = lambda: True
+    from baselines.fastkv.llama_model import llama_decoderlayer_forward_fastkv as ref_layer_forward
+
+    class _Attn:                                    # duck-typed attention: scales its input, exposes tsp_idx / kv_cluster
+        def __init__(self, tsp_idx, tsp_layer):
+            self.tsp_idx, self.kv_cluster = tsp_idx, types.SimpleNamespace(tsp_layer=tsp_layer)
+
+        def __call__(self, hidden_states=None, **kw):
+            return hidden_states * 0.5, None, None
+
+    Bh, Sh, Hh = 2, 48, 64
+    hid = ((torch.arange(Bh * Sh * Hh, dtype=torch.float32).view(Bh, Sh, Hh) % 97) / 8.0).half()
+    tsp = torch.stack([torch.sort(torch.randperm(Sh, generator=torch.Generator().manual_seed(5 + b))[:17]).values for b in range(Bh)])
+    pos = torch.arange(Sh)[None].expand(Bh, -1)
+    layer_g = {"hidden_in": hid.view(torch.int16).numpy(), "tsp_idx": tsp.numpy(), "position_ids": pos.numpy()}
+    for tag, tsp_layer, idx in (("tsp", True, tsp), ("not_tsp_layer", False, tsp), ("tsp_none", True, None)):
+        self_ = types.SimpleNamespace(input_layernorm=lambda x: x, post_attention_layernorm=lambda x: x, mlp=lambda x: x * 0.25,
+                                      self_attn=_Attn(idx, tsp_layer))
+        out = ref_layer_forward(self_, hid, position_ids=pos)
+        layer_g["hidden_out_" + tag] = out[0].view(torch.int16).numpy()
+        layer_g["has_new_pos_" + tag] = np.array(self_.new_position_ids is not None)
+        if self_.new_position_ids is not None:
+            layer_g["new_pos_" + tag] = self_.new_position_ids.numpy()
+    np.savez_compressed(os.path.join(HERE, "decoder_layer_tsp.npz"), **layer_g)
+    print("decoder_layer_tsp ok")
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote meta.json")

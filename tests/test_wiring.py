@@ -1,0 +1,160 @@
+"""Plugin boundary (baselines.monkeypatch) and model wiring on CPU: BASELINE.json configs[0] "CPU plumbing".
+
+The product cluster has no CPU path, so these tests put the oracle-backed cluster (test infrastructure) into the patched
+model -- what is under test is the wiring: class swap before construction, compressed K/V into the cache, TSP gather +
+position rewire + rotary refresh, last-token cut, decode after prefill, the fullkv arm, and the reference's recorded
+decoder-layer behaviour (tests/golden/decoder_layer_tsp.npz)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+
+def _oracle_cluster(old):
+    """Oracle-backed stand-in with the same attributes; the CPU model runs in fp32, the oracle (like the path) in fp16."""
+    from oracle.fastkv_oracle import OracleFastKVCluster
+
+    class Fp32Adapter(OracleFastKVCluster):
+        def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups, layer_idx):
+            dt = key_states.dtype
+            if dt == torch.float16:
+                return super().update_kv(key_states, query_states, value_states, attention_mask, num_key_value_groups, layer_idx)
+            if query_states.shape[2] < (int(query_states.shape[2] * self.retain_rate) if self.eviction_mode == "proportional"
+                                        else self.max_capacity_prompt):
+                return key_states, value_states, None
+            k, v, t = super().update_kv(key_states.half(), query_states.half(), value_states.half(), attention_mask,
+                                        num_key_value_groups, layer_idx)
+            return k.to(dt), v.to(dt), t
+
+    return Fp32Adapter(old.window_size, old.max_capacity_prompt, old.kernel_size, old.pooling, old.tsp_layer,
+                       old.tsp_length, old.tsp_rate, old.retain_rate, old.eviction_mode)
+
+
+def _args(**kw):
+    from benchmark import prefill
+    a = prefill.parse_args(["--model_path", "tiny", "--device", "cpu", "--save_txt", ""])
+    a.save_txt = False
+    a.cluster_factory = _oracle_cluster
+    a.random_tokens = True
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_fastkv_prefill_plumbing_cpu():
+    from benchmark import prefill
+    a = _args(method="fastkv", context_lengths=[300], max_capacity_prompts=64, tsp_len=96, tsp_idx=1, num_warmups=0)
+    res = prefill.run(a)[0]
+    # every layer caches exactly `capacity` rows: layers 0..tsp_idx from 300 tokens, later ones from the 96 TSP survivors
+    assert res["cache_lens"] == [64, 64, 64, 64]
+    assert res["logits_shape"][:2] == [1, 1]                         # last-token cut (llama_model.py:392)
+
+
+def test_tsp_reduces_sequence_after_tsp_layer_and_decode_works():
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import prefill
+    a = _args(method="fastkv", max_capacity_prompts=40, tsp_len=80, tsp_idx=0)
+    a.context_lengths = [200]
+    replace_llama("fastkv")
+    model = prefill.build_model(a, "cpu")
+    from transformers.models.llama import modeling_llama
+    assert type(model.model.layers[0].self_attn).__name__ == "LlamaFastKVAttention"
+    assert isinstance(model.model.layers[0].self_attn, modeling_llama._fastkv_stock_attention)
+    set_model(model, a)
+    for layer in model.model.layers:
+        layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+    seen = []
+    hooks = [l.register_forward_hook(lambda m, i, o: seen.append(o.shape[1])) for l in model.model.layers]
+    ids = torch.randint(0, 1000, (1, 200))
+    with torch.no_grad():
+        out = model(ids, attention_mask=torch.ones_like(ids))
+    for h in hooks:
+        h.remove()
+    assert seen == [80, 80, 80, 80]                                  # layer 0 is the TSP layer: its OUTPUT is already gathered
+    tsp = model.model.layers[0].self_attn.tsp_idx
+    assert tsp.shape == (1, 80) and bool((tsp[:, 1:] > tsp[:, :-1]).all()) and tsp[0, -1] == 199
+    assert torch.equal(model.model.layers[0].new_position_ids, tsp)
+    # decode one token on top of the compressed cache: cache grows by one row per layer
+    pkv = out.past_key_values
+    before = [int(pkv.layers[i].keys.shape[-2]) for i in range(4)]
+    nxt = out.logits[:, -1].argmax(-1, keepdim=True)
+    with torch.no_grad():
+        out2 = model(nxt, past_key_values=pkv, position_ids=torch.tensor([[200]]))
+    after = [int(out2.past_key_values.layers[i].keys.shape[-2]) for i in range(4)]
+    assert after == [b + 1 for b in before] and out2.logits.shape[:2] == (1, 1)
+    assert model.model.layers[0].self_attn.tsp_idx is None            # decode: no TSP (llama_model.py:143-145)
+
+
+def test_no_compression_equals_fullkv():
+    """With budgets above the prompt length FastKV takes the early-out everywhere: logits must equal the fullkv arm."""
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import prefill
+    ids = torch.randint(0, 1000, (1, 50))
+    outs = {}
+    for method in ("fastkv", "fullkv"):
+        a = _args(method=method, max_capacity_prompts=512, tsp_len=2048, tsp_idx=1)
+        a.context_lengths = [50]
+        replace_llama(method)
+        torch.manual_seed(7)
+        model = prefill.build_model(a, "cpu")
+        set_model(model, a)
+        with torch.no_grad():
+            outs[method] = model(ids, attention_mask=torch.ones_like(ids)).logits
+    assert outs["fastkv"].shape == outs["fullkv"].shape == (1, 1, 1024)
+    assert torch.equal(outs["fastkv"], outs["fullkv"])
+    replace_llama("fastkv")
+
+
+def test_mistral_patch_runs():
+    from baselines.monkeypatch import replace_mistral, set_model
+    from transformers import MistralConfig, MistralForCausalLM
+    replace_mistral("fastkv")
+    cfg = MistralConfig(hidden_size=128, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, intermediate_size=256,
+                        vocab_size=500, head_dim=32, sliding_window=None, max_position_embeddings=512)
+    cfg._attn_implementation = "sdpa"
+    model = MistralForCausalLM(cfg).eval()
+    assert type(model.model.layers[0].self_attn).__name__ == "MistralFastKVAttention"
+    a = types.SimpleNamespace(method="fastkv", window_size=8, kernel_size=5, pooling="avgpool", max_capacity_prompts=32, tsp_len=64,
+                              tsp_rate=0.2, eviction_mode="constant", tsp_idx=1, retain_rate=0.1)
+    set_model(model, a)
+    assert a.window_size == [8, 8, 8]                                 # listified like monkeypatch.py:121-139
+    for layer in model.model.layers:
+        layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+    ids = torch.randint(0, 500, (1, 150))
+    with torch.no_grad():
+        out = model(ids)
+    assert [int(out.past_key_values.layers[i].keys.shape[-2]) for i in range(3)] == [32, 32, 32]
+    assert out.logits.shape == (1, 1, 500)
+
+
+def test_unsupported_methods_are_refused():
+    from baselines.monkeypatch import replace_llama
+    with pytest.raises(NotImplementedError):
+        replace_llama("snapkv")
+
+
+def test_decoder_layer_matches_reference_golden():
+    """llama_decoderlayer_forward_fastkv of the reference, recorded on a duck-typed layer (make_golden.py)."""
+    from baselines.fastkv.llama_model import llama_decoderlayer_forward_fastkv
+    g = np.load(f"{GOLDEN}/decoder_layer_tsp.npz")
+    hid = torch.from_numpy(g["hidden_in"]).view(torch.float16)
+    tsp, pos = torch.from_numpy(g["tsp_idx"]), torch.from_numpy(g["position_ids"])
+
+    class Attn:
+        def __init__(self, idx, tsp_layer):
+            self.tsp_idx, self.kv_cluster = idx, types.SimpleNamespace(tsp_layer=tsp_layer)
+
+        def __call__(self, hidden_states=None, **kw):
+            return hidden_states * 0.5, None
+
+    for tag, tsp_layer, idx in (("tsp", True, tsp), ("not_tsp_layer", False, tsp), ("tsp_none", True, None)):
+        me = types.SimpleNamespace(input_layernorm=lambda x: x, post_attention_layernorm=lambda x: x, mlp=lambda x: x * 0.25,
+                                   self_attn=Attn(idx, tsp_layer))
+        out = llama_decoderlayer_forward_fastkv(me, hid, position_ids=pos)
+        assert torch.equal(out.view(torch.int16), torch.from_numpy(g["hidden_out_" + tag])), tag
+        assert (me.new_position_ids is not None) == bool(g["has_new_pos_" + tag]), tag
+        if me.new_position_ids is not None:
+            assert torch.equal(me.new_position_ids, torch.from_numpy(g["new_pos_" + tag]))
