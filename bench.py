@@ -166,6 +166,34 @@ def cpu_baseline(work: HotPathPrefill):
                       f"each, scaled to 15+1+16 layers; OpenMP threads auto-picked from 16/32/64/128 on {ncpu} logical CPUs"}
 
 
+def whole_model_ttft(work):
+    """BASELINE.json's other half: prefill TTFT of the whole model at 32k through the reference's own harness shape
+    (benchmark/prefill.py: monkeypatch -> model(input_ids, attention_mask), device events), random-init Llama-3-8B geometry
+    (no checkpoints on the box), PyTorch-ROCm SDPA attention; FastKV (TSP layer 15, budget 2048) vs the full-KV arm."""
+    import gc
+    del work.layers_in[:]
+    work.hidden = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    from benchmark import prefill
+    res = {}
+    for method in ("fastkv", "fullkv"):
+        args = prefill.parse_args(["--model_path", "llama3-8b", "--method", method, "--max_capacity_prompts", str(CFG["budget"]),
+                                   "--tsp_len", str(CFG["tsp_len"]), "--tsp_idx", str(CFG["tsp_idx"]), "--context_lengths",
+                                   str(CFG["S"]), "--num_warmups", "1", "--num_runs", "3", "--pooling", CFG["pooling"]])
+        args.save_txt = False
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):          # the harness prints its own report; stdout carries ONE JSON line
+            r = prefill.run(args)[0]
+        res[method] = {"ttft_ms": round(r["ttft_s_mean"] * 1e3, 2), "tokens_per_s": round(r["tokens_per_s"], 1),
+                       "max_mem_GiB": round(r["max_mem_GiB"], 2)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    res["speedup_vs_fullkv"] = round(res["fullkv"]["ttft_ms"] / res["fastkv"]["ttft_ms"], 3)
+    res["config"] = "random-init Llama-3-8B geometry, 32768 all-ones token ids, B=1, fp16, SDPA attention, 1 warm-up + 3 runs"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented replay / roofline-shape / CPU legs")
+    ap.add_argument("--no-ttft", action="store_true", help="skip the whole-model TTFT leg (random-init Llama-3-8B, fastkv vs fullkv)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -264,6 +293,8 @@ def main():
                               "roofline_shape": compact_roofline_shape(lib, dev, 10)}
             if world == 1 and not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(work)
+            if world == 1 and not a.no_ttft:
+                out["ttft"] = whole_model_ttft(work)
     if dist is not None and not a.no_extras:
         # The path with a real exchange step: ONE prompt of world*32768 tokens sharded on the sequence axis (rank r holds
         # positions [r*S, (r+1)*S)), pre-TSP layers only (after TSP the 2048 surviving tokens fit one GPU).  Per layer:

@@ -61,9 +61,9 @@ def build_model(args, device):
         cfg = Cfg(**kw)
         cfg._attn_implementation = args.attn_implementation
         with torch.device(device):
-            model = AutoModelForCausalLM.from_config(cfg, torch_dtype=args.dtype, attn_implementation=args.attn_implementation)
+            model = AutoModelForCausalLM.from_config(cfg, dtype=args.dtype, attn_implementation=args.attn_implementation)
     else:
-        model = AutoModelForCausalLM.from_pretrained(args.model_path, torch_dtype=args.dtype, low_cpu_mem_usage=True,
+        model = AutoModelForCausalLM.from_pretrained(args.model_path, dtype=args.dtype, low_cpu_mem_usage=True,
                                                      device_map="auto" if device != "cpu" else None, use_cache=args.use_cache,
                                                      attn_implementation=args.attn_implementation)
     return model.eval()
