@@ -246,3 +246,30 @@ def test_arithmetic_contract_on_gpu(dev):
     g, _ = run(5, hi, lo)
     wf = torch.tensor([Lo.fastkv_oracle_fix_to_f32(int(v)) for v in big.tolist()])
     assert torch.equal(bits(g), bits(wf))
+
+
+@pytest.mark.parametrize("shape", [
+    # (B, H, Hkv, S, D, W, ks, pooling, cap, tsp_len): long prompt, published proportional recipe at 128k (streaming select path)
+    dict(B=1, H=32, Hkv=8, S=131072, D=128, W=8, ks=7, pooling="avgpool", cap=13107, tsp_len=26214),
+    # head_dim 256 (Gemma-style geometry), G=2
+    dict(B=1, H=8, Hkv=4, S=5000, D=256, W=8, ks=7, pooling="maxpool", cap=600, tsp_len=1200),
+    # budget above 16384 winners per head: the ranking reads its key list from L2 instead of LDS
+    dict(B=1, H=4, Hkv=2, S=40000, D=64, W=8, ks=5, pooling="avgpool", cap=20000, tsp_len=0),
+    # wide window (W=32, G=2 -> 64 query rows = two MFMA row blocks), batch 3
+    dict(B=3, H=4, Hkv=2, S=2100, D=128, W=32, ks=13, pooling="maxpool", cap=300, tsp_len=700),
+])
+def test_large_and_unusual_shapes_bit_exact(shape, dev):
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    s = shape
+    q, k, v = make_qkv(77, s["B"], s["H"], s["Hkv"], s["S"], s["D"], s["W"])
+    want = O.update_kv(q, k, v, s["W"], s["ks"], s["pooling"], s["cap"], s["tsp_len"], "score", return_scores=True)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    got = ops.update_kv(qd, kd, vd, s["W"], s["ks"], s["pooling"], s["cap"], s["tsp_len"], "score", return_indices=True,
+                        return_scores=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16))          # scores
+    assert torch.equal(got[3].cpu(), want[2])                                              # per-head indices, reference order
+    assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])       # compacted K / V
+    if s["tsp_len"]:
+        assert torch.equal(got[2].cpu(), want[3])
