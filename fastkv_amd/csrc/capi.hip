@@ -225,7 +225,7 @@ int fastkv_sp_rowsum_f16(const fastkv_problem *p, void *logits, const fastkv_sp_
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
-int fastkv_sp_scores_f16(const fastkv_problem *p, const void *logits, const fastkv_sp_window *w, const float *global_max,
+int fastkv_sp_scores_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, const float *global_max,
                          const int64_t *global_sum, void *c_out, void *t_out, void *workspace, size_t workspace_bytes,
                          void *stream)
 {
@@ -238,8 +238,7 @@ int fastkv_sp_scores_f16(const fastkv_problem *p, const void *logits, const fast
     int hi = w->own_hi < n_glob - w->pos0 ? w->own_hi : n_glob - w->pos0;
     const int n_own = hi - w->own_lo;
     if (n_own > 0 && !c_out) return FASTKV_EINVAL;
-    float *rinv = reinterpret_cast<float *>((char *)workspace + sp_qf_bytes(p));
-    hipError_t e = launch_sp_scores(*p, (const uint16_t *)logits, *w, global_max, global_sum, rinv, (uint16_t *)c_out, n_own,
+    hipError_t e = launch_sp_scores(*p, (uint16_t *)logits, *w, global_max, global_sum, (uint16_t *)c_out, n_own,
                                     (uint16_t *)t_out, n_own, n_own, (hipStream_t)stream);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }

@@ -74,8 +74,8 @@ hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const in
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
 hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,
                               int64_t *sums, hipStream_t st);
-hipError_t launch_sp_scores(const fastkv_problem &p, const uint16_t *logits, const fastkv_sp_window &w, const float *gmax,
-                            const int64_t *sums, float *rinv_scratch, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out,
+hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, const float *gmax,
+                            const int64_t *sums, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out,
                             int64_t t_row_stride, int n_own, hipStream_t st);
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,

@@ -259,8 +259,11 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
 // S <= 32768) and re-reading only what the same thread wrote for longer rows.
 constexpr int RS_THREADS = 1024;
 constexpr int RS_SUPER = RS_THREADS * 8 * 4;
-// mode 0 (one GPU): scale+mask, max, sum -> gmax, rinv.  Sequence sharding splits it around the two all-reduces:
-// mode 1: scale+mask, local max -> gmax[row];  mode 2: sum given the global max in gmax[row] -> sums[row] (2^-40 fixed point).
+// mode 0 (one GPU): scale+mask, max, sum, then the row is rewritten with the fp16 PROBABILITIES p = fp16(e * (1/sum))
+// (utils.py:103) -- one exp per element: e stays in registers between the sum and the normalisation when the row fits
+// one super chunk.  Sequence sharding splits it around the two all-reduces:
+// mode 1: scale+mask, local max -> gmax[row];  mode 2: sum given the global max in gmax[row] -> sums[row] (2^-40 fixed
+// point);  mode 3: probabilities in place from the global max (gmax[row]) and the global sum (sums[row], NaN flag gmax[rows+row]).
 __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restrict__ logits, ColWin cw, int W, int Sp, float sqrtD,
                                                                float rsqrtD, int mode, float *__restrict__ gmax,
                                                                float *__restrict__ rinv, uint64_t *__restrict__ sums,
@@ -275,6 +278,7 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     __shared__ float smax[RS_THREADS / 64];
     __shared__ uint64_t ssum[RS_THREADS / 64];
     __shared__ int snan[RS_THREADS / 64];
+    __shared__ float s_rinv;
     const int row = blockIdx.x, rw = row % W, n = cw.S_glob - W, S = cw.ncols;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint16_t *p = logits + (size_t)row * Sp;
@@ -283,7 +287,7 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     uint4 keep[4];
     float m = -INFINITY;
     int sawnan = 0;
-    for (int sc = 0; sc < (mode == 2 ? 0 : nsc); ++sc) {
+    for (int sc = 0; sc < (mode >= 2 ? 0 : nsc); ++sc) {
         const int base = sc * RS_SUPER + threadIdx.x * 8;
         uint4 raw[4];
 #pragma unroll
@@ -308,7 +312,8 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
                 outw[e >> 1] |= (uint32_t)s16 << ((e & 1) * 16);
             }
             keep[u] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-            if (j0 < S) *reinterpret_cast<uint4 *>(p + j0) = keep[u];
+            // (one GPU, row in one super chunk: the scaled values stay in registers; only the probabilities are stored)
+            if (j0 < S && !(mode == 0 && nsc == 1)) *reinterpret_cast<uint4 *>(p + j0) = keep[u];
         }
     }
     m = wave_max(m);
@@ -322,11 +327,12 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
         if (threadIdx.x == 0) { gmax[row] = m; gmax[gridDim.x + row] = sawnan ? 1.0f : 0.0f; }
         return;
     }
-    if (mode == 2) m = gmax[row];
+    if (mode >= 2) m = gmax[row];
 
     uint64_t ahi = 0, alo = 0;
     int nan = 0;
-    for (int sc = nsc - 1; sc >= 0; --sc) {
+    float ev[32];                                              // e of the last super chunk processed below (sc == 0)
+    for (int sc = (mode == 3 ? -1 : nsc - 1); sc >= 0; --sc) {
         const int base = sc * RS_SUPER + threadIdx.x * 8;
         if (sc != nsc - 1 || mode == 2) {
 #pragma unroll
@@ -341,9 +347,10 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
             const uint32_t wds[4] = {keep[u].x, keep[u].y, keep[u].z, keep[u].w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                uint16_t hb = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                const float ex = det_expf(h2f(hb) - m);
+                ev[u * 8 + e] = ex;
                 if (j0 + e >= cw.own_lo && j0 + e < cw.own_hi) {
-                    uint16_t hb = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                    float ex = det_expf(h2f(hb) - m);
                     if (ex != ex) nan = 1;
                     else { uint32_t hi, lo; exp_to_fix(ex, hi, lo); ahi += hi; alo += lo; }
                 }
@@ -361,20 +368,44 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
         for (int u = 0; u < RS_THREADS / 64; ++u) { s += ssum[u]; bad |= snan[u]; }
         if (mode == 2) {
             sums[row] = bad ? FK_SUM_POISON : s;
-        } else {
+        } else if (mode == 0) {
+            const float ri = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);
             gmax[row] = m;
-            rinv[row] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);
+            rinv[row] = ri;
+            s_rinv = ri;
+        } else {                                               // mode 3: globally reduced sum, NaN flag after the maxima
+            const int64_t gs = (int64_t)sums[row];
+            s_rinv = (gmax[gridDim.x + row] != 0.0f || gs < 0) ? __builtin_nanf("") : 1.0f / fix_to_f32((uint64_t)gs);
         }
     }
-}
-
-// rinv = 1 / sum for globally reduced fixed-point sums (sequence sharding); nanflag (max-reduced over the ranks) marks
-// rows that hold a NaN somewhere in the prompt: their probabilities are NaN, as on one GPU.
-__global__ void stats_finish_kernel(const int64_t *__restrict__ sums, const float *__restrict__ nanflag, int rows,
-                                    float *__restrict__ rinv)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) rinv[i] = (nanflag[i] != 0.0f || sums[i] < 0) ? __builtin_nanf("") : 1.0f / fix_to_f32((uint64_t)sums[i]);
+    if (mode == 2) return;
+    __syncthreads();
+    // ---- pass 3: probabilities in place (every column, halo columns included: score_finalize pools over them)
+    const float ri = s_rinv;
+    for (int sc = 0; sc < nsc; ++sc) {
+        const int base = sc * RS_SUPER + threadIdx.x * 8;
+        const bool have_e = (mode == 0 && sc == 0);            // pass 2 ended on super chunk 0 with its e in registers
+        if (!have_e) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j0 = base + u * (RS_THREADS * 8);
+                keep[u] = *reinterpret_cast<const uint4 *>(p + (j0 < S ? j0 : jlast));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j0 = base + u * (RS_THREADS * 8);
+            const uint32_t wds[4] = {keep[u].x, keep[u].y, keep[u].z, keep[u].w};
+            uint32_t outw[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ex = have_e ? ev[u * 8 + e]
+                                        : det_expf(h2f((uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu)) - m);
+                outw[e >> 1] |= (uint32_t)f2h(ex * ri) << ((e & 1) * 16);
+            }
+            if (j0 < S) *reinterpret_cast<uint4 *>(p + j0) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+        }
+    }
 }
 
 // one LDS histogram update per lane; the lanes that agree with lane 0 are folded into a single atomic
@@ -393,15 +424,14 @@ __device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool ac
 
 // ------------------------------------------------------------------------------------------ score_finalize
 // grid (tilesC, Hkv, B), 256 threads; thread t <-> position tile*TP - pad + t, TP = 256 - 2*pad outputs per block.
-// The G*W logits of a position are fetched in batches of 32 independent loads before any arithmetic.
-constexpr int FIN_MAXR = 1024;
-__global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ gmax,
-                                                             const float *__restrict__ rinv, int H, int Hkv, ColWin cw, int W,
+// Reads the fp16 probabilities row_stats left in the logits buffer: sum over the W window rows -> fp16 (utils.py:104),
+// pool -> fp16 (utils.py:105-108), sum over the G heads of the group -> fp16 (utils.py:112).  The G*W values of a
+// position are fetched in batches of 32 independent loads before any arithmetic.
+__global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ probs, int H, int Hkv, ColWin cw, int W,
                                                              int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
                                                              int64_t c_row_stride, uint32_t *__restrict__ hist12)
 {
     __shared__ float s_tile[2][256];
-    __shared__ float s_gmax[FIN_MAXR], s_rinv[FIN_MAXR];
     __shared__ uint32_t s_hist[HIST12];
     const int g = blockIdx.y, b = blockIdx.z;
     const int G = H / Hkv, n = cw.S_glob - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * W;
@@ -410,24 +440,19 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
     const bool inrange = (j >= 0) && (j < cw.ncols) && (cw.pos0 + j >= 0) && (cw.pos0 + j < n);
     const bool is_out = (t >= pad) && (t < pad + TP) && inrange && (j >= cw.own_lo) && (j < cw.own_hi);
     const size_t row0 = (size_t)(b * H + g * G) * W;
-    const uint16_t *lp = logits + row0 * Sp + (inrange ? j : 0);
-    for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
+    const uint16_t *lp = probs + row0 * Sp + (inrange ? j : 0);
+    if (hist12) for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
     float gsum = 0.0f, a = 0.0f;
     int head = 0, rw = 0;
     for (int rb = 0; rb < R; rb += 32) {
         uint16_t x[32];
 #pragma unroll
         for (int u = 0; u < 32; ++u) x[u] = lp[(size_t)(rb + u < R ? rb + u : R - 1) * Sp];     // unconditional (clamped) loads
-        if (rb == 0) {                                              // row statistics, fetched under the logit loads
-            for (int i = t; i < R; i += 256) { s_gmax[i] = gmax[row0 + i]; s_rinv[i] = rinv[row0 + i]; }
-            __syncthreads();
-        }
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             const int rr = rb + u;                                  // uniform
             if (rr < R) {
-                const float e = det_expf(h2f(x[u]) - s_gmax[rr]);
-                a = a + h2f(f2h(e * s_rinv[rr]));                   // sum over the window rows (utils.py:104)
+                a = a + h2f(x[u]);                                  // sum over the window rows (utils.py:104)
                 if (++rw == W) {                                    // last window row of head `head`
                     rw = 0;
                     float sv = inrange ? h2f(f2h(a)) : (pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY);   // padding, utils.py:106,108
@@ -567,8 +592,8 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         ProfScope ps_(K_FINALIZE, st);
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
-        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv, p.H, p.Hkv, cw, p.window, L.Sp,
-                           p.kernel, p.pooling, c_out, c_row_stride, hist);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, L.Sp, p.kernel,
+                           p.pooling, c_out, c_row_stride, hist);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
@@ -602,22 +627,26 @@ hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const f
     return hipGetLastError();
 }
 
-hipError_t launch_sp_scores(const fastkv_problem &p, const uint16_t *logits, const fastkv_sp_window &w, const float *gmax,
-                            const int64_t *sums, float *rinv_scratch, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out,
+hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, const float *gmax,
+                            const int64_t *sums, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out,
                             int64_t t_row_stride, int n_own, hipStream_t st)
 {
     const ColWin cw = {w.ncols, w.pos0, w.own_lo, w.own_hi, w.S_glob};
-    const int rows = p.B * p.H * p.window;
+    const float sqrtD = (float)sqrt((double)p.D);
     hipError_t e;
-    hipLaunchKernelGGL(stats_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, sums, gmax + rows, rows, rinv_scratch);
+    {
+        ProfScope ps_(K_ROWSTATS, st);   // probabilities in place from the globally reduced max / sum
+        hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, cw, p.window, w.Sp, sqrtD,
+                           1.0f / sqrtD, 3, const_cast<float *>(gmax), (float *)nullptr, (uint64_t *)sums, (uint32_t *)nullptr, 0);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_own <= 0) return hipSuccess;
     {
         ProfScope ps_(K_FINALIZE, st);
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((n_own + TP - 1) / TP, p.Hkv, p.B);
-        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, gmax, rinv_scratch, p.H, p.Hkv, cw, p.window,
-                           w.Sp, p.kernel, p.pooling, c_out, c_row_stride, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, w.Sp, p.kernel,
+                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {

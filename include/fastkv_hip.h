@@ -141,10 +141,11 @@ int fastkv_sp_rowmax_f16(const fastkv_problem *p, void *logits, const fastkv_sp_
 /* local_sum[B*H*window] (int64, 2^-40 fixed point) = sum over owned columns of exp(x - global_max); all-reduce with SUM */
 int fastkv_sp_rowsum_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, const float *global_max,
                          int64_t *local_sum, void *stream);
-/* scores of the owned candidate positions: c_out [B,Hkv,n_own] (utils.py:103-112), t_out [B,n_own] optional (utils.py:127);
+/* rewrites `logits` in place with the fp16 probabilities (utils.py:103), then the scores of the owned candidate
+ * positions: c_out [B,Hkv,n_own] (utils.py:104-112), t_out [B,n_own] optional (utils.py:127);
  * n_own = min(own_hi, S_glob - window - pos0) - own_lo */
 /* global_max: the MAX-reduced buffer of fastkv_sp_rowmax_f16 (maxima + NaN flags) */
-int fastkv_sp_scores_f16(const fastkv_problem *p, const void *logits, const fastkv_sp_window *w, const float *global_max,
+int fastkv_sp_scores_f16(const fastkv_problem *p, void *logits, const fastkv_sp_window *w, const float *global_max,
                          const int64_t *global_sum, void *c_out, void *t_out, void *workspace, size_t workspace_bytes,
                          void *stream);
 
