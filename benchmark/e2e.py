@@ -1,0 +1,94 @@
+"""End-to-end latency harness: counterpart of /root/reference/benchmark/e2e.py (`:53-176`): one prefill followed by
+`genlen-1` greedy decode steps over the (compressed) cache, every forward bracketed by device events (`:72-93`),
+throughput = (genlen-1) / total time.  Same flags as benchmark/prefill.py (+ `--genlen`); models are random-initialised
+geometries (no checkpoints on the GPU box), decode attention runs through PyTorch-ROCm SDPA -- the decode kernel itself
+is outside this repository's hot path, what this harness exercises is that the compressed, per-layer cache produced by
+the prefill path is consumed correctly step after step (positions restart at the compressed length when no
+`position_ids` are passed, exactly as in the reference, `:82-90`)."""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from benchmark import prefill as P
+
+
+def main(model, args):
+    from baselines.monkeypatch import set_model
+    dev = next(model.parameters()).device
+    input_id = torch.ones((args.eval_batch_size, args.context_length), dtype=torch.int64, device=dev)
+    if args.random_tokens:
+        g = torch.Generator(device="cpu").manual_seed(args.seed)
+        input_id = torch.randint(0, model.config.vocab_size, input_id.shape, generator=g).to(dev)
+    attn_mask = torch.ones_like(input_id)
+    set_model(model, args)
+    if args.cluster_factory is not None:
+        for layer in model.model.layers:
+            layer.self_attn.kv_cluster = args.cluster_factory(layer.self_attn.kv_cluster)
+    use_events = dev.type == "cuda"
+
+    def timed(fn):
+        if use_events:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e), out
+        t0 = time.perf_counter()
+        out = fn()
+        return (time.perf_counter() - t0) * 1e3, out
+
+    results = []
+    for it in range(args.num_warmups + args.num_runs):
+        with torch.no_grad():
+            t_prefill, out = timed(lambda: model(input_id, attention_mask=attn_mask))
+            pkv = out.past_key_values
+            tok = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
+            generated = [int(tok[0, 0])]
+            t_decode = 0.0
+            for _ in range(args.genlen - 1):
+                dt, out = timed(lambda: model(input_ids=tok, past_key_values=pkv))
+                t_decode += dt
+                pkv = out.past_key_values
+                tok = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
+                generated.append(int(tok[0, 0]))
+        if it >= args.num_warmups:
+            results.append((t_prefill, t_decode, len(generated)))
+        cache_len = int(pkv.layers[0].keys.shape[-2])
+        del out, pkv
+    pre = np.array([r[0] for r in results])
+    dec = np.array([r[1] for r in results])
+    tot = pre + dec
+    res = {"method": args.method, "context_length": args.context_length, "genlen": args.genlen, "prefill_ms": float(pre.mean()),
+           "decode_ms_per_token": float(dec.mean() / max(1, args.genlen - 1)),
+           "throughput_tok_s": float((args.genlen - 1) / (tot.mean() / 1e3)), "final_cache_len_layer0": cache_len}
+    print(f"[e2e] {args.method} ctx={args.context_length} gen={args.genlen}: prefill {res['prefill_ms']:.1f} ms, "
+          f"decode {res['decode_ms_per_token']:.2f} ms/token, e2e throughput {res['throughput_tok_s']:.1f} tok/s, cache {cache_len}")
+    return res
+
+
+def run(args):
+    P.set_seed(args.seed)
+    from baselines.monkeypatch import replace_llama, replace_mistral
+    replace_llama(args.method)
+    replace_mistral(args.method)
+    model = P.build_model(args, args.device)
+    out = []
+    for context_length in args.context_lengths:
+        args.context_length = context_length
+        print(f"E2E latency benchmark ({args.method}) | Context length={context_length}")
+        out.append(main(model, args))
+    return out
+
+
+if __name__ == "__main__":
+    run(P.parse_args())

@@ -158,3 +158,12 @@ def test_decoder_layer_matches_reference_golden():
         assert (me.new_position_ids is not None) == bool(g["has_new_pos_" + tag]), tag
         if me.new_position_ids is not None:
             assert torch.equal(me.new_position_ids, torch.from_numpy(g["new_pos_" + tag]))
+
+
+def test_e2e_driver_cpu():
+    """benchmark/e2e.py: prefill + greedy decode over the compressed cache (counterpart of the reference driver)."""
+    from benchmark import e2e
+    a = _args(method="fastkv", context_lengths=[200], max_capacity_prompts=48, tsp_len=80, tsp_idx=1, num_warmups=0, genlen=5)
+    res = e2e.run(a)[0]
+    assert res["final_cache_len_layer0"] == 48 + 4                   # budget + the 4 decoded tokens
+    assert res["throughput_tok_s"] > 0
