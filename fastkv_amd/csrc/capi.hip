@@ -134,16 +134,22 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     uint16_t *keys = by_score ? reinterpret_cast<uint16_t *>(ws + L.off_keys) : nullptr;
     const int64_t kal = ((int64_t)kk + 7) & ~(int64_t)7;
 
-    hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st);
+    // capacity == S (post-TSP layers in constant mode): every candidate is selected; score_finalize writes the identity
+    // list and the keys itself and the selection kernel is skipped
+    const bool select_all = (kk == L.n);
+    hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
+                                select_all ? keys : nullptr, kal);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
     if (scores_out) {
         e = hipMemcpy2DAsync(scores_out, (size_t)L.n * 2, c, (size_t)L.n_pad * 2, (size_t)L.n * 2, (size_t)p->B * p->Hkv,
                              hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
-    e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
-                      reinterpret_cast<const uint32_t *>(ws + L.off_hist), st);
-    if (e != hipSuccess) return FASTKV_ELAUNCH;
+    if (!select_all) {
+        e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
+                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), st);
+        if (e != hipSuccess) return FASTKV_ELAUNCH;
+    }
     if (p->tsp_len) {
         e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
                           reinterpret_cast<const uint32_t *>(ws + L.off_thist), st);

@@ -69,7 +69,8 @@ static inline Layout make_layout(const fastkv_problem &p)
 // launchers (defined in score.hip / select.hip / compact.hip); all return hipError_t of the launch
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
-                        char *ws, hipStream_t st);
+                        char *ws, hipStream_t st, int64_t *all_idx = nullptr, uint16_t *all_keys = nullptr,
+                        int64_t all_key_stride = 0);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
 hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,

@@ -257,13 +257,14 @@ __global__ void __launch_bounds__(256) score_logits_kernel(const uint16_t *__res
 // is used.  Pass 1 rewrites the row in place with the scaled (+masked) logits and finds the row maximum; pass 2
 // accumulates sum exp(x - max) in fixed point, re-using the registers of the last super chunk (the whole row when
 // S <= 32768) and re-reading only what the same thread wrote for longer rows.
-constexpr int RS_THREADS = 1024;
-constexpr int RS_SUPER = RS_THREADS * 8 * 4;
+// Workgroup size by row length: 1024 threads for long rows, 256 for rows up to 8192 positions (post-TSP layers), where
+// a 1024-thread group would be three quarters idle and pay 16-wave barriers.
 // mode 0 (one GPU): scale+mask, max, sum, then the row is rewritten with the fp16 PROBABILITIES p = fp16(e * (1/sum))
 // (utils.py:103) -- one exp per element: e stays in registers between the sum and the normalisation when the row fits
 // one super chunk.  Sequence sharding splits it around the two all-reduces:
 // mode 1: scale+mask, local max -> gmax[row];  mode 2: sum given the global max in gmax[row] -> sums[row] (2^-40 fixed
 // point);  mode 3: probabilities in place from the global max (gmax[row]) and the global sum (sums[row], NaN flag gmax[rows+row]).
+template <int RS_THREADS>
 __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restrict__ logits, ColWin cw, int W, int Sp, float sqrtD,
                                                                float rsqrtD, int mode, float *__restrict__ gmax,
                                                                float *__restrict__ rinv, uint64_t *__restrict__ sums,
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
         const int lo = blockIdx.x * per, hi = min(lo + per, hist_words);
         for (int i = lo + threadIdx.x; i < hi; i += RS_THREADS) hist_zero[i] = 0;
     }
+    constexpr int RS_SUPER = RS_THREADS * 8 * 4;
     __shared__ float smax[RS_THREADS / 64];
     __shared__ uint64_t ssum[RS_THREADS / 64];
     __shared__ int snan[RS_THREADS / 64];
@@ -429,7 +431,9 @@ __device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool ac
 // position are fetched in batches of 32 independent loads before any arithmetic.
 __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ probs, int H, int Hkv, ColWin cw, int W,
                                                              int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
-                                                             int64_t c_row_stride, uint32_t *__restrict__ hist12)
+                                                             int64_t c_row_stride, uint32_t *__restrict__ hist12,
+                                                             int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
+                                                             int64_t all_key_stride)
 {
     __shared__ float s_tile[2][256];
     __shared__ uint32_t s_hist[HIST12];
@@ -481,6 +485,17 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
     }
     const uint16_t c16 = f2h(gsum);
     if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + (j - cw.own_lo)] = c16;
+    if (all_idx) {
+        // k == n (post-TSP layers in constant mode): every candidate is selected, so the "selection" is the
+        // identity list in ascending position plus the keys the ranking needs -- no selection kernel is launched
+        const int nloc = n;                                           // one GPU only (cw.pos0 == 0, own == all)
+        if (is_out) {
+            all_idx[(size_t)(b * Hkv + g) * nloc + j] = (int64_t)j;
+            if (all_keys) all_keys[(size_t)(b * Hkv + g) * all_key_stride + j] = (uint16_t)mono16(c16);
+        }
+        if (all_keys && blockIdx.x == 0 && t < (int)(all_key_stride - nloc)) all_keys[(size_t)(b * Hkv + g) * all_key_stride + nloc + t] = 0;
+        return;
+    }
     // high-12-bit key histogram of this row for the selection kernel: block-local first, then one global atomic per
     // non-empty bin (integer atomics: the counts do not depend on arrival order)
     if (!hist12) return;
@@ -569,7 +584,7 @@ static hipError_t launch_logits(const fastkv_problem &p, const Layout &L, const 
 
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
-                        char *ws, hipStream_t st)
+                        char *ws, hipStream_t st, int64_t *all_idx, uint16_t *all_keys, int64_t all_key_stride)
 {
     float *qf = reinterpret_cast<float *>(ws + L.off_qf);
     uint16_t *logits = reinterpret_cast<uint16_t *>(ws + L.off_logits);
@@ -584,8 +599,12 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     if ((e = launch_logits(p, L, q, qs, p.S - p.window, k, ks, qf, logits, L.Sp, 0, st)) != hipSuccess) return e;
     {
         ProfScope ps_(K_ROWSTATS, st);
-        hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, cw, p.window, L.Sp, sqrtD,
-                           rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, p.B * (p.Hkv + 1) * HIST12);
+        if (p.S <= 8192)
+            hipLaunchKernelGGL(row_stats_kernel<256>, dim3(p.B * p.H * p.window), dim3(256), 0, st, logits, cw, p.window, L.Sp, sqrtD,
+                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, p.B * (p.Hkv + 1) * HIST12);
+        else
+            hipLaunchKernelGGL(row_stats_kernel<1024>, dim3(p.B * p.H * p.window), dim3(1024), 0, st, logits, cw, p.window, L.Sp, sqrtD,
+                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, p.B * (p.Hkv + 1) * HIST12);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     {
@@ -593,7 +612,7 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
         hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, L.Sp, p.kernel,
-                           p.pooling, c_out, c_row_stride, hist);
+                           p.pooling, c_out, c_row_stride, hist, all_idx, all_keys, all_key_stride);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
@@ -622,7 +641,7 @@ hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const f
     const float sqrtD = (float)sqrt((double)p.D);
     const ColWin cw = {w.ncols, w.pos0, w.own_lo, w.own_hi, w.S_glob};
     ProfScope ps_(K_ROWSTATS, st);
-    hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, cw, p.window, w.Sp, sqrtD,
+    hipLaunchKernelGGL(row_stats_kernel<1024>, dim3(p.B * p.H * p.window), dim3(1024), 0, st, logits, cw, p.window, w.Sp, sqrtD,
                        1.0f / sqrtD, mode, gmax, (float *)nullptr, (uint64_t *)sums, (uint32_t *)nullptr, 0);
     return hipGetLastError();
 }
@@ -636,7 +655,7 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
     hipError_t e;
     {
         ProfScope ps_(K_ROWSTATS, st);   // probabilities in place from the globally reduced max / sum
-        hipLaunchKernelGGL(row_stats_kernel, dim3(p.B * p.H * p.window), dim3(RS_THREADS), 0, st, logits, cw, p.window, w.Sp, sqrtD,
+        hipLaunchKernelGGL(row_stats_kernel<1024>, dim3(p.B * p.H * p.window), dim3(1024), 0, st, logits, cw, p.window, w.Sp, sqrtD,
                            1.0f / sqrtD, 3, const_cast<float *>(gmax), (float *)nullptr, (uint64_t *)sums, (uint32_t *)nullptr, 0);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -646,7 +665,7 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((n_own + TP - 1) / TP, p.Hkv, p.B);
         hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, w.Sp, p.kernel,
-                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr);
+                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, (int64_t)0);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
