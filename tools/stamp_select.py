@@ -1,4 +1,4 @@
-import os, sys, ctypes
+import os, sys
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT)
 import torch
@@ -11,15 +11,12 @@ v=torch.randn(1,S,Hkv,D,device=dev,dtype=torch.float16).transpose(1,2)
 for _ in range(3): ops.update_kv(q,k,v,W,7,'maxpool',2048,0,'score')
 torch.cuda.synchronize()
 ws=list(ops._ws_cache.values())[0]
-# find stamps: g_cnt region is inside workspace; scan for plausible: easier - recompute offsets
-from fastkv_amd._lib import Problem, load
-# layout mirror
 def al(x,a=256): return (x+a-1)//a*a
-B=1;R_alloc=32;Sp=S;n=S-W;n_pad=(n+7)//8*8;kk=2040
+B=1;Sp=S;n=S-W;n_pad=(n+7)//8*8
 o=0
-o+=al(B*Hkv*R_alloc*D*4); o+=al(B*H*W*Sp*2); o+=al(B*H*W*4)*2; o+=al(B*Hkv*n_pad*2); o+=al(B*n_pad*2); o+=al(B*Hkv*4096*4); o+=al(B*4096*4); o+=al(B*Hkv*kk*8)
-off_sel=o; rows=8; kal=2040
-g_cnt=off_sel+al(rows*2*kal*4)+al(rows*2*kal*2)
-st=ws[off_sel:off_sel+8*16*8].view(torch.int64).view(8,16).cpu()
-for r in range(8):
-    t=st[r,:8]; print("row",r," ".join(f"{(int(t[i+1])-int(t[i]))*10/1000:.1f}us" for i in range(7)))
+o+=al(B*Hkv*32*D*4); o+=al(B*H*W*Sp*2); o+=al(B*H*W*4)*2; o+=al(B*Hkv*n_pad*2); o+=al(B*n_pad*2)
+off_hist=o
+st=ws[off_hist+8*4096*4:off_hist+8*4096*4+8*16*8].view(torch.int64).view(8,16).cpu()
+names=["load+histcopy","find12","pass2","find4","pass3a(count+scan)","pass3b(emit)"]
+for r in range(2):
+    t=st[r,:7]; print("row",r," ".join(f"{names[i]}={(int(t[i+1])-int(t[i]))*10/1000:.1f}us" for i in range(6)))
