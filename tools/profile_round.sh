@@ -25,4 +25,4 @@ for name,counter in (("fetch","FETCH_SIZE"),("write","WRITE_SIZE")):
 json.dump(out, open(f'gpurun_out/{tag}_pmc_summary.json','w'), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
-cat gpurun_out/${tag}_bench.json | cut -c1-400
+python tools/profile_summarise.py ${tag} > /dev/null; cat gpurun_out/${tag}_bench.json | cut -c1-400

@@ -1,0 +1,61 @@
+"""Summarise one tools/profile_round.sh run (gpurun_out/<tag>_*) into the files kept under profiles/.
+
+    python tools/profile_summarise.py r01c          # reads gpurun_out/, writes profiles/
+
+Outputs: <tag>_bench.json, <tag>_bench_under_rocprofv3.json, <tag>_rocprofv3_kernel_stats.csv (rocprofv3's own --stats
+table, all kernels of the run), <tag>_fk_kernels_by_grid.csv (our kernels from the kernel trace, split by grid size so
+that the S=32768 and the post-TSP S=2048 launches are not averaged together), <tag>_pmc_fetch_write_summary.json and
+traffic.json (per-launch HBM bytes read by bench.py).
+"""
+import collections, csv, glob, json, os, shutil, statistics as st, sys
+
+tag = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(G, pattern))
+    return f[0] if f else None
+
+
+shutil.copy(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_bench.json"))
+shutil.copy(os.path.join(G, f"{tag}_trace_bench.json"), os.path.join(P, f"{tag}_bench_under_rocprofv3.json"))
+shutil.copy(one(f"{tag}_trace/*/*_kernel_stats.csv"), os.path.join(P, f"{tag}_rocprofv3_kernel_stats.csv"))
+shutil.copy(os.path.join(G, f"{tag}_pmc_summary.json"), os.path.join(P, f"{tag}_pmc_fetch_write_summary.json"))
+
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(one(f"{tag}_trace/*/*_kernel_trace.csv"))):
+    if "fk::" in r["Kernel_Name"]:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[(name, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(os.path.join(P, f"{tag}_fk_kernels_by_grid.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "GridSizeX", "WorkgroupSizeX", "Calls", "AverageNs", "MedianNs", "MinNs", "MaxNs"])
+    for (name, grid, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([name, grid, wg, len(v), round(st.mean(v), 1), st.median(v), min(v), max(v)])
+
+pmc = json.load(open(os.path.join(G, f"{tag}_pmc_summary.json")))
+
+
+def kib(counter, prefix):
+    hits = {k: v for k, v in pmc.get(counter, {}).items() if k.startswith(prefix)}
+    k = max(hits, key=lambda k: hits[k]["median"])          # the S=32768 launches are the largest of a kernel
+    return hits[k]["median"]
+
+
+lf, lw = kib("FETCH_SIZE", "fk::score_logits"), kib("WRITE_SIZE", "fk::score_logits")
+cf, cw = kib("FETCH_SIZE", "fk::compact_kv"), kib("WRITE_SIZE", "fk::compact_kv")
+json.dump({
+    "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
+              "--no-extras`, medians over launches; counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide 16-B/lane "
+              "reads, guides/MI355X_MICROARCH.md HBM section; the compact kernel calibrates it: 2*FETCH = its 8.39 MB of row reads)",
+    "score_logits_hbm_bytes_per_launch": int((2 * lf + lw) * 1024),
+    "score_logits_fetch_kib_raw": lf, "score_logits_write_kib": lw,
+    "compact_kv_hbm_bytes_per_launch": int((2 * cf + cw) * 1024),
+    "compact_kv_fetch_kib_raw": cf, "compact_kv_write_kib": cw,
+    "note": "score_logits: 2*FETCH = K once + Q window (algorithmic 67.17 MB); the remaining 16.8 MB is the fp16 logits write "
+            "consumed by row_stats/score_finalize",
+}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(P, f"{tag}_fk_kernels_by_grid.csv")).read())
+print(open(os.path.join(P, "traffic.json")).read())
