@@ -79,13 +79,13 @@ int fastkv_select_f16(const void *scores, int64_t rows, int64_t row_stride, int6
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     if (order == FASTKV_ORDER_INDEX) {
-        e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, append, idx_out, k + append, nullptr, 0, nullptr, st);
+        e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, append, idx_out, k + append, nullptr, 0, nullptr, nullptr, nullptr, st);
     } else {
         if (!workspace || workspace_bytes < select_ws_bytes(rows, n, k)) return FASTKV_EWORKSPACE;
         const int64_t kal = (k + 7) & ~(int64_t)7;
         int64_t *asc = reinterpret_cast<int64_t *>(workspace);
         uint16_t *keys = reinterpret_cast<uint16_t *>((char *)workspace + align_up((size_t)rows * kal * sizeof(int64_t), 256));
-        e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, 0, asc, kal, keys, kal, nullptr, st);
+        e = launch_select((const uint16_t *)scores, rows, row_stride, n, k, 0, asc, kal, keys, kal, nullptr, nullptr, nullptr, st);
         if (e == hipSuccess) e = launch_rank_scatter(asc, kal, keys, kal, rows, k, idx_out, k, st);
     }
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
@@ -137,6 +137,8 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     // capacity == S (post-TSP layers in constant mode): every candidate is selected; score_finalize writes the identity
     // list and the keys itself and the selection kernel is skipped
     const bool select_all = (kk == L.n);
+    uint32_t *arrive = reinterpret_cast<uint32_t *>(ws + L.off_arrive), *seltab = reinterpret_cast<uint32_t *>(ws + L.off_seltab);
+    const size_t nchunks = ((size_t)L.n + 2047) / 2048;
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
                                 select_all ? keys : nullptr, kal);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
@@ -147,12 +149,13 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     }
     if (!select_all) {
         e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
-                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), st);
+                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
     if (p->tsp_len) {
         e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
-                          reinterpret_cast<const uint32_t *>(ws + L.off_thist), st);
+                          reinterpret_cast<const uint32_t *>(ws + L.off_thist), arrive + (size_t)p->B * p->Hkv,
+                          seltab + (size_t)p->B * p->Hkv * nchunks * 32, st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
     e = launch_compact(*p, k, k_strides, v, v_strides, idx_asc, keys, by_score ? kv_idx_out : nullptr, k_out, v_out, st);

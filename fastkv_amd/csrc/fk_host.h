@@ -20,7 +20,8 @@ struct Layout {
     int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
     int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
     int ntA;                         // tiles of score_logits
-    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_idx, off_keys, total;
+    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_idx, off_keys, total;
+    int zero_words;                  // u32 words from off_hist that row_stats zeroes: histograms + arrival counters
 };
 
 static inline size_t select_ws_bytes(int64_t rows, int64_t n, int64_t k)
@@ -55,7 +56,10 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_c = o;      o += align_up((size_t)p.B * p.Hkv * L.n_pad * 2, 256);
     L.off_t = o;      o += align_up((size_t)p.B * L.n_pad * 2, 256);
     L.off_hist = o;   o += align_up((size_t)p.B * p.Hkv * HIST12 * 4, 256);     // 12-bit key histograms of the score rows
-    L.off_thist = o;  o += align_up((size_t)p.B * HIST12 * 4, 256);             // ... and of the TSP rows (adjacent: zeroed together)
+    L.off_thist = o;  o += (size_t)p.B * HIST12 * 4;                            // ... and of the TSP rows (adjacent: zeroed together)
+    L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
+    L.zero_words = (int)((o - L.off_hist) / 4);
+    L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {
@@ -80,7 +84,7 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
                             int64_t t_row_stride, int n_own, hipStream_t st);
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
-                         const uint32_t *hist12, hipStream_t st);
+                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st);
 hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, const uint16_t *keys, int64_t key_row_stride,
                                int64_t rows, int64_t k, int64_t *out, int64_t out_row_stride, hipStream_t st);
 // idx: ascending-position winners; keys != nullptr => rows are placed in ORDER_SCORE (rank by comparison counting) and

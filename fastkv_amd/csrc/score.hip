@@ -601,10 +601,10 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         ProfScope ps_(K_ROWSTATS, st);
         if (p.S <= 8192)
             hipLaunchKernelGGL(row_stats_kernel<256>, dim3(p.B * p.H * p.window), dim3(256), 0, st, logits, cw, p.window, L.Sp, sqrtD,
-                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, p.B * (p.Hkv + 1) * HIST12);
+                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, L.zero_words);
         else
             hipLaunchKernelGGL(row_stats_kernel<1024>, dim3(p.B * p.H * p.window), dim3(1024), 0, st, logits, cw, p.window, L.Sp, sqrtD,
-                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, p.B * (p.Hkv + 1) * HIST12);
+                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, L.zero_words);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     {

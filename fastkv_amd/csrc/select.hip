@@ -267,6 +267,175 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint16_t
     if (kout) for (int i = k + tid; i < ((k + 7) & ~7); i += SEL_THREADS) kout[i] = 0;
 }
 
+// ------------------------------------------------------------------------------------------ split select
+// The fused operator's selection: a row is cut into chunks of 2048 positions, one 256-thread workgroup each
+// (grid = chunks x rows: 128 workgroups for the 8 rows of the 32k configuration instead of 8).  The 12-bit histogram
+// of the row is complete when the kernel starts (score_finalize / tsp_rowsum built it), so every workgroup derives the
+// threshold prefix by itself.  What a workgroup cannot know alone -- the low nibble of the k-th value and how many
+// winners precede its chunk -- goes through a small table in the workspace:
+//   phase 1  count the chunk's keys above the threshold prefix and the nibble histogram of those carrying it; publish the
+//            17 counters (one 128-B line per chunk), release, bump the row's arrival counter
+//   phase 2  wait until all chunks of the row have arrived (all workgroups of the launch are co-resident: the host
+//            takes this path only for <= SPL_MAX_WGS workgroups), sum the tables -> k-th value, quota of ties, and the
+//            number of winners before this chunk; ordered compaction of the chunk straight to the output lists.
+// The arrival counters are zeroed by row_stats together with the histograms.
+constexpr int SPL_THREADS = 256, SPL_CHUNK = SPL_THREADS * 8, SPL_LINE = 32, SPL_MAX_WGS = 1024;
+
+struct SplShared {
+    uint32_t wtot[4];
+    uint32_t bcast[4];
+    uint32_t h4[16];
+    uint32_t cg12;
+    uint32_t tot[17], pre[17];
+};
+
+__global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_t *__restrict__ scores, int64_t row_stride, int n, int k,
+                                                                   int append, int64_t *__restrict__ idx_out, int64_t idx_row_stride,
+                                                                   uint16_t *__restrict__ key_out, int64_t key_row_stride,
+                                                                   const uint32_t *__restrict__ hist12, uint32_t *__restrict__ arrive,
+                                                                   uint32_t *__restrict__ table)
+{
+    __shared__ SplShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int chunk = blockIdx.x, nchunks = gridDim.x, rowi = blockIdx.y;
+    const uint16_t *row = scores + (size_t)rowi * row_stride;
+    int64_t *out = idx_out + (size_t)rowi * idx_row_stride;
+    uint16_t *kout = key_out ? key_out + (size_t)rowi * key_row_stride : nullptr;
+    uint32_t *tab = table + ((size_t)rowi * nchunks) * SPL_LINE;
+
+    // this thread's 8 keys (rows of the fused operator are 16-B aligned with a padded stride: the vector that straddles n
+    // is readable; a vector wholly past n re-reads the row's last one and is ignored)
+    const int j0 = chunk * SPL_CHUNK + tid * 8;
+    const int jl = ((n - 1) >> 3) << 3;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(row + (j0 < n ? j0 : jl));
+    // 12-bit histogram: thread t owns bins 4095-16t .. 4080-16t (descending)
+    uint32_t c[16];
+    {
+        const uint4 *gh = reinterpret_cast<const uint4 *>(hist12 + (size_t)rowi * HIST12 + (HIST12 - 16 - 16 * tid));
+        const uint4 a0 = gh[0], a1 = gh[1], a2 = gh[2], a3 = gh[3];
+        c[15] = a0.x; c[14] = a0.y; c[13] = a0.z; c[12] = a0.w; c[11] = a1.x; c[10] = a1.y; c[9] = a1.z; c[8] = a1.w;
+        c[7] = a2.x; c[6] = a2.y; c[5] = a2.z; c[4] = a2.w; c[3] = a3.x; c[2] = a3.y; c[1] = a3.z; c[0] = a3.w;
+    }
+    if (tid < 16) sh.h4[tid] = 0;
+    if (tid == 16) sh.cg12 = 0;
+    if (tid >= 32 && tid < 32 + 17) { sh.tot[tid - 32] = 0; sh.pre[tid - 32] = 0; }
+    if (chunk == 0) {
+        for (int a = tid; a < append; a += SPL_THREADS) out[k + a] = (int64_t)n + a;          // the window positions (utils.py:128-129)
+        if (kout) for (int i = k + tid; i < ((k + 7) & ~7); i += SPL_THREADS) kout[i] = 0;   // rank_partial reads whole vectors
+    }
+    {
+        uint32_t loc = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) loc += c[u];
+        uint32_t inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up((int)inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) sh.wtot[w] = inc;
+        __syncthreads();
+        uint32_t above = inc - loc;
+        for (int u = 0; u < w; ++u) above += sh.wtot[u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (above < (uint32_t)k && (uint32_t)k <= above + c[u]) { sh.bcast[0] = HIST12 - 1 - 16 * tid - u; sh.bcast[1] = above; }
+            above += c[u];
+        }
+        __syncthreads();
+    }
+    const uint32_t thr12 = sh.bcast[0], above12 = sh.bcast[1];
+    // ---------------- phase 1
+    uint32_t keys[8];
+    {
+        uint32_t cg = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            keys[e] = key_of(raw, e);
+            const bool ok = j0 + e < n;
+            cg += (ok && (keys[e] >> 4) > thr12);
+            if (ok && (keys[e] >> 4) == thr12) atomicAdd(&sh.h4[keys[e] & 15u], 1u);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cg += __shfl_xor((int)cg, o, 64);
+        if (lane == 0 && cg) atomicAdd(&sh.cg12, cg);
+    }
+    __syncthreads();
+    if (w == 0) {
+        if (lane < 17)
+            __hip_atomic_store(&tab[chunk * SPL_LINE + lane], lane < 16 ? sh.h4[lane] : sh.cg12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (lane == 0) {
+            __hip_atomic_fetch_add(&arrive[rowi], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&arrive[rowi], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)nchunks) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) __builtin_trap();          // seconds: the launch is broken, fail loudly instead of hanging
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 2: totals over the row and over the chunks before this one
+    for (int i = tid; i < nchunks * 17; i += SPL_THREADS) {
+        const int cc = i / 17, f = i - cc * 17;
+        const uint32_t v = __hip_atomic_load(&tab[cc * SPL_LINE + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) {
+            atomicAdd(&sh.tot[f], v);
+            if (cc < chunk) atomicAdd(&sh.pre[f], v);
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        const uint32_t cnt = lane < 16 ? sh.tot[15 - lane] : 0;          // lane l owns nibble 15-l (descending)
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t v = __shfl_up((int)inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        const uint32_t above = inc - cnt, kk = (uint32_t)k - above12;
+        if (lane < 16 && above < kk && kk <= above + cnt) { sh.bcast[2] = 15 - lane; sh.bcast[3] = above; }
+    }
+    __syncthreads();
+    const uint32_t thr4 = sh.bcast[2];
+    const uint32_t thr = (thr12 << 4) | thr4;
+    const uint32_t quota = (uint32_t)k - (above12 + sh.bcast[3]);       // elements equal to thr that are kept
+    uint32_t gt_base = sh.pre[16], eq_base = sh.pre[thr4];
+    for (uint32_t nb = thr4 + 1; nb < 16; ++nb) gt_base += sh.pre[nb];
+    // ordered compaction of the chunk
+    uint32_t cg = 0, ce = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool ok = j0 + e < n;
+        cg += (ok && keys[e] > thr);
+        ce += (ok && keys[e] == thr);
+    }
+    const uint32_t pk = cg | (ce << 16);
+    uint32_t inc = pk;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();                                                     // wtot is reused
+    if (lane == 63) sh.wtot[w] = inc;
+    __syncthreads();
+    uint32_t ex = inc - pk;
+    for (int u = 0; u < w; ++u) ex += sh.wtot[u];
+    uint32_t gt_before = gt_base + (ex & 0xffffu), eq_before = eq_base + (ex >> 16);
+    if (pk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (j0 + e < n) {
+                int pos = -1;
+                if (keys[e] > thr) { pos = (int)(gt_before + min(eq_before, quota)); gt_before++; }
+                else if (keys[e] == thr) { if (eq_before < quota) pos = (int)(gt_before + eq_before); eq_before++; }
+                if (pos >= 0) { out[pos] = (int64_t)(j0 + e); if (kout) kout[pos] = (uint16_t)keys[e]; }
+            }
+        }
+    }
+}
+
 // Stand-alone ORDER_SCORE: out[r, rank(p)] = idx_asc[r, p].  grid (ceil(k/16), rows), 256 threads = 16 winners x 16 lanes.
 __global__ void __launch_bounds__(256) rank_scatter_kernel(const int64_t *__restrict__ idx_asc, int64_t asc_row_stride,
                                                            const uint16_t *__restrict__ keys, int64_t key_row_stride, int k,
@@ -284,9 +453,17 @@ __global__ void __launch_bounds__(256) rank_scatter_kernel(const int64_t *__rest
 
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
-                         const uint32_t *hist12, hipStream_t st)
+                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st)
 {
     if (rows == 0) return hipSuccess;
+    const int64_t nchunks = (n + SPL_CHUNK - 1) / SPL_CHUNK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && (row_stride % 8 == 0) && (row_stride >= ((n + 7) & ~(int64_t)7));
+    if (hist12 && arrive && table && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec) {
+        ProfScope ps_(K_SELECT, st);
+        hipLaunchKernelGGL(select_split_kernel, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
+                           (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12, arrive, table);
+        return hipGetLastError();
+    }
     const int64_t kal = (k + 7) & ~(int64_t)7;
     const int list_in_lds = kal <= 16384 ? 1 : 0;                      // 96 KiB of dynamic LDS at most
     const size_t dyn = list_in_lds ? (size_t)kal * 6 : 0;
