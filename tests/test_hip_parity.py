@@ -119,6 +119,19 @@ def test_degenerate_rows(dev):
     ko, vo, tsp, kvi = ops.update_kv(qd, kd, vd, 8, 7, "avgpool", 256, 512, "score", return_indices=True)
     want = O.update_kv(q, k, v, 8, 7, "avgpool", 256, 512, "score")
     assert torch.equal(kvi.cpu(), want[2]) and torch.equal(tsp.cpu(), want[3])
+    # the same on rows long enough for the chunked selection (several workgroups per row): ties in every chunk, the
+    # quota of equal values runs out in the middle of one; K rows periodic in the position -> a handful of distinct scores
+    for period, cap, tsp_len in ((1, 2048, 1024), (5, 3000, 4100), (64, 1500, 0)):
+        q, k, v = make_qkv(6, 1, 8, 2, 10000, 128, 8)
+        k = k.clone(); k[:, :, :9992] = k[:, :, :period].repeat(1, 1, 9992 // period + 1, 1)[:, :, :9992]
+        qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+        for order in ("index", "score"):
+            ko, vo, tsp, kvi = ops.update_kv(qd, kd, vd, 8, 7, "maxpool", cap, tsp_len, order, return_indices=True)
+            want = O.update_kv(q, k, v, 8, 7, "maxpool", cap, tsp_len, order)
+            assert torch.equal(kvi.cpu(), want[2]), (period, order)
+            assert torch.equal(ko.cpu(), want[0]) and torch.equal(vo.cpu(), want[1])
+            if tsp_len:
+                assert torch.equal(tsp.cpu(), want[3])
 
 
 def test_gather_rows_tsp_propagation(dev):
