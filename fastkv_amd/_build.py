@@ -38,7 +38,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), *HIPCC_FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    extra = os.environ.get("FASTKV_CXXFLAGS", "").split()          # measurement builds only (e.g. -DFK_STAMP)
+    cmd = [hipcc(), *HIPCC_FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

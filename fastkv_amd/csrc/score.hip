@@ -28,6 +28,16 @@ namespace fk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Measurement build (-DFK_STAMP): per-wave wall-clock stamps (100 MHz) of the matrix-pipe kernel's stages.
+#ifdef FK_STAMP
+__device__ unsigned long long g_stamps[4096 * 8];
+#define FK_STAMP_AT(slot) do { if (lane == 0) g_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 8 + (slot)] = wall_clock64(); } while (0)
+#define FK_CYC_AT(slot) do { if (lane == 0) g_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 8 + (slot)] = clock64(); } while (0)
+#else
+#define FK_STAMP_AT(slot) do { } while (0)
+#define FK_CYC_AT(slot) do { } while (0)
+#endif
+
 // A rank's view of a logits row.  Column x holds global prompt position pos0 + x.  One GPU: ncols = S, pos0 = 0,
 // own = [0, S).  Sequence sharding (fastkv_amd/dist.py): the row holds the rank's positions plus `pad` halo columns on
 // either side (needed by the pooling window); statistics and outputs cover the owned columns only.
@@ -88,18 +98,30 @@ __device__ __forceinline__ void stage_k(const uint16_t *__restrict__ kb, int64_t
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct KStage { u32x4 r0, r1, r2, r3, r4, r5, r6, r7; };
 
-__device__ __forceinline__ u32x4 k_load1(const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane, int i)
-{
-    int jj = key0 + i * 8 + (lane >> 3);
-    jj = jj < S ? jj : S - 1;
-    return *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
-}
+// One phase of a 64-key tile: 8 x 16 B per lane (lane l: key row i*8 + (l>>3), bytes (l&7)*16 of the 128-B phase slice).
+// Full tiles are buffer loads: ONE per-lane 32-bit offset, the tile base in a wave-uniform descriptor and the row block
+// in the scalar offset; only the ragged last tile clamps the row per lane.  Per-load 64-bit vector addresses for two stages cost 64 VGPRs and spilled.
 __device__ __forceinline__ void k_fetch(KStage &st, const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane)
 {
-    st.r0 = k_load1(kb, ks_s, key0, S, ph, lane, 0); st.r1 = k_load1(kb, ks_s, key0, S, ph, lane, 1);
-    st.r2 = k_load1(kb, ks_s, key0, S, ph, lane, 2); st.r3 = k_load1(kb, ks_s, key0, S, ph, lane, 3);
-    st.r4 = k_load1(kb, ks_s, key0, S, ph, lane, 4); st.r5 = k_load1(kb, ks_s, key0, S, ph, lane, 5);
-    st.r6 = k_load1(kb, ks_s, key0, S, ph, lane, 6); st.r7 = k_load1(kb, ks_s, key0, S, ph, lane, 7);
+    if (key0 + 64 <= S) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(kb + (int64_t)key0 * ks_s + ph * DH), 0, 0x7fffffff, 0x00020000);        // wave-uniform
+        const int loff = ((lane >> 3) * (int)ks_s + (lane & 7) * 8) * 2;
+        const int step = (int)ks_s * 16;                                                                     // 8 rows, bytes
+#define FK_KLD(i) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (i) * step, 0))
+        st.r0 = FK_KLD(0); st.r1 = FK_KLD(1); st.r2 = FK_KLD(2); st.r3 = FK_KLD(3);
+        st.r4 = FK_KLD(4); st.r5 = FK_KLD(5); st.r6 = FK_KLD(6); st.r7 = FK_KLD(7);
+#undef FK_KLD
+    } else {
+        u32x4 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int jj = key0 + i * 8 + (lane >> 3);
+            jj = jj < S ? jj : S - 1;
+            t[i] = *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
+        }
+        st.r0 = t[0]; st.r1 = t[1]; st.r2 = t[2]; st.r3 = t[3]; st.r4 = t[4]; st.r5 = t[5]; st.r6 = t[6]; st.r7 = t[7];
+    }
 }
 __device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned char *my)
 {
@@ -112,8 +134,61 @@ __device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned ch
     __builtin_amdgcn_wave_barrier();
 }
 
+// One 64-dim phase of a 64-key tile: 64 k-steps x 2 column blocks = 128 MFMAs, in 8 groups of 4 k-steps.
+// Software pipeline, two groups deep: the LDS reads of group c+2 (2 x 16 B of K per lane, 4 A values) and the fp16->fp32
+// conversions of group c+1 are issued between the MFMAs of group c.  Each converted B operand has its own register until
+// its MFMA has issued: re-using one temporary for every conversion (what the compiler does with the naive loop) makes each
+// conversion wait for the in-flight MFMA that still reads it -- 84 cycles per MFMA instead of 64.
+struct KGroup { uint4 k0, k1; float a0, a1, a2, a3; };
+__device__ __forceinline__ KGroup read_group(const unsigned char *my, const float *Ap, int n31, int c)
+{
+    KGroup g;
+    g.k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
+    g.k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
+    g.a0 = Ap[(c * 4 + 0) * 64]; g.a1 = Ap[(c * 4 + 1) * 64]; g.a2 = Ap[(c * 4 + 2) * 64]; g.a3 = Ap[(c * 4 + 3) * 64];
+    return g;
+}
+struct BGroup { float b0[4], b1[4], a[4]; };
+__device__ __forceinline__ float cvt_lo_hi(uint32_t wd, int sh) { return h2f((uint16_t)((wd >> sh) & 0xffffu)); }
+__device__ __forceinline__ void mfma_phase(f32x16 &acc0, f32x16 &acc1, const unsigned char *my, const float *Ap, int n31, int sh)
+{
+    KGroup r1 = read_group(my, Ap, n31, 0), r2 = read_group(my, Ap, n31, 1);
+    BGroup cur;
+    {
+        const uint32_t w0[4] = {r1.k0.x, r1.k0.y, r1.k0.z, r1.k0.w}, w1[4] = {r1.k1.x, r1.k1.y, r1.k1.z, r1.k1.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cur.b0[u] = cvt_lo_hi(w0[u], sh); cur.b1[u] = cvt_lo_hi(w1[u], sh); }
+        cur.a[0] = r1.a0; cur.a[1] = r1.a1; cur.a[2] = r1.a2; cur.a[3] = r1.a3;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        // r2 = raw operands of group c+1 (already requested); request group c+2
+        KGroup r3 = r2;
+        if (c + 2 < 8) r3 = read_group(my, Ap, n31, c + 2);
+        BGroup nxt = cur;
+        const uint32_t w0[4] = {r2.k0.x, r2.k0.y, r2.k0.z, r2.k0.w}, w1[4] = {r2.k1.x, r2.k1.y, r2.k1.z, r2.k1.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                            // k-step 4c+u: dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b1[u], acc1, 0, 0, 0);
+            if (c + 1 < 8) { nxt.b0[u] = cvt_lo_hi(w0[u], sh); nxt.b1[u] = cvt_lo_hi(w1[u], sh); }
+        }
+        if (c + 1 < 8) { nxt.a[0] = r2.a0; nxt.a[1] = r2.a1; nxt.a[2] = r2.a2; nxt.a[3] = r2.a3; }
+        cur = nxt;
+        r2 = r3;
+        // the interleave, spelled out for the machine scheduler (left alone it sinks every conversion in front of its
+        // own MFMA): the group's LDS reads, then one MFMA followed by one conversion (shift + cvt) eight times
+        if (c + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            if (c + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+        }
+    }
+}
+
 template <int D>
-__global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
+__global__ void __launch_bounds__(256, 2) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
                                                                 int64_t ks_s, const uint16_t *__restrict__ q, int64_t qs_b,
                                                                 int64_t qs_h, int64_t qs_s, int q_row0, int H, int Hkv, int S,
                                                                 int W, int R, int passes, int Sp, int col_off,
@@ -122,7 +197,7 @@ __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
     __shared__ float As[(D / 2) * 64];                   // A operand of every k-step, shared by the 4 waves (same head)
     constexpr int NPH = D / DH;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = blockIdx.x % Hkv, blk = blockIdx.x / Hkv, nblk = gridDim.x / Hkv, b = blockIdx.y;
     const int G = H / Hkv;
     const int nwt = (S + 63) / 64;                       // 64-key wave tiles of this head
@@ -131,63 +206,99 @@ __global__ void __launch_bounds__(256) score_logits_mfma_kernel(const uint16_t *
     unsigned char *my = slab[w];
     const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
 
+    FK_STAMP_AT(0);
     for (int pass = 0; pass < passes; ++pass) {
-        KStage st;
-        k_fetch(st, kb, ks_s, (wave_id < nwt ? wave_id : 0) * 64, S, 0, lane);
         // A image: As[s][l] = q[row = pass*32 + (l&31)][dim = 2s + (l>>5)] (lane l of k-step s holds A[i=l&31][k=l>>5]);
-        // rows are the group's G heads x W window rows, row = i*W + r  <->  Q[b, g*G+i, S-W+r, :]   (utils.py:94)
+        // rows are the group's G heads x W window rows, row = i*W + r  <->  Q[b, g*G+i, S-W+r, :]   (utils.py:94).
+        // The query rows are requested BEFORE the first K tile (loads return in order: waiting for Q must not wait for
+        // the cold K rows), as unconditional 16-B vectors, all in flight together.
+        constexpr int QV = 32 * (D / 8) / 256;                 // 16-B vectors per thread
+        uint4 qv[QV];
+#pragma unroll
+        for (int u = 0; u < QV; ++u) {
+            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const int row = pass * 32 + rowl, rc = row < R ? row : R - 1;
+            const int i = rc / W, r = rc - i * W;
+            qv[u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(q_row0 + r) * qs_s + ch * 8);
+        }
+        // two register stages: the K rows of a phase are requested two phases (128 MFMAs) before they are committed to LDS
+        KStage sA, sB;
+        {
+            const int first = (wave_id < nwt ? wave_id : 0) * 64;
+            k_fetch(sA, kb, ks_s, first, S, 0, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (pass) __syncthreads();
-        for (int e = threadIdx.x; e < 32 * (D / 2); e += 256) {
-            const int rowl = e / (D / 2), dp = e - rowl * (D / 2);          // one fp16 pair (dims 2dp, 2dp+1) per item
-            const int row = pass * 32 + rowl;
-            uint32_t pr = 0;
-            if (row < R) {
-                const int i = row / W, r = row - i * W;
-                pr = *reinterpret_cast<const uint32_t *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(q_row0 + r) * qs_s + 2 * dp);
+#pragma unroll
+        for (int u = 0; u < QV; ++u) {
+            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const bool live = pass * 32 + rowl < R;
+            const uint32_t wds[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                       // fp16 pair (dims 2dp, 2dp+1), dp = ch*4 + e
+                const uint32_t pr = live ? wds[e] : 0u;
+                As[(ch * 4 + e) * 64 + rowl] = h2f((uint16_t)(pr & 0xffffu));
+                As[(ch * 4 + e) * 64 + 32 + rowl] = h2f((uint16_t)(pr >> 16));
             }
-            As[dp * 64 + rowl] = h2f((uint16_t)(pr & 0xffffu));
-            As[dp * 64 + 32 + rowl] = h2f((uint16_t)(pr >> 16));
         }
         __syncthreads();
+        // the second stage is requested only now: at launch every wave of the chip asks for its first K rows at once
+        // (16 MiB per stage at the 32k shape), and the query rows above queue behind whatever was requested before them
+        {
+            const int first = (wave_id < nwt ? wave_id : 0) * 64;
+            if (NPH >= 2) k_fetch(sB, kb, ks_s, first, S, 1, lane);
+            else if (wave_id + nwaves < nwt) k_fetch(sB, kb, ks_s, (wave_id + nwaves) * 64, S, 0, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FK_STAMP_AT(1);
         uint16_t *lp = logits + ((size_t)(b * H + g * G) * W + (size_t)pass * 32) * Sp + col_off;
-
-        for (int wt = wave_id; wt < nwt; wt += nwaves) {
+        int stamp_i = 2;
+        (void)stamp_i;
+        int tcount = 0;                                          // tiles done (NPH == 1: the stage alternates per tile)
+        for (int wt = wave_id; wt < nwt; wt += nwaves, ++tcount) {
             const int key0 = wt * 64;
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
-                k_commit(st, lane, my);
-                // prefetch the next phase (or the next tile's first phase) while the matrix pipe runs
-                if (ph + 1 < NPH) k_fetch(st, kb, ks_s, key0, S, ph + 1, lane);
-                else if (wt + nwaves < nwt) k_fetch(st, kb, ks_s, (wt + nwaves) * 64, S, 0, lane);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint4 k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
-                    const uint4 k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
-                    const uint32_t w0[4] = {k0.x, k0.y, k0.z, k0.w}, w1[4] = {k1.x, k1.y, k1.z, k1.w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int s = ph * (DH / 2) + c * 4 + u;             // dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
-                        const float b0 = h2f((uint16_t)((w0[u] >> sh) & 0xffffu));
-                        const float b1 = h2f((uint16_t)((w1[u] >> sh) & 0xffffu));
-                        const float a = As[s * 64 + lane];
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-                    }
-                }
+                // commit the stage holding this phase, then re-use it for the phase two steps ahead.  The loads must be
+                // issued HERE, ahead of the MFMAs that cover their latency: without the scheduling barriers the machine
+                // scheduler sinks them to the end of the phase, right in front of the wait of the next commit.
+                if (tcount == 0 && ph < 2) FK_CYC_AT(2 + ph * 3);
+                const bool useA = NPH >= 2 ? ((ph & 1) == 0) : ((tcount & 1) == 0);
+                int nkey, nph;                                   // phase (ph + 2) in tile order
+                if (NPH == 1) { nkey = (wt + 2 * nwaves) * 64; nph = 0; }
+                else if (ph + 2 < NPH) { nkey = key0; nph = ph + 2; }
+                else { nkey = (wt + nwaves) * 64; nph = ph + 2 - NPH; }
+                const bool more = nkey < nwt * 64;
+                if (useA) { k_commit(sA, lane, my); if (more) k_fetch(sA, kb, ks_s, nkey, S, nph, lane); }
+                else { k_commit(sB, lane, my); if (more) k_fetch(sB, kb, ks_s, nkey, S, nph, lane); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (tcount == 0 && ph < 2) FK_CYC_AT(3 + ph * 3);
+                mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);              // ... and the next commit (which waits for them) stays behind the MFMAs
+                if (tcount == 0 && ph < 2) FK_CYC_AT(4 + ph * 3);
             }
             // C/D map: register i of lane l is row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31
             const int j0 = key0 + n31, j1 = key0 + 32 + n31;
+            if (key0 + 64 <= S && pass * 32 + 32 <= R) {        // full tile: branch-free stores
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
-                if (pass * 32 + m < R) {
-                    if (j0 < S) lp[(size_t)m * Sp + j0] = f2h(acc0[i]);
-                    if (j1 < S) lp[(size_t)m * Sp + j1] = f2h(acc1[i]);
+                for (int i = 0; i < 16; ++i) {
+                    const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                    lp[(size_t)m * Sp + j0] = f2h(acc0[i]);
+                    lp[(size_t)m * Sp + j1] = f2h(acc1[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                    if (pass * 32 + m < R) {
+                        if (j0 < S) lp[(size_t)m * Sp + j0] = f2h(acc0[i]);
+                        if (j1 < S) lp[(size_t)m * Sp + j1] = f2h(acc1[i]);
+                    }
                 }
             }
         }
@@ -677,4 +788,12 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
     return hipSuccess;
 }
 
+#ifdef FK_STAMP
+}  // namespace fk
+extern "C" int fastkv_debug_read_stamps(unsigned long long *host, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::g_stamps), n * sizeof(unsigned long long));
+}
+namespace fk {
+#endif
 }  // namespace fk
