@@ -49,6 +49,22 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p)
     return make_layout(q).total;
 }
 
+// One 256-thread block: zero the control block, then magic + epoch 0.
+__global__ void fastkv_ctrl_init_kernel(uint32_t *ctrl)
+{
+    for (int i = threadIdx.x; i < (int)(CTRL_BYTES / 4); i += blockDim.x) ctrl[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { ctrl[0] = (uint32_t)(CTRL_MAGIC & 0xffffffffu); ctrl[1] = (uint32_t)(CTRL_MAGIC >> 32); }
+}
+
+int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255)) return FASTKV_EINVAL;
+    if (workspace_bytes < CTRL_BYTES) return FASTKV_EWORKSPACE;
+    hipLaunchKernelGGL(fastkv_ctrl_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint32_t *>(workspace));
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
 size_t fastkv_select_workspace_bytes(int64_t rows, int64_t n, int64_t k) { return select_ws_bytes(rows, n, k); }
 
 int fastkv_score_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,

@@ -9,6 +9,10 @@ namespace fk {
 
 constexpr int TKA = 256;        // keys per workgroup in score_logits (4 waves x 64 lanes, one key per lane)
 constexpr int SEL_THREADS = 1024;
+constexpr size_t CTRL_BYTES = 8192;  // control block at the start of every operator workspace (fastkv_workspace_init):
+                                     // u64 magic, u32 epoch, then at byte 64 the hand-off flags of the fused score kernel
+constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
+constexpr int FUSED_MAX_WGS = 512;   // workgroups of one fused score launch (2 per CU): sizes its partial records and flags
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -20,7 +24,7 @@ struct Layout {
     int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
     int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
     int ntA;                         // tiles of score_logits
-    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_idx, off_keys, total;
+    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_fpart, off_idx, off_keys, total;
     int zero_words;                  // u32 words from off_hist that row_stats zeroes: histograms + arrival counters
 };
 
@@ -48,7 +52,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.Sp = (p.S + 7) / 8 * 8;
     L.n_pad = (L.n + 7) / 8 * 8;
     L.ntA = (p.S + TKA - 1) / TKA;
-    size_t o = 0;
+    size_t o = CTRL_BYTES;
     L.off_qf = o;     o += align_up((size_t)p.B * p.Hkv * L.R_alloc * p.D * 4, 256);
     L.off_logits = o; o += align_up((size_t)p.B * p.H * p.window * L.Sp * 2, 256);
     L.off_gmax = o;   o += align_up((size_t)p.B * p.H * p.window * 4, 256);
@@ -60,6 +64,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
     L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
+    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * 32 * 12, 256);        // fused score: row max / row sum records
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {
@@ -75,6 +80,9 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
                         char *ws, hipStream_t st, int64_t *all_idx = nullptr, uint16_t *all_keys = nullptr,
                         int64_t all_key_stride = 0);
+// fused logits + softmax + window-row sum (fused.hip); false = shape not covered, take the three-kernel path
+bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
+                        const int64_t *ks, uint16_t *hs, int hs_stride, char *ws, hipStream_t st, hipError_t *err);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
 hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,

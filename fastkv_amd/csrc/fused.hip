@@ -1,0 +1,408 @@
+// Fused window scoring for the common geometry (G*W == 32 query rows per KV head, W == 8, rows short enough that a wave
+// keeps the logits of all its tiles in registers): ONE launch replaces score_logits + row_stats and the window-row sum of
+// score_finalize (/root/reference/baselines/fastkv/utils.py:93-104).  The 16 MiB of logits of the 32k shape never leave
+// the registers; what reaches memory is hs[b,h,j] = fp16(sum over the W window rows of the fp16 probabilities), 2 MiB,
+// which score_finalize then pools and sums over the heads of the group (utils.py:105-112).
+//
+// Same arithmetic, operation for operation, as the unfused kernels (and as oracle/fastkv_oracle.c): fp32 fma chain
+// on the matrix pipe -> fp16 -> true division by sqrt(D) -> fp16 -> window mask -> row max -> det_expf -> 2^-40
+// fixed-point sum -> p = fp16(e * (1/sum)) -> sequential fp32 sum over the window rows -> fp16.
+//
+// The softmax needs two chip-wide reductions per query row (max, then sum).  All workgroups of the launch are resident
+// at once (the host takes this path only when grid <= 2 workgroups per CU and the occupancy query agrees), so the
+// reductions are in-kernel hand-offs instead of kernel boundaries:
+//   every workgroup publishes its 32 partial row maxima / sums as plain per-workgroup records and then a flag word
+//   carrying the launch TOKEN (a process-wide counter, so a flag left behind by an earlier launch or by uninitialised
+//   memory never matches); consumers poll the flags of the nblk workgroups of their (batch, kv head) and then read the
+//   records.  No atomics on shared words, nothing to zero beforehand, order-free integer / max combination.
+#include "fk_device.h"
+#include "fk_host.h"
+#include "prof.h"
+#include "mfma_tile.h"
+#include <cstdlib>
+
+namespace fk {
+
+#ifdef FK_STAMP
+__device__ unsigned long long g_fstamps[4096 * 8];
+#define FKF_STAMP(slot) do { if (lane == 0) g_fstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define FKF_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the nblk partial records
+
+// One wave polls the nblk flag words (one 4-B sc1 load per lane and pass), sleeping between passes: pollers share the
+// memory channel of those words with the producers' stores.
+__device__ __forceinline__ void wait_flags(const uint32_t *flags, int nblk, uint32_t token, int lane)
+{
+    uint32_t spins = 0;
+    for (;;) {
+        bool ok = true;
+        for (int l = lane; l < nblk; l += 64)
+            ok = ok && (__hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) __builtin_trap();          // seconds: a partner never arrived; fail loudly instead of hanging
+    }
+    // every byte handed over is stored write-through (sc1) and drained before its flag, and every load of it is an sc1
+    // load: no cache invalidate is needed, only the compiler must keep those loads behind the poll
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int D, int PER>
+__global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
+                                                             const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
+                                                             int H, int Hkv, int S, float sqrtD, float rsqrtD,
+                                                             uint16_t *__restrict__ hs, int hs_stride, float *__restrict__ pmax,
+                                                             uint64_t *__restrict__ psum, const uint32_t *__restrict__ ctrl,
+                                                             uint32_t *__restrict__ zero_area, int zero_words)
+{
+    constexpr int W = 8, G = 4, NPH = D / DH;
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
+    __shared__ float As[(D / 2) * 64];
+    __shared__ float s_f[FUSED_PARTS][32];
+    __shared__ uint64_t s_u[FUSED_PARTS][32];
+    __shared__ uint32_t s_bad[FUSED_PARTS][32];
+    __shared__ float s_row[32];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x % Hkv, blk = blockIdx.x / Hkv, nblk = gridDim.x / Hkv, b = blockIdx.y;
+    const int bg = b * Hkv + g, BG = gridDim.y * Hkv;
+    const int n = S - W;
+    const int nwt = (S + 63) / 64;
+    const int wave_id = blk * 4 + w, nwaves = nblk * 4;
+    const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
+    unsigned char *my = slab[w];
+    const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
+
+    // control block (fastkv_workspace_init): a missing initialisation must not turn into a silent wrong answer.  The token
+    // of this launch is the epoch left by the previous one + 1 (score_finalize bumps it): never a launch argument, which a
+    // graph replay would freeze; the flags still hold the previous token or the zeros of the initialisation.
+    if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
+    const uint32_t token = ctrl[2] + 1u ? ctrl[2] + 1u : 1u;
+    uint32_t *flags = const_cast<uint32_t *>(ctrl) + 16;
+    FKF_STAMP(0);
+    // zero the key histograms / arrival counters that score_finalize, tsp_rowsum and the selection accumulate into
+    {
+        const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = (zero_words + nwg - 1) / nwg;
+        const int lo = wg * per, hi2 = min(lo + per, zero_words);
+        for (int i = lo + (int)threadIdx.x; i < hi2; i += 256) zero_area[i] = 0;
+    }
+
+    // ---------------------------------------------------------------- A operand (see score_logits_mfma_kernel)
+    constexpr int QV = 32 * (D / 8) / 256;
+    uint4 qv[QV];
+#pragma unroll
+    for (int u = 0; u < QV; ++u) {
+        const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+        const int i = rowl / W, r = rowl - i * W;
+        qv[u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(n + r) * qs_s + ch * 8);
+    }
+    KStage sA, sB;
+    k_fetch(sA, kb, ks_s, (wave_id < nwt ? wave_id : 0) * 64, S, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < QV; ++u) {
+        const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+        const uint32_t wds[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            As[(ch * 4 + e) * 64 + rowl] = h2f((uint16_t)(wds[e] & 0xffffu));
+            As[(ch * 4 + e) * 64 + 32 + rowl] = h2f((uint16_t)(wds[e] >> 16));
+        }
+    }
+    __syncthreads();
+    {
+        const int first = (wave_id < nwt ? wave_id : 0) * 64;
+        if (NPH >= 2) k_fetch(sB, kb, ks_s, first, S, 1, lane);
+        else if (wave_id + nwaves < nwt) k_fetch(sB, kb, ks_s, (wave_id + nwaves) * 64, S, 0, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------------------------------------------------------- phase A: logits of this wave's tiles, row maxima
+    // lg[t][i]: scaled + masked fp16 logits of query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns key0 + n31 (low half)
+    // and key0 + 32 + n31 (high half); mx[i] = running maximum of row m(i) over this lane's columns
+    uint32_t lg[PER][16];
+    float mx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx[i] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lg[t][i] = 0;
+        const int wt = wave_id + t * nwaves;
+        if (wt < nwt) {
+            const int key0 = wt * 64;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+                const bool useA = NPH >= 2 ? ((ph & 1) == 0) : ((t & 1) == 0);
+                int nkey, nph;
+                if (NPH == 1) { nkey = (wt + 2 * nwaves) * 64; nph = 0; }
+                else if (ph + 2 < NPH) { nkey = key0; nph = ph + 2; }
+                else { nkey = (wt + nwaves) * 64; nph = ph + 2 - NPH; }
+                const bool more = nkey < nwt * 64 && (NPH == 1 ? t + 2 < PER : (ph + 2 < NPH || t + 1 < PER));
+                if (useA) { k_commit(sA, lane, my); if (more) k_fetch(sA, kb, ks_s, nkey, S, nph, lane); }
+                else { k_commit(sB, lane, my); if (more) k_fetch(sB, kb, ks_s, nkey, S, nph, lane); }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int j0 = key0 + n31, j1 = j0 + 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rw = (i & 3) + 4 * hi;                                         // window row of query row m(i): m % W
+                uint16_t s0 = f2h(scale_div(h2f(f2h(acc0[i])), sqrtD, rsqrtD));          // utils.py:94 (matmul -> fp16, / sqrt(D) -> fp16)
+                uint16_t s1 = f2h(scale_div(h2f(f2h(acc1[i])), sqrtD, rsqrtD));
+                if (j0 >= n && (j0 - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));           // utils.py:95-101
+                if (j1 >= n && (j1 - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
+                if (j0 < S) mx[i] = fmaxf(mx[i], h2f(s0));
+                if (j1 < S) mx[i] = fmaxf(mx[i], h2f(s1));
+                lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
+            }
+        }
+    }
+    FKF_STAMP(1);
+    // row maxima: across the 32 lanes of a half wave, then across the 4 waves, then published
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o, 64));
+    }
+    if (n31 == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_f[w][(i & 3) + 8 * (i >> 2) + 4 * hi] = mx[i];
+    }
+    __syncthreads();
+    uint32_t *flag1 = flags + (size_t)bg * nblk, *flag2 = flags + (size_t)(BG + bg) * nblk;
+    float *pm = pmax + (size_t)bg * nblk * 32;
+    uint64_t *psu = psum + (size_t)bg * nblk * 32;
+    if (w == 0) {
+        if (lane < 32)
+            __hip_atomic_store(pm + blk * 32 + lane, fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane])),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // write-through record
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       // ... drained before its flag
+        if (lane == 0) __hip_atomic_store(flag1 + blk, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_flags(flag1, nblk, token, lane);
+    }
+    __syncthreads();
+    {
+        const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
+        float rec[FUSED_MAX_WGS / 8 / FUSED_PARTS];                  // nblk <= FUSED_MAX_WGS / 8 ... all loads in flight together
+#pragma unroll
+        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+            const int bl = part + u * FUSED_PARTS;
+            rec[u] = __hip_atomic_load(pm + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float v = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) v = fmaxf(v, rec[u]);
+        s_f[part][row] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v = s_f[0][threadIdx.x];
+#pragma unroll
+        for (int u = 1; u < FUSED_PARTS; ++u) v = fmaxf(v, s_f[u][threadIdx.x]);
+        s_row[threadIdx.x] = v;
+    }
+    __syncthreads();
+
+    FKF_STAMP(2);
+    // ---------------------------------------------------------------- phase B: e = exp(x - max), fixed-point row sums
+    float gm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gm[i] = s_row[(i & 3) + 8 * (i >> 2) + 4 * hi];
+    float ev[PER][2][16];
+    uint32_t ahi[16], alo[16], nanbits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int key0 = (wave_id + t * nwaves) * 64;          // >= S when the wave has no tile t: nothing is counted
+        const int j0 = key0 + n31, j1 = j0 + 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e0 = det_expf(h2f((uint16_t)(lg[t][i] & 0xffffu)) - gm[i]);
+            const float e1 = det_expf(h2f((uint16_t)(lg[t][i] >> 16)) - gm[i]);
+            ev[t][0][i] = e0;
+            ev[t][1][i] = e1;
+            if (j0 < S) {
+                if (e0 != e0) nanbits |= 1u << i;
+                else { uint32_t h2, l2; exp_to_fix(e0, h2, l2); ahi[i] += h2; alo[i] += l2; }
+            }
+            if (j1 < S) {
+                if (e1 != e1) nanbits |= 1u << i;
+                else { uint32_t h2, l2; exp_to_fix(e1, h2, l2); ahi[i] += h2; alo[i] += l2; }
+            }
+        }
+    }
+    FKF_STAMP(3);
+    // per lane at most 2*PER <= 8 elements per row (hi <= 2^16, lo <= 2^24 each): the 32-bit lane sums are exact; they
+    // are combined to the 2^-40 fixed-point value before the half-wave reduction
+    uint64_t tot[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        tot[i] = ((uint64_t)ahi[i] << 24) + alo[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) tot[i] += (uint64_t)__shfl_xor((long long)tot[i], o, 64);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) nanbits |= (uint32_t)__shfl_xor((int)nanbits, o, 64);
+    if (n31 == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            s_u[w][m] = tot[i];
+            s_bad[w][m] = (nanbits >> i) & 1u;
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        if (lane < 32) {
+            const uint32_t bad = s_bad[0][lane] | s_bad[1][lane] | s_bad[2][lane] | s_bad[3][lane];
+            __hip_atomic_store(psu + blk * 32 + lane, bad ? FK_SUM_POISON : s_u[0][lane] + s_u[1][lane] + s_u[2][lane] + s_u[3][lane],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flag2 + blk, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_flags(flag2, nblk, token, lane);
+    }
+    __syncthreads();
+    {
+        const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
+        uint64_t rec[FUSED_MAX_WGS / 8 / FUSED_PARTS];
+#pragma unroll
+        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+            const int bl = part + u * FUSED_PARTS;
+            rec[u] = __hip_atomic_load(psu + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint64_t s = 0;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+            if (part + u * FUSED_PARTS < nblk) { if (rec[u] == FK_SUM_POISON) bad = 1; else s += rec[u]; }
+        }
+        s_u[part][row] = s;
+        s_bad[part][row] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        uint64_t s = 0;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int u = 0; u < FUSED_PARTS; ++u) { s += s_u[u][threadIdx.x]; bad |= s_bad[u][threadIdx.x]; }
+        s_row[threadIdx.x] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);          // utils.py:103
+    }
+    __syncthreads();
+
+    FKF_STAMP(4);
+    // ---------------------------------------------------------------- phase C: probabilities, sum over the window rows
+    // Head i4 = i >> 2 of the group owns rows 8*i4 .. 8*i4+7; the lower half wave holds window rows 0-3 of every head,
+    // the upper half rows 4-7.  The reference adds the 8 fp16 probabilities in ascending row order (fp32 accumulator,
+    // utils.py:104): the lower half's partial sum crosses to the upper half, which finishes it and owns the result.
+    float ri[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ri[i] = s_row[(i & 3) + 8 * (i >> 2) + 4 * hi];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int key0 = (wave_id + t * nwaves) * 64;
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk) {
+            const int j = key0 + bk * 32 + n31;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                float p[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) p[u] = h2f(f2h(ev[t][bk][4 * i4 + u] * ri[4 * i4 + u]));
+                float a = 0.0f;
+                a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
+                float c = __shfl_xor(a, 32, 64);                 // upper half: the lower half's sum of rows 0-3
+                c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
+                if (hi && j < n) hs[(size_t)(b * H + g * G + i4) * hs_stride + j] = f2h(c);
+            }
+        }
+    }
+    FKF_STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+template <int D, int PER> static bool fused_resident(int grid_wgs)
+{
+    static int wgs_per_cu = -1, cus = 0;
+    if (wgs_per_cu < 0) {
+        int dev = 0, nb = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER>), 256, 0) !=
+                hipSuccess) {
+            wgs_per_cu = 0;
+        } else {
+            wgs_per_cu = nb;
+            cus = prop.multiProcessorCount;
+        }
+    }
+    return wgs_per_cu >= 1 && grid_wgs <= (wgs_per_cu < 2 ? wgs_per_cu : 2) * cus;
+}
+
+// Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
+// covered and the caller must take the three-kernel path.
+bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
+                        const int64_t *ks, uint16_t *hs, int hs_stride, char *ws, hipStream_t st, hipError_t *err)
+{
+    static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    if (disabled || L.engine != ENGINE_MFMA || L.R != 32 || p.window != 8 || p.H / p.Hkv != 4) return false;
+    const int nwt = (p.S + 63) / 64;
+    int nblk = (2 * 256) / (p.Hkv * p.B);
+    if (nblk < 1) return false;
+    if (nblk > FUSED_MAX_WGS / 8) nblk = FUSED_MAX_WGS / 8;
+    if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
+    const int per = (nwt + nblk * 4 - 1) / (nblk * 4);
+    if (per > 4) return false;
+    nblk = (nwt + per * 4 - 1) / (per * 4);
+    const int PERT = per <= 1 ? 1 : per <= 2 ? 2 : 4;
+    if ((size_t)p.B * p.Hkv * nblk > FUSED_MAX_WGS) return false;
+    const float sqrtD = (float)sqrt((double)p.D);
+    float *pmax = reinterpret_cast<float *>(ws + L.off_fpart);
+    uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 4);
+    const uint32_t *ctrl = reinterpret_cast<const uint32_t *>(ws);
+    uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
+    dim3 grid(nblk * p.Hkv, p.B);
+    const int wgs = nblk * p.Hkv * p.B;
+    bool resident = false;
+#define FK_RES(DV) (PERT == 1 ? fused_resident<DV, 1>(wgs) : PERT == 2 ? fused_resident<DV, 2>(wgs) : fused_resident<DV, 4>(wgs))
+    resident = p.D == 64 ? FK_RES(64) : p.D == 128 ? FK_RES(128) : FK_RES(256);
+#undef FK_RES
+    if (!resident) return false;
+    ProfScope ps_(K_LOGITS, st);
+#define FK_FUSED(DV, PV)                                                                                                         \
+    hipLaunchKernelGGL((score_fused_kernel<DV, PV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],           \
+                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, hs, hs_stride, pmax, psum, \
+                       ctrl, zero, L.zero_words)
+#define FK_FUSED_D(DV)                                                                             \
+    do {                                                                                           \
+        if (PERT == 1) FK_FUSED(DV, 1); else if (PERT == 2) FK_FUSED(DV, 2); else FK_FUSED(DV, 4);  \
+    } while (0)
+    if (p.D == 64) FK_FUSED_D(64);
+    else if (p.D == 128) FK_FUSED_D(128);
+    else FK_FUSED_D(256);
+#undef FK_FUSED_D
+#undef FK_FUSED
+    *err = hipGetLastError();
+    return true;
+}
+
+#ifdef FK_STAMP
+}  // namespace fk
+extern "C" int fastkv_debug_read_fused_stamps(unsigned long long *host, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::g_fstamps), n * sizeof(unsigned long long));
+}
+namespace fk {
+#endif
+}  // namespace fk

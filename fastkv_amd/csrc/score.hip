@@ -23,10 +23,10 @@
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
+#include "mfma_tile.h"
 
 namespace fk {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Measurement build (-DFK_STAMP): per-wave wall-clock stamps (100 MHz) of the matrix-pipe kernel's stages.
 #ifdef FK_STAMP
@@ -65,29 +65,6 @@ __global__ void prep_q_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int6
     qf[(((size_t)bg * (R_alloc / RB) + pass) * D + d) * RB + rr] = v;
 }
 
-// ------------------------------------------------------------------------------------------ K staging shared by both engines
-// A wave stages 64 dims of its 64 consecutive key rows through a private LDS slab: coalesced 16-B global loads (8 lanes
-// per 128-B row segment), 144-B padded rows so that one-row-per-lane ds_read_b128 is bank-conflict free.
-constexpr int DH = 64;
-constexpr int ROWB = DH * 2 + 16;
-
-__device__ __forceinline__ void stage_k(const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane,
-                                        unsigned char *my)
-{
-    const int lrow = lane >> 3, lchunk = lane & 7;
-    uint4 st[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int jj = key0 + i * 8 + lrow;
-        jj = jj < S ? jj : S - 1;
-        st[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)jj * ks_s + ph * DH + lchunk * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(my + (i * 8 + lrow) * ROWB + lchunk * 16) = st[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // ------------------------------------------------------------------------------------------ score_logits, matrix pipe
 // Persistent waves: grid.x = nblk * Hkv with blockIdx.x % Hkv = kv head (the Hkv workgroups that stream the same token
 // range run together, one per XCD under round-robin placement, so an XCD's L2 keeps one head's query block: speed only),
@@ -95,98 +72,6 @@ __device__ __forceinline__ void stage_k(const uint16_t *__restrict__ kb, int64_t
 // nwaves, ...  The A operand (the head's 32 query rows, all D/2 k-steps) is loaded into registers once per wave; the
 // K rows of the next phase/tile are fetched into registers while the matrix pipe works on the current LDS slab.
 // Eight named 16-B registers (an indexed local array carried across the tile loop ends up in scratch memory).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct KStage { u32x4 r0, r1, r2, r3, r4, r5, r6, r7; };
-
-// One phase of a 64-key tile: 8 x 16 B per lane (lane l: key row i*8 + (l>>3), bytes (l&7)*16 of the 128-B phase slice).
-// Full tiles are buffer loads: ONE per-lane 32-bit offset, the tile base in a wave-uniform descriptor and the row block
-// in the scalar offset; only the ragged last tile clamps the row per lane.  Per-load 64-bit vector addresses for two stages cost 64 VGPRs and spilled.
-__device__ __forceinline__ void k_fetch(KStage &st, const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane)
-{
-    if (key0 + 64 <= S) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint16_t *>(kb + (int64_t)key0 * ks_s + ph * DH), 0, 0x7fffffff, 0x00020000);        // wave-uniform
-        const int loff = ((lane >> 3) * (int)ks_s + (lane & 7) * 8) * 2;
-        const int step = (int)ks_s * 16;                                                                     // 8 rows, bytes
-#define FK_KLD(i) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (i) * step, 0))
-        st.r0 = FK_KLD(0); st.r1 = FK_KLD(1); st.r2 = FK_KLD(2); st.r3 = FK_KLD(3);
-        st.r4 = FK_KLD(4); st.r5 = FK_KLD(5); st.r6 = FK_KLD(6); st.r7 = FK_KLD(7);
-#undef FK_KLD
-    } else {
-        u32x4 t[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int jj = key0 + i * 8 + (lane >> 3);
-            jj = jj < S ? jj : S - 1;
-            t[i] = *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
-        }
-        st.r0 = t[0]; st.r1 = t[1]; st.r2 = t[2]; st.r3 = t[3]; st.r4 = t[4]; st.r5 = t[5]; st.r6 = t[6]; st.r7 = t[7];
-    }
-}
-__device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned char *my)
-{
-    unsigned char *base = my + (lane >> 3) * ROWB + (lane & 7) * 16;
-    *reinterpret_cast<u32x4 *>(base + 0 * 8 * ROWB) = st.r0; *reinterpret_cast<u32x4 *>(base + 1 * 8 * ROWB) = st.r1;
-    *reinterpret_cast<u32x4 *>(base + 2 * 8 * ROWB) = st.r2; *reinterpret_cast<u32x4 *>(base + 3 * 8 * ROWB) = st.r3;
-    *reinterpret_cast<u32x4 *>(base + 4 * 8 * ROWB) = st.r4; *reinterpret_cast<u32x4 *>(base + 5 * 8 * ROWB) = st.r5;
-    *reinterpret_cast<u32x4 *>(base + 6 * 8 * ROWB) = st.r6; *reinterpret_cast<u32x4 *>(base + 7 * 8 * ROWB) = st.r7;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// One 64-dim phase of a 64-key tile: 64 k-steps x 2 column blocks = 128 MFMAs, in 8 groups of 4 k-steps.
-// Software pipeline, two groups deep: the LDS reads of group c+2 (2 x 16 B of K per lane, 4 A values) and the fp16->fp32
-// conversions of group c+1 are issued between the MFMAs of group c.  Each converted B operand has its own register until
-// its MFMA has issued: re-using one temporary for every conversion (what the compiler does with the naive loop) makes each
-// conversion wait for the in-flight MFMA that still reads it -- 84 cycles per MFMA instead of 64.
-struct KGroup { uint4 k0, k1; float a0, a1, a2, a3; };
-__device__ __forceinline__ KGroup read_group(const unsigned char *my, const float *Ap, int n31, int c)
-{
-    KGroup g;
-    g.k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
-    g.k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
-    g.a0 = Ap[(c * 4 + 0) * 64]; g.a1 = Ap[(c * 4 + 1) * 64]; g.a2 = Ap[(c * 4 + 2) * 64]; g.a3 = Ap[(c * 4 + 3) * 64];
-    return g;
-}
-struct BGroup { float b0[4], b1[4], a[4]; };
-__device__ __forceinline__ float cvt_lo_hi(uint32_t wd, int sh) { return h2f((uint16_t)((wd >> sh) & 0xffffu)); }
-__device__ __forceinline__ void mfma_phase(f32x16 &acc0, f32x16 &acc1, const unsigned char *my, const float *Ap, int n31, int sh)
-{
-    KGroup r1 = read_group(my, Ap, n31, 0), r2 = read_group(my, Ap, n31, 1);
-    BGroup cur;
-    {
-        const uint32_t w0[4] = {r1.k0.x, r1.k0.y, r1.k0.z, r1.k0.w}, w1[4] = {r1.k1.x, r1.k1.y, r1.k1.z, r1.k1.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { cur.b0[u] = cvt_lo_hi(w0[u], sh); cur.b1[u] = cvt_lo_hi(w1[u], sh); }
-        cur.a[0] = r1.a0; cur.a[1] = r1.a1; cur.a[2] = r1.a2; cur.a[3] = r1.a3;
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        // r2 = raw operands of group c+1 (already requested); request group c+2
-        KGroup r3 = r2;
-        if (c + 2 < 8) r3 = read_group(my, Ap, n31, c + 2);
-        BGroup nxt = cur;
-        const uint32_t w0[4] = {r2.k0.x, r2.k0.y, r2.k0.z, r2.k0.w}, w1[4] = {r2.k1.x, r2.k1.y, r2.k1.z, r2.k1.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                            // k-step 4c+u: dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b0[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b1[u], acc1, 0, 0, 0);
-            if (c + 1 < 8) { nxt.b0[u] = cvt_lo_hi(w0[u], sh); nxt.b1[u] = cvt_lo_hi(w1[u], sh); }
-        }
-        if (c + 1 < 8) { nxt.a[0] = r2.a0; nxt.a[1] = r2.a1; nxt.a[2] = r2.a2; nxt.a[3] = r2.a3; }
-        cur = nxt;
-        r2 = r3;
-        // the interleave, spelled out for the machine scheduler (left alone it sinks every conversion in front of its
-        // own MFMA): the group's LDS reads, then one MFMA followed by one conversion (shift + cvt) eight times
-        if (c + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            if (c + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
-        }
-    }
-}
-
 template <int D>
 __global__ void __launch_bounds__(256, 2) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
                                                                 int64_t ks_s, const uint16_t *__restrict__ q, int64_t qs_b,
@@ -541,20 +426,26 @@ __device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool ac
 // pool -> fp16 (utils.py:105-108), sum over the G heads of the group -> fp16 (utils.py:112).  The G*W values of a
 // position are fetched in batches of 32 independent loads before any arithmetic.
 __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ probs, int H, int Hkv, ColWin cw, int W,
-                                                             int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
+                                                             int wr, int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
                                                              int64_t c_row_stride, uint32_t *__restrict__ hist12,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
-                                                             int64_t all_key_stride)
+                                                             int64_t all_key_stride, uint32_t *__restrict__ epoch_bump)
 {
+    // after a fused score launch: advance the workspace epoch (fused.hip; the next launch's hand-off token)
+    if (epoch_bump && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        const uint32_t e = *epoch_bump + 1u;
+        *epoch_bump = e ? e : 1u;
+    }
     __shared__ float s_tile[2][256];
     __shared__ uint32_t s_hist[HIST12];
     const int g = blockIdx.y, b = blockIdx.z;
-    const int G = H / Hkv, n = cw.S_glob - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * W;
+    // wr = rows of `probs` per query head: W (probabilities, summed here) or 1 (the fused kernel already summed them)
+    const int G = H / Hkv, n = cw.S_glob - W, pad = ksize / 2, TP = 256 - 2 * pad, R = G * wr;
     const int t = threadIdx.x;
     const int j = cw.own_lo + blockIdx.x * TP - pad + t;            // column; global candidate position pos0 + j
     const bool inrange = (j >= 0) && (j < cw.ncols) && (cw.pos0 + j >= 0) && (cw.pos0 + j < n);
     const bool is_out = (t >= pad) && (t < pad + TP) && inrange && (j >= cw.own_lo) && (j < cw.own_hi);
-    const size_t row0 = (size_t)(b * H + g * G) * W;
+    const size_t row0 = (size_t)(b * H + g * G) * wr;
     const uint16_t *lp = probs + row0 * Sp + (inrange ? j : 0);
     if (hist12) for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
     float gsum = 0.0f, a = 0.0f;
@@ -568,7 +459,7 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
             const int rr = rb + u;                                  // uniform
             if (rr < R) {
                 a = a + h2f(x[u]);                                  // sum over the window rows (utils.py:104)
-                if (++rw == W) {                                    // last window row of head `head`
+                if (++rw == wr) {                                   // last window row of head `head`
                     rw = 0;
                     float sv = inrange ? h2f(f2h(a)) : (pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY);   // padding, utils.py:106,108
                     float *st = s_tile[head & 1];
@@ -707,8 +598,12 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     const ColWin cw = {p.S, 0, 0, p.S, p.S};
     hipError_t e;
 
-    if ((e = launch_logits(p, L, q, qs, p.S - p.window, k, ks, qf, logits, L.Sp, 0, st)) != hipSuccess) return e;
-    {
+    int wr = p.window;
+    if (launch_score_fused(p, L, q, qs, k, ks, logits, L.Sp, ws, st, &e)) {
+        if (e != hipSuccess) return e;
+        wr = 1;                                                  // `logits` now holds hs[b,h,:] (window rows already summed)
+    } else {
+        if ((e = launch_logits(p, L, q, qs, p.S - p.window, k, ks, qf, logits, L.Sp, 0, st)) != hipSuccess) return e;
         ProfScope ps_(K_ROWSTATS, st);
         if (p.S <= 8192)
             hipLaunchKernelGGL(row_stats_kernel<256>, dim3(p.B * p.H * p.window), dim3(256), 0, st, logits, cw, p.window, L.Sp, sqrtD,
@@ -722,8 +617,9 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         ProfScope ps_(K_FINALIZE, st);
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
-        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, L.Sp, p.kernel,
-                           p.pooling, c_out, c_row_stride, hist, all_idx, all_keys, all_key_stride);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, wr, L.Sp, p.kernel,
+                           p.pooling, c_out, c_row_stride, hist, all_idx, all_keys, all_key_stride,
+                           wr == 1 ? reinterpret_cast<uint32_t *>(ws) + 2 : (uint32_t *)nullptr);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
@@ -775,8 +671,9 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
         ProfScope ps_(K_FINALIZE, st);
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((n_own + TP - 1) / TP, p.Hkv, p.B);
-        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, w.Sp, p.kernel,
-                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, p.window, w.Sp, p.kernel,
+                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, (int64_t)0,
+                           (uint32_t *)nullptr);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {

@@ -44,7 +44,7 @@ class HipLocalOps:
                             capacity=S, tsp_len=0, order=0, reserved=self.ops._engine)
 
     def _ws(self, p, dev):
-        return self.ops._workspace(self.lib.fastkv_sp_workspace_bytes(ctypes.byref(p)), dev)
+        return self.ops._workspace(self.lib.fastkv_sp_workspace_bytes(ctypes.byref(p)), dev, "scratch")
 
     def logits(self, q_win, k, logits_ext, col_off, window, kernel_size, pooling):
         B, H, W, D = q_win.shape

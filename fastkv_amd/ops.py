@@ -33,12 +33,19 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
-    """Grow-only per-(device, stream) scratch; reuse is safe because all users are ordered on that stream."""
-    key = (device.index, _stream())
+def _workspace(nbytes: int, device: torch.device, kind: str = "op") -> torch.Tensor:
+    """Grow-only per-(device, stream, kind) scratch; reuse is safe because all users are ordered on that stream.
+
+    kind "op": workspace of fastkv_update_kv_f16 / fastkv_score_f16 -- its first 8 KiB are the control block that
+    fastkv_workspace_init sets up once per allocation and that only those entry points may touch.
+    kind "scratch": plain scratch of the stand-alone select and the sequence-sharded stages (written from byte 0)."""
+    key = (device.index, _stream(), kind)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if kind == "op":
+            check(load().fastkv_workspace_init(ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
+                                               ctypes.c_void_p(_stream())), "workspace_init")
         _ws_cache[key] = ws
     return ws
 
@@ -130,7 +137,7 @@ def select(scores2d: torch.Tensor, k: int, order: str = "index", append: int = 0
     L = load()
     rows, n = scores2d.shape
     out = torch.empty(rows, k + append, dtype=torch.int64, device=scores2d.device)
-    ws = _workspace(L.fastkv_select_workspace_bytes(rows, n, k), scores2d.device)
+    ws = _workspace(L.fastkv_select_workspace_bytes(rows, n, k), scores2d.device, "scratch")
     rc = L.fastkv_select_f16(scores2d.data_ptr(), rows, scores2d.stride(0), n, k, ORDER[order], append, out.data_ptr(),
                              ws.data_ptr(), ws.numel(), _stream())
     check(rc, "select")

@@ -63,6 +63,17 @@ typedef struct fastkv_problem {
 size_t fastkv_workspace_bytes(const fastkv_problem *p);
 
 /*
+ * Call ONCE per workspace allocation (256-B aligned, any size >= 8 KiB), before its first use by
+ * `fastkv_update_kv_f16` / `fastkv_score_f16`: the first 8 KiB of an operator workspace are a control block (magic word,
+ * call epoch, hand-off flags of the fused scoring kernel) that the library keeps consistent from then on, so no per-call
+ * memset is needed and graph replays are safe.  A workspace that was never initialised makes the scoring kernel trap
+ * (a loud HIP error at the next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
+ * The fused scoring kernel also needs all its workgroups resident at once: do not run two scoring calls concurrently on
+ * one GPU (set FASTKV_FUSED=0 to take the three-kernel path if you must).
+ */
+int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The whole operator: replaces the compress branch of FastKVCluster.update_kv (utils.py:93-132).
  *   q, k, v        fp16, logical [B,H,S,D] / [B,Hkv,S,D] with the given element strides
  *   k_out, v_out   fp16 [B,Hkv,capacity,D] contiguous: rows 0..capacity-window-1 are the selected
