@@ -96,6 +96,97 @@ __device__ __forceinline__ float fix_to_f32(uint64_t s)
     return bits_f32(((uint32_t)(exp2 - 40 + 127) << 23) | (mant & 0x7fffffu));
 }
 
+// ---- two elements per instruction: v_pk_mul/fma/add_f32 are IEEE per component, so every component below is bit-identical
+// to the scalar function above (same operations, same order); only rint / convert / select / integer steps stay scalar
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
+
+__device__ __forceinline__ f32x2 det_expf2(f32x2 d)
+{
+    const bool ok0 = d.x >= -87.0f, ok1 = d.y >= -87.0f;
+    f32x2 dc;
+    dc.x = ok0 ? (d.x > 0.0f ? 0.0f : d.x) : -1.0f;
+    dc.y = ok1 ? (d.y > 0.0f ? 0.0f : d.y) : -1.0f;
+    f32x2 n = dc * splat2(1.44269504088896341f);
+    n.x = __builtin_rintf(n.x);
+    n.y = __builtin_rintf(n.y);
+    f32x2 r = fma2(n, splat2(-0.693359375f), dc);
+    r = fma2(n, splat2(2.12194440e-4f), r);
+    f32x2 p = splat2(1.9875691500e-4f);
+    p = fma2(p, r, splat2(1.3981999507e-3f));
+    p = fma2(p, r, splat2(8.3334519073e-3f));
+    p = fma2(p, r, splat2(4.1665795894e-2f));
+    p = fma2(p, r, splat2(1.6666665459e-1f));
+    p = fma2(p, r, splat2(5.0000001201e-1f));
+    const f32x2 r2 = r * r;
+    p = fma2(p, r2, r);
+    p = p + splat2(1.0f);
+    f32x2 out;
+    out.x = bits_f32((uint32_t)((int32_t)f32_bits(p.x) + (int32_t)n.x * (1 << 23)));
+    out.y = bits_f32((uint32_t)((int32_t)f32_bits(p.y) + (int32_t)n.y * (1 << 23)));
+    if (!ok0) out.x = (d.x != d.x) ? d.x : 0.0f;
+    if (!ok1) out.y = (d.y != d.y) ? d.y : 0.0f;
+    return out;
+}
+
+// exp_to_fix of both components; NaN components must be excluded by the caller (as with exp_to_fix)
+__device__ __forceinline__ void exp_to_fix2(f32x2 e, uint32_t &hi0, uint32_t &lo0, uint32_t &hi1, uint32_t &lo1)
+{
+    const f32x2 a = e * splat2(65536.0f);
+    f32x2 hf;
+    hf.x = __builtin_truncf(a.x);
+    hf.y = __builtin_truncf(a.y);
+    const f32x2 rem = a - hf;
+    const f32x2 l = rem * splat2(16777216.0f);
+    hi0 = (uint32_t)hf.x; hi1 = (uint32_t)hf.y;
+    lo0 = (uint32_t)__builtin_rintf(l.x); lo1 = (uint32_t)__builtin_rintf(l.y);
+}
+
+// scale_div of both components
+__device__ __forceinline__ f32x2 scale_div2(f32x2 x, float c, float rc)
+{
+    const f32x2 q0 = x * splat2(rc);
+    const f32x2 r = fma2(-q0, splat2(c), x);
+    f32x2 q1 = fma2(r, splat2(rc), q0);
+    if (x.x == 0.0f || __builtin_isinf(x.x)) q1.x = q0.x;
+    if (x.y == 0.0f || __builtin_isinf(x.y)) q1.y = q0.y;
+    return q1;
+}
+
+// Reduction of 16 per-lane values over the 32 lanes of a half wave in 16 exchanges instead of 80: every step halves the
+// number of values a lane carries (it keeps the half selected by one bit of its lane id and sends the other half to the
+// partner).  Returns the fully reduced value of index halfwave_red_index(lane); lanes 2t and 2t+1 hold the same one.
+__device__ __forceinline__ int halfwave_red_index(int lane)
+{
+    return ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+template <typename T, typename Op> __device__ __forceinline__ T halfwave_reduce16(const T (&v)[16], int lane, Op op)
+{
+    T a[8], b[4], c[2], d;
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const T keep = up ? v[8 + i] : v[i], send = up ? v[i] : v[8 + i]; a[i] = op(keep, __shfl_xor(send, 16, 64)); }
+    }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const T keep = up ? a[4 + i] : a[i], send = up ? a[i] : a[4 + i]; b[i] = op(keep, __shfl_xor(send, 8, 64)); }
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const T keep = up ? b[2 + i] : b[i], send = up ? b[i] : b[2 + i]; c[i] = op(keep, __shfl_xor(send, 4, 64)); }
+    }
+    {
+        const bool up = (lane & 2) != 0;
+        const T keep = up ? c[1] : c[0], send = up ? c[0] : c[1];
+        d = op(keep, __shfl_xor(send, 2, 64));
+    }
+    return op(d, __shfl_xor(d, 1, 64));
+}
+
 #define FK_SUM_POISON 0xffffffffffffffffull   // a NaN was seen in the row (oracle: rinv = NaN)
 
 __device__ __forceinline__ float wave_max(float v)

@@ -157,8 +157,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rw = (i & 3) + 4 * hi;                                         // window row of query row m(i): m % W
-                uint16_t s0 = f2h(scale_div(h2f(f2h(acc0[i])), sqrtD, rsqrtD));          // utils.py:94 (matmul -> fp16, / sqrt(D) -> fp16)
-                uint16_t s1 = f2h(scale_div(h2f(f2h(acc1[i])), sqrtD, rsqrtD));
+                // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both columns of the pair in one packed sequence)
+                const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(acc1[i]))}, sqrtD, rsqrtD);
+                uint16_t s0 = f2h(sc.x), s1 = f2h(sc.y);
                 if (j0 >= n && (j0 - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));           // utils.py:95-101
                 if (j1 >= n && (j1 - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
                 if (j0 < S) mx[i] = fmaxf(mx[i], h2f(s0));
@@ -169,14 +170,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     FKF_STAMP(1);
     // row maxima: across the 32 lanes of a half wave, then across the 4 waves, then published
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o, 64));
-    }
-    if (n31 == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_f[w][(i & 3) + 8 * (i >> 2) + 4 * hi] = mx[i];
+    {
+        const float r = halfwave_reduce16(mx, lane, [](float a, float b) { return fmaxf(a, b); });
+        const int i = halfwave_red_index(lane);
+        if ((lane & 1) == 0) s_f[w][(i & 3) + 8 * (i >> 2) + 4 * hi] = r;
     }
     __syncthreads();
     uint32_t *flag1 = flags + (size_t)bg * nblk, *flag2 = flags + (size_t)(BG + bg) * nblk;
@@ -225,40 +222,35 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int key0 = (wave_id + t * nwaves) * 64;          // >= S when the wave has no tile t: nothing is counted
-        const int j0 = key0 + n31, j1 = j0 + 32;
+        const bool in0 = key0 + n31 < S, in1 = key0 + 32 + n31 < S;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float e0 = det_expf(h2f((uint16_t)(lg[t][i] & 0xffffu)) - gm[i]);
-            const float e1 = det_expf(h2f((uint16_t)(lg[t][i] >> 16)) - gm[i]);
-            ev[t][0][i] = e0;
-            ev[t][1][i] = e1;
-            if (j0 < S) {
-                if (e0 != e0) nanbits |= 1u << i;
-                else { uint32_t h2, l2; exp_to_fix(e0, h2, l2); ahi[i] += h2; alo[i] += l2; }
-            }
-            if (j1 < S) {
-                if (e1 != e1) nanbits |= 1u << i;
-                else { uint32_t h2, l2; exp_to_fix(e1, h2, l2); ahi[i] += h2; alo[i] += l2; }
-            }
+            const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
+            const f32x2 e = det_expf2(x - splat2(gm[i]));
+            ev[t][0][i] = e.x;
+            ev[t][1][i] = e.y;
+            uint32_t h0, l0, h1, l1;
+            exp_to_fix2(e, h0, l0, h1, l1);
+            const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
+            if ((in0 && nan0) || (in1 && nan1)) nanbits |= 1u << i;
+            ahi[i] += (in0 && !nan0 ? h0 : 0u) + (in1 && !nan1 ? h1 : 0u);
+            alo[i] += (in0 && !nan0 ? l0 : 0u) + (in1 && !nan1 ? l1 : 0u);
         }
     }
     FKF_STAMP(3);
     // per lane at most 2*PER <= 8 elements per row (hi <= 2^16, lo <= 2^24 each): the 32-bit lane sums are exact; they
     // are combined to the 2^-40 fixed-point value before the half-wave reduction
-    uint64_t tot[16];
+    {
+        uint64_t tot[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        tot[i] = ((uint64_t)ahi[i] << 24) + alo[i];
+        for (int i = 0; i < 16; ++i) tot[i] = ((uint64_t)ahi[i] << 24) + alo[i];
+        const uint64_t r = halfwave_reduce16(tot, lane, [](uint64_t a, uint64_t b) { return a + b; });
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) tot[i] += (uint64_t)__shfl_xor((long long)tot[i], o, 64);
-    }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) nanbits |= (uint32_t)__shfl_xor((int)nanbits, o, 64);
-    if (n31 == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int o = 16; o > 0; o >>= 1) nanbits |= (uint32_t)__shfl_xor((int)nanbits, o, 64);
+        const int i = halfwave_red_index(lane);
+        if ((lane & 1) == 0) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
-            s_u[w][m] = tot[i];
+            s_u[w][m] = r;
             s_bad[w][m] = (nanbits >> i) & 1u;
         }
     }
