@@ -371,7 +371,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     resident = p.D == 64 ? FK_RES(64) : p.D == 128 ? FK_RES(128) : FK_RES(256);
 #undef FK_RES
     if (!resident) return false;
-    ProfScope ps_(K_LOGITS, st);
+    ProfScope ps_(K_FUSED, st);
 #define FK_FUSED(DV, PV)                                                                                                         \
     hipLaunchKernelGGL((score_fused_kernel<DV, PV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],           \
                        (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, hs, hs_stride, pmax, psum, \

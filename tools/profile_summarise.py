@@ -44,18 +44,20 @@ def kib(counter, prefix):
     return hits[k]["median"]
 
 
-lf, lw = kib("FETCH_SIZE", "fk::score_logits"), kib("WRITE_SIZE", "fk::score_logits")
+fused = any(k.startswith("fk::score_fused") for k in pmc.get("FETCH_SIZE", {}))
+dom = "fk::score_fused" if fused else "fk::score_logits"
+lf, lw = kib("FETCH_SIZE", dom), kib("WRITE_SIZE", dom)
 cf, cw = kib("FETCH_SIZE", "fk::compact_kv"), kib("WRITE_SIZE", "fk::compact_kv")
 json.dump({
     "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
               "--no-extras`, medians over launches; counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide 16-B/lane "
               "reads, guides/MI355X_MICROARCH.md HBM section; the compact kernel calibrates it: 2*FETCH = its 8.39 MB of row reads)",
-    "score_logits_hbm_bytes_per_launch": int((2 * lf + lw) * 1024),
-    "score_logits_fetch_kib_raw": lf, "score_logits_write_kib": lw,
+    dom[4:] + "_hbm_bytes_per_launch": int((2 * lf + lw) * 1024),
+    dom[4:] + "_fetch_kib_raw": lf, dom[4:] + "_write_kib": lw,
     "compact_kv_hbm_bytes_per_launch": int((2 * cf + cw) * 1024),
     "compact_kv_fetch_kib_raw": cf, "compact_kv_write_kib": cw,
-    "note": "score_logits: 2*FETCH = K once + Q window (algorithmic 67.17 MB); the remaining 16.8 MB is the fp16 logits write "
-            "consumed by row_stats/score_finalize",
+    "note": "dominant kernel: 2*FETCH = K once + Q window (algorithmic 67.17 MB) + hand-off records; WRITE = the fp16 window-row "
+            "sums hs (score_fused) or the fp16 logits (score_logits)",
 }, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_fk_kernels_by_grid.csv")).read())
 print(open(os.path.join(P, "traffic.json")).read())
