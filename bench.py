@@ -135,9 +135,11 @@ def cpu_baseline(work: HotPathPrefill):
     for nt in sorted({min(ncpu, x) for x in (16, 32, 64, 128)}):
         O.set_threads(nt)
         O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
-        t0 = time.perf_counter()
-        O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
-        dt = time.perf_counter() - t0
+        dt = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
+            dt = min(dt, time.perf_counter() - t0)
         if dt < best[1]:
             best = (nt, dt)
     cores = best[0]
@@ -146,12 +148,19 @@ def cpu_baseline(work: HotPathPrefill):
     def cpu_layer(i):
         q, k, v = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[i])
         c = work.clusters[i]
-        oc = OracleFastKVCluster(c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.tsp_layer, c.tsp_length,
-                                 c.tsp_rate, c.retain_rate, c.eviction_mode)
-        oc.update_kv(k, q, v, None, G, i)                                    # warm-up (page-in, thread pool)
-        t0 = time.perf_counter()
-        out = oc.update_kv(k, q, v, None, G, i)
-        return time.perf_counter() - t0, out
+
+        def fresh():                                                         # update_kv may mutate the cluster (proportional mode)
+            return OracleFastKVCluster(c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.tsp_layer, c.tsp_length,
+                                       c.tsp_rate, c.retain_rate, c.eviction_mode)
+
+        fresh().update_kv(k, q, v, None, G, i)                               # warm-up (page-in, thread pool)
+        best_t, out = 1e9, None
+        for _ in range(3):                                                   # the host is shared: best of 3
+            oc = fresh()
+            t0 = time.perf_counter()
+            out = oc.update_kv(k, q, v, None, G, i)
+            best_t = min(best_t, time.perf_counter() - t0)
+        return best_t, out
 
     t_pre = [cpu_layer(i)[0] for i in (0, 1)]
     t_tsp, out = cpu_layer(CFG["tsp_idx"])
@@ -163,7 +172,7 @@ def cpu_baseline(work: HotPathPrefill):
     step_s = 15 * (sum(t_pre) / 2) + t_tsp + 16 * (sum(t_post) / 2) + t_g
     return {"value": round(CFG["S"] / step_s, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
             "ms_per_step": round(step_s * 1e3, 1),
-            "sample": "oracle update_kv: layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, 1 warm-up + 1 timed "
+            "sample": "oracle update_kv: layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, 1 warm-up + best of 3 timed "
                       f"each, scaled to 15+1+16 layers; OpenMP threads auto-picked from 16/32/64/128 on {ncpu} logical CPUs"}
 
 
