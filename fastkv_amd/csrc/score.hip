@@ -422,9 +422,11 @@ __device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool ac
 
 // ------------------------------------------------------------------------------------------ score_finalize
 // grid (tilesC, Hkv, B), 256 threads; thread t <-> position tile*TP - pad + t, TP = 256 - 2*pad outputs per block.
-// Reads the fp16 probabilities row_stats left in the logits buffer: sum over the W window rows -> fp16 (utils.py:104),
-// pool -> fp16 (utils.py:105-108), sum over the G heads of the group -> fp16 (utils.py:112).  The G*W values of a
-// position are fetched in batches of 32 independent loads before any arithmetic.
+// Reads `probs` (wr rows per query head: the W fp16 probability rows that row_stats left, or the single row of window-row
+// sums that the fused kernel left): sum over the window rows -> fp16 (utils.py:104), pool -> fp16 (utils.py:105-108),
+// sum over the G heads of the group -> fp16 (utils.py:112).  The values of a position are fetched in batches of up to 32
+// independent loads before any arithmetic; heads go through the LDS tile four at a time (one barrier per four heads).
+constexpr int FIN_HB = 4;
 __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__restrict__ probs, int H, int Hkv, ColWin cw, int W,
                                                              int wr, int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
                                                              int64_t c_row_stride, uint32_t *__restrict__ hist12,
@@ -436,7 +438,7 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
         const uint32_t e = *epoch_bump + 1u;
         *epoch_bump = e ? e : 1u;
     }
-    __shared__ float s_tile[2][256];
+    __shared__ float s_tile[2][FIN_HB][256];
     __shared__ uint32_t s_hist[HIST12];
     const int g = blockIdx.y, b = blockIdx.z;
     // wr = rows of `probs` per query head: W (probabilities, summed here) or 1 (the fused kernel already summed them)
@@ -447,7 +449,9 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
     const bool is_out = (t >= pad) && (t < pad + TP) && inrange && (j >= cw.own_lo) && (j < cw.own_hi);
     const size_t row0 = (size_t)(b * H + g * G) * wr;
     const uint16_t *lp = probs + row0 * Sp + (inrange ? j : 0);
-    if (hist12) for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
+    const bool want_hist = hist12 && !all_idx;
+    if (want_hist) for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
+    const float padv = pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY;            // padding, utils.py:106,108
     float gsum = 0.0f, a = 0.0f;
     int head = 0, rw = 0;
     for (int rb = 0; rb < R; rb += 32) {
@@ -461,26 +465,30 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
                 a = a + h2f(x[u]);                                  // sum over the window rows (utils.py:104)
                 if (++rw == wr) {                                   // last window row of head `head`
                     rw = 0;
-                    float sv = inrange ? h2f(f2h(a)) : (pooling == FASTKV_POOL_AVG ? 0.0f : -INFINITY);   // padding, utils.py:106,108
-                    float *st = s_tile[head & 1];
-                    st[t] = sv;
-                    __syncthreads();
-                    if (is_out) {
-                        float pv;
-                        if (pooling == FASTKV_POOL_AVG) {
-                            pv = 0.0f;
-                            for (int o = -pad; o <= pad; ++o) pv = pv + st[t + o];
-                            pv = pv / (float)ksize;
-                        } else {
-                            pv = -INFINITY;
-                            for (int o = -pad; o <= pad; ++o) { float xv = st[t + o]; if (xv > pv || xv != xv) pv = xv; }
-                        }
-                        gsum = gsum + h2f(f2h(pv));                 // sum over the heads of the group (utils.py:112)
-                    }
-                    // s_tile is double buffered: head+2 rewrites this half only after the barrier of head+1,
-                    // which every thread reaches after its reads above
+                    s_tile[(head / FIN_HB) & 1][head % FIN_HB][t] = inrange ? h2f(f2h(a)) : padv;
                     a = 0.0f;
                     ++head;
+                    if (head % FIN_HB == 0 || head == G) {          // a batch of heads is in the tile: pool them
+                        const int hb = (head - 1) / FIN_HB, nh = head - hb * FIN_HB;
+                        __syncthreads();
+                        if (is_out) {
+                            for (int hh = 0; hh < nh; ++hh) {
+                                const float *st = s_tile[hb & 1][hh];
+                                float pv;
+                                if (pooling == FASTKV_POOL_AVG) {
+                                    pv = 0.0f;
+                                    for (int o = -pad; o <= pad; ++o) pv = pv + st[t + o];
+                                    pv = pv / (float)ksize;
+                                } else {
+                                    pv = -INFINITY;
+                                    for (int o = -pad; o <= pad; ++o) { float xv = st[t + o]; if (xv > pv || xv != xv) pv = xv; }
+                                }
+                                gsum = gsum + h2f(f2h(pv));          // sum over the heads of the group (utils.py:112)
+                            }
+                        }
+                        // the tile is double buffered: batch hb+2 rewrites this half only after the barrier of batch hb+1,
+                        // which every thread reaches after its reads above
+                    }
                 }
             }
         }
@@ -499,8 +507,9 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
         return;
     }
     // high-12-bit key histogram of this row for the selection kernel: block-local first, then one global atomic per
-    // non-empty bin (integer atomics: the counts do not depend on arrival order)
-    if (!hist12) return;
+    // non-empty bin (integer atomics: the counts do not depend on arrival order).  (Letting the thread that opens a bin
+    // flush it -- no scan over the 4096 bins -- was measured slower: returning LDS atomics on the few hot bins serialise.)
+    if (!want_hist) return;
     hist12_add(s_hist, mono16(c16) >> 4, is_out, t & 63);
     __syncthreads();
     uint32_t *gh = hist12 + (size_t)(b * Hkv + g) * HIST12;
