@@ -155,8 +155,9 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     const bool select_all = (kk == L.n);
     uint32_t *arrive = reinterpret_cast<uint32_t *>(ws + L.off_arrive), *seltab = reinterpret_cast<uint32_t *>(ws + L.off_seltab);
     const size_t nchunks = ((size_t)L.n + 2047) / 2048;
+    uint32_t *epoch_bump = nullptr;                          // set when the fused score kernel ran: the compaction advances the epoch
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
-                                select_all ? keys : nullptr, kal);
+                                select_all ? keys : nullptr, kal, &epoch_bump);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
     if (scores_out) {
         e = hipMemcpy2DAsync(scores_out, (size_t)L.n * 2, c, (size_t)L.n_pad * 2, (size_t)L.n * 2, (size_t)p->B * p->Hkv,
@@ -174,7 +175,7 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
                           seltab + (size_t)p->B * p->Hkv * nchunks * 32, st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
-    e = launch_compact(*p, k, k_strides, v, v_strides, idx_asc, keys, by_score ? kv_idx_out : nullptr, k_out, v_out, st);
+    e = launch_compact(*p, k, k_strides, v, v_strides, idx_asc, keys, by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -26,8 +26,13 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
                                                          const int64_t *__restrict__ idx, const uint16_t *__restrict__ keys,
                                                          int64_t *__restrict__ idx_sorted, int Hkv, int S, int W, int cap,
                                                          int keys_in_lds, uint16_t *__restrict__ k_out,
-                                                         uint16_t *__restrict__ v_out)
+                                                         uint16_t *__restrict__ v_out, uint32_t *__restrict__ epoch_bump)
 {
+    // last kernel of the operator: advance the workspace epoch after a fused score launch (fused.hip)
+    if (epoch_bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const uint32_t e = *epoch_bump + 1u;
+        *epoch_bump = e ? e : 1u;
+    }
     constexpr int RPB = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) uint16_t s_keys[];   // winner keys for the ranking (dynamic: 0 B when unused)
     const int bg = blockIdx.y, b = bg / Hkv, g = bg % Hkv;
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
 
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
-                          hipStream_t st)
+                          hipStream_t st, uint32_t *epoch_bump)
 {
     const int lpr = p.D / 8;
     const int rows_per_block = 256 / lpr;
@@ -87,7 +92,7 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
 #define FK_COMPACT(LPRV)                                                                                                   \
     hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), dyn, st, (const uint16_t *)k, ks[0], ks[1], ks[2],       \
                        (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \
-                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out)
+                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out, epoch_bump)
     if (lpr == 8) FK_COMPACT(8);
     else if (lpr == 16) FK_COMPACT(16);
     else FK_COMPACT(32);

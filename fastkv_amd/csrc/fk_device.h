@@ -187,6 +187,59 @@ template <typename T, typename Op> __device__ __forceinline__ T halfwave_reduce1
     return op(d, __shfl_xor(d, 1, 64));
 }
 
+// pool1d over `ksize` taps centred on st[t] (utils.py:105-108): avg = sequential fp32 sum / ksize, max with NaN propagation.
+// The caller stores the padding value (0 for avg, -inf for max) at out-of-range positions.
+// The taps are read into registers first (KMAX independent LDS reads) and combined afterwards in tap order: a rolled
+// "read, add, read, add" loop is a chain of LDS round trips, which two waves per SIMD cannot hide (measured in the fused
+// score kernel: 5.4 us for 12 pools per thread).
+template <int KMAX> __device__ __forceinline__ float pool_taps_n(const float *st, int t, int pad, int ksize, bool avg)
+{
+    float v[KMAX];
+#pragma unroll
+    for (int o = 0; o < KMAX; ++o) v[o] = st[t - pad + (o < ksize ? o : ksize - 1)];
+    float pv;
+    if (avg) {
+        pv = 0.0f;
+#pragma unroll
+        for (int o = 0; o < KMAX; ++o) if (o < ksize) pv = pv + v[o];
+        pv = pv / (float)ksize;
+    } else {
+        pv = -INFINITY;
+#pragma unroll
+        for (int o = 0; o < KMAX; ++o) if (o < ksize && (v[o] > pv || v[o] != v[o])) pv = v[o];
+    }
+    return pv;
+}
+__device__ __forceinline__ float pool_taps(const float *st, int t, int pad, int ksize, bool avg)
+{
+    if (ksize <= 7) return pool_taps_n<7>(st, t, pad, ksize, avg);
+    if (ksize <= 15) return pool_taps_n<15>(st, t, pad, ksize, avg);
+    float pv;
+    if (avg) {
+        pv = 0.0f;
+        for (int o = -pad; o <= pad; ++o) pv = pv + st[t + o];
+        pv = pv / (float)ksize;
+    } else {
+        pv = -INFINITY;
+        for (int o = -pad; o <= pad; ++o) { const float xv = st[t + o]; if (xv > pv || xv != xv) pv = xv; }
+    }
+    return pv;
+}
+
+// one LDS histogram update per lane; the lanes that agree with lane 0 are folded into a single atomic
+__device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool active, int lane)
+{
+    const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
+    const uint64_t same = __ballot(active && bin == first);
+    if (active) {
+        if (bin == first) {
+            if (lane == __builtin_ctzll(same)) atomicAdd(&hist[first], (uint32_t)__builtin_popcountll(same));
+        } else {
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+}
+
 #define FK_SUM_POISON 0xffffffffffffffffull   // a NaN was seen in the row (oracle: rinv = NaN)
 
 __device__ __forceinline__ float wave_max(float v)

@@ -79,10 +79,11 @@ static inline Layout make_layout(const fastkv_problem &p)
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
                         char *ws, hipStream_t st, int64_t *all_idx = nullptr, uint16_t *all_keys = nullptr,
-                        int64_t all_key_stride = 0);
-// fused logits + softmax + window-row sum (fused.hip); false = shape not covered, take the three-kernel path
+                        int64_t all_key_stride = 0, uint32_t **epoch_bump_later = nullptr);
+// fused logits + softmax + window-row sum + pooling/head sum (fused.hip); false = shape not covered, take the three-kernel path
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
-                        const int64_t *ks, uint16_t *hs, int hs_stride, char *ws, hipStream_t st, hipError_t *err);
+                        const int64_t *ks, uint16_t *hs, int hs_stride, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx,
+                        uint16_t *all_keys, int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
 hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,
@@ -99,7 +100,7 @@ hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, c
 // idx_sorted_out (optional) receives the indices in that order
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
-                          hipStream_t st);
+                          hipStream_t st, uint32_t *epoch_bump = nullptr);
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
                               int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st);
 

@@ -56,7 +56,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
                                                              uint16_t *__restrict__ hs, int hs_stride, float *__restrict__ pmax,
                                                              uint64_t *__restrict__ psum, const uint32_t *__restrict__ ctrl,
-                                                             uint32_t *__restrict__ zero_area, int zero_words)
+                                                             uint32_t *__restrict__ zero_area, int zero_words, int ksize, int pooling,
+                                                             uint16_t *__restrict__ c_out, int64_t c_row_stride,
+                                                             int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
+                                                             int64_t all_key_stride)
 {
     constexpr int W = 8, G = 4, NPH = D / DH;
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
@@ -82,12 +85,19 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     const uint32_t token = ctrl[2] + 1u ? ctrl[2] + 1u : 1u;
     uint32_t *flags = const_cast<uint32_t *>(ctrl) + 16;
     FKF_STAMP(0);
-    // zero the key histograms / arrival counters that score_finalize, tsp_rowsum and the selection accumulate into
+    // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
+    // workgroups of bg: they zero it themselves with write-through stores that are drained before their first flag, so
+    // passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of the selection
+    // are touched by later kernels only.
+    uint32_t *hist_row = zero_area + (size_t)bg * HIST12;
+    for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
+        __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
+        const int first = BG * HIST12, rest = zero_words - first;
         const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-        const int per = (zero_words + nwg - 1) / nwg;
-        const int lo = wg * per, hi2 = min(lo + per, zero_words);
-        for (int i = lo + (int)threadIdx.x; i < hi2; i += 256) zero_area[i] = 0;
+        const int per = (rest + nwg - 1) / nwg;
+        const int lo = wg * per, hi2 = min(lo + per, rest);
+        for (int i = lo + (int)threadIdx.x; i < hi2; i += 256) zero_area[first + i] = 0;
     }
 
     // ---------------------------------------------------------------- A operand (see score_logits_mfma_kernel)
@@ -175,8 +185,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         const int i = halfwave_red_index(lane);
         if ((lane & 1) == 0) s_f[w][(i & 3) + 8 * (i >> 2) + 4 * hi] = r;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's histogram zeros have reached memory
     __syncthreads();
     uint32_t *flag1 = flags + (size_t)bg * nblk, *flag2 = flags + (size_t)(BG + bg) * nblk;
+    uint32_t *flag3 = flags + (size_t)(2 * BG + bg) * nblk;
     float *pm = pmax + (size_t)bg * nblk * 32;
     uint64_t *psu = psum + (size_t)bg * nblk * 32;
     if (w == 0) {
@@ -316,11 +328,86 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
                 float c = __shfl_xor(a, 32, 64);                 // upper half: the lower half's sum of rows 0-3
                 c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
-                if (hi && j < n) hs[(size_t)(b * H + g * G + i4) * hs_stride + j] = f2h(c);
+                if (hi && j < n)
+                    __hip_atomic_store(hs + (size_t)(b * H + g * G + i4) * hs_stride + j, f2h(c), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);                         // write-through: read by other workgroups below
             }
         }
     }
     FKF_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (w == 0) {
+        if (lane == 0) __hip_atomic_store(flag3 + blk, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_flags(flag3, nblk, token, lane);
+    }
+    __syncthreads();
+    FKF_STAMP(6);
+
+    // ---------------------------------------------------------------- phase D: pool, sum over the heads, scores + histogram
+    // (score_finalize of the three-kernel path, utils.py:105-112.)  This workgroup owns candidates [blk*CH, (blk+1)*CH);
+    // thread t of a pass <-> position p0 - pad + t, TP = 256 - 2*pad outputs per pass.  LDS: the K slabs are free now.
+    {
+        constexpr int PPT = 5, TW = 256 * PPT;                       // positions per thread and pass; [G][TW] floats + the histogram
+        static_assert(G * TW * sizeof(float) + HIST12 * sizeof(uint32_t) <= sizeof(slab), "phase D does not fit the K slabs");
+        float(*tile)[TW] = reinterpret_cast<float(*)[TW]>(&slab[0][0]);
+        uint32_t *s_hist = reinterpret_cast<uint32_t *>(&slab[0][0] + G * TW * sizeof(float));
+        const bool want_hist = all_idx == nullptr;
+        const int pad = ksize / 2, TP = TW - 2 * pad, t = threadIdx.x;
+        const int CH = (n + nblk - 1) / nblk, lo = blk * CH, hiC = min(n, lo + CH);
+        const bool avg = pooling == FASTKV_POOL_AVG;
+        const float padv = avg ? 0.0f : -INFINITY;
+        if (want_hist) for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
+        for (int p0 = lo; p0 < hiC; p0 += TP) {                      // one pass at the shapes this kernel takes (CH <= 1024)
+            const int need = min(TP, hiC - p0) + 2 * pad;            // tile columns in use
+            uint16_t x[PPT][G];
+#pragma unroll
+            for (int u = 0; u < PPT; ++u) {                          // all loads of the pass in flight together
+                const int tt = u * 256 + t, j = p0 - pad + tt;
+                const bool inr = tt < need && j >= 0 && j < n;
+#pragma unroll
+                for (int i4 = 0; i4 < G; ++i4)
+                    x[u][i4] = __hip_atomic_load(hs + (size_t)(b * H + g * G + i4) * hs_stride + (inr ? j : 0), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < PPT; ++u) {
+                const int tt = u * 256 + t, j = p0 - pad + tt;
+                const bool inr = tt < need && j >= 0 && j < n;
+#pragma unroll
+                for (int i4 = 0; i4 < G; ++i4) tile[i4][tt] = inr ? h2f(x[u][i4]) : padv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PPT; ++u) {
+                if (u * 256 >= need) break;
+                const int tt = u * 256 + t, j = p0 - pad + tt;
+                const bool is_out = tt >= pad && tt < need - pad && j < n;          // j >= p0 >= 0 here
+                float gsum = 0.0f;
+                if (is_out) {
+                    float pv[G];
+#pragma unroll
+                    for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], tt, pad, ksize, avg);
+#pragma unroll
+                    for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
+                }
+                const uint16_t c16 = f2h(gsum);
+                if (is_out) {
+                    c_out[(size_t)bg * c_row_stride + j] = c16;
+                    if (all_idx) {                           // capacity == S: identity selection + keys (see score_finalize)
+                        all_idx[(size_t)bg * n + j] = (int64_t)j;
+                        if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
+                    }
+                }
+                if (want_hist) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
+            }
+            __syncthreads();
+        }
+        if (all_keys && blk == 0 && t < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + t] = 0;
+        if (want_hist)
+            for (int i = t; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
+    }
+    FKF_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -345,7 +432,8 @@ template <int D, int PER> static bool fused_resident(int grid_wgs)
 // Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
 // covered and the caller must take the three-kernel path.
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
-                        const int64_t *ks, uint16_t *hs, int hs_stride, char *ws, hipStream_t st, hipError_t *err)
+                        const int64_t *ks, uint16_t *hs, int hs_stride, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx,
+                        uint16_t *all_keys, int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err)
 {
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
     if (disabled || L.engine != ENGINE_MFMA || L.R != 32 || p.window != 8 || p.H / p.Hkv != 4) return false;
@@ -375,7 +463,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 #define FK_FUSED(DV, PV)                                                                                                         \
     hipLaunchKernelGGL((score_fused_kernel<DV, PV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],           \
                        (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, hs, hs_stride, pmax, psum, \
-                       ctrl, zero, L.zero_words)
+                       ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride)
 #define FK_FUSED_D(DV)                                                                             \
     do {                                                                                           \
         if (PERT == 1) FK_FUSED(DV, 1); else if (PERT == 2) FK_FUSED(DV, 2); else FK_FUSED(DV, 4);  \

@@ -406,20 +406,6 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
     }
 }
 
-// one LDS histogram update per lane; the lanes that agree with lane 0 are folded into a single atomic
-__device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool active, int lane)
-{
-    const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
-    const uint64_t same = __ballot(active && bin == first);
-    if (active) {
-        if (bin == first) {
-            if (lane == __builtin_ctzll(same)) atomicAdd(&hist[first], (uint32_t)__builtin_popcountll(same));
-        } else {
-            atomicAdd(&hist[bin], 1u);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ score_finalize
 // grid (tilesC, Hkv, B), 256 threads; thread t <-> position tile*TP - pad + t, TP = 256 - 2*pad outputs per block.
 // Reads `probs` (wr rows per query head: the W fp16 probability rows that row_stats left, or the single row of window-row
@@ -431,13 +417,8 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
                                                              int wr, int Sp, int ksize, int pooling, uint16_t *__restrict__ c_out,
                                                              int64_t c_row_stride, uint32_t *__restrict__ hist12,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
-                                                             int64_t all_key_stride, uint32_t *__restrict__ epoch_bump)
+                                                             int64_t all_key_stride)
 {
-    // after a fused score launch: advance the workspace epoch (fused.hip; the next launch's hand-off token)
-    if (epoch_bump && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-        const uint32_t e = *epoch_bump + 1u;
-        *epoch_bump = e ? e : 1u;
-    }
     __shared__ float s_tile[2][FIN_HB][256];
     __shared__ uint32_t s_hist[HIST12];
     const int g = blockIdx.y, b = blockIdx.z;
@@ -473,16 +454,7 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
                         __syncthreads();
                         if (is_out) {
                             for (int hh = 0; hh < nh; ++hh) {
-                                const float *st = s_tile[hb & 1][hh];
-                                float pv;
-                                if (pooling == FASTKV_POOL_AVG) {
-                                    pv = 0.0f;
-                                    for (int o = -pad; o <= pad; ++o) pv = pv + st[t + o];
-                                    pv = pv / (float)ksize;
-                                } else {
-                                    pv = -INFINITY;
-                                    for (int o = -pad; o <= pad; ++o) { float xv = st[t + o]; if (xv > pv || xv != xv) pv = xv; }
-                                }
+                                const float pv = pool_taps(s_tile[hb & 1][hh], t, pad, ksize, pooling == FASTKV_POOL_AVG);
                                 gsum = gsum + h2f(f2h(pv));          // sum over the heads of the group (utils.py:112)
                             }
                         }
@@ -593,9 +565,18 @@ static hipError_t launch_logits(const fastkv_problem &p, const Layout &L, const 
     return hipGetLastError();
 }
 
+// After a fused score launch the workspace epoch must advance before the next one (fused.hip: the hand-off token).  In the
+// whole operator the compaction kernel does it; the stand-alone scoring entry point launches this single thread.
+__global__ void epoch_bump_kernel(uint32_t *epoch)
+{
+    const uint32_t e = *epoch + 1u;
+    *epoch = e ? e : 1u;
+}
+
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
-                        char *ws, hipStream_t st, int64_t *all_idx, uint16_t *all_keys, int64_t all_key_stride)
+                        char *ws, hipStream_t st, int64_t *all_idx, uint16_t *all_keys, int64_t all_key_stride,
+                        uint32_t **epoch_bump_later)
 {
     float *qf = reinterpret_cast<float *>(ws + L.off_qf);
     uint16_t *logits = reinterpret_cast<uint16_t *>(ws + L.off_logits);
@@ -607,34 +588,42 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     const ColWin cw = {p.S, 0, 0, p.S, p.S};
     hipError_t e;
 
-    int wr = p.window;
-    if (launch_score_fused(p, L, q, qs, k, ks, logits, L.Sp, ws, st, &e)) {
+    if (epoch_bump_later) *epoch_bump_later = nullptr;
+    // one launch for the common geometry (the `logits` area then holds the window-row sums hs[b,h,:]) ...
+    const bool fused = launch_score_fused(p, L, q, qs, k, ks, logits, L.Sp, c_out, c_row_stride, all_idx, all_keys, all_key_stride,
+                                          ws, st, &e);
+    if (fused) {
         if (e != hipSuccess) return e;
-        wr = 1;                                                  // `logits` now holds hs[b,h,:] (window rows already summed)
     } else {
+        // ... or logits -> row statistics / probabilities -> window-row sum + pooling + head sum
         if ((e = launch_logits(p, L, q, qs, p.S - p.window, k, ks, qf, logits, L.Sp, 0, st)) != hipSuccess) return e;
-        ProfScope ps_(K_ROWSTATS, st);
-        if (p.S <= 8192)
-            hipLaunchKernelGGL(row_stats_kernel<256>, dim3(p.B * p.H * p.window), dim3(256), 0, st, logits, cw, p.window, L.Sp, sqrtD,
-                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, L.zero_words);
-        else
-            hipLaunchKernelGGL(row_stats_kernel<1024>, dim3(p.B * p.H * p.window), dim3(1024), 0, st, logits, cw, p.window, L.Sp, sqrtD,
-                               rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, L.zero_words);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    {
+        {
+            ProfScope ps_(K_ROWSTATS, st);
+            if (p.S <= 8192)
+                hipLaunchKernelGGL(row_stats_kernel<256>, dim3(p.B * p.H * p.window), dim3(256), 0, st, logits, cw, p.window, L.Sp,
+                                   sqrtD, rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, L.zero_words);
+            else
+                hipLaunchKernelGGL(row_stats_kernel<1024>, dim3(p.B * p.H * p.window), dim3(1024), 0, st, logits, cw, p.window, L.Sp,
+                                   sqrtD, rsqrtD, 0, gmax, rinv, (uint64_t *)nullptr, hist, L.zero_words);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         ProfScope ps_(K_FINALIZE, st);
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((L.n + TP - 1) / TP, p.Hkv, p.B);
-        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, wr, L.Sp, p.kernel,
-                           p.pooling, c_out, c_row_stride, hist, all_idx, all_keys, all_key_stride,
-                           wr == 1 ? reinterpret_cast<uint32_t *>(ws) + 2 : (uint32_t *)nullptr);
+        hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, p.window, L.Sp, p.kernel,
+                           p.pooling, c_out, c_row_stride, hist, all_idx, all_keys, all_key_stride);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
         ProfScope ps_(K_TSP_ROWSUM, st);
         hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((L.n + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, L.n, t_out,
                            t_row_stride, hist + (size_t)p.B * p.Hkv * HIST12);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (fused) {
+        uint32_t *epoch = reinterpret_cast<uint32_t *>(ws) + 2;
+        if (epoch_bump_later) *epoch_bump_later = epoch;
+        else hipLaunchKernelGGL(epoch_bump_kernel, dim3(1), dim3(1), 0, st, epoch);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -681,8 +670,7 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
         const int pad = p.kernel / 2, TP = 256 - 2 * pad;
         dim3 gridC((n_own + TP - 1) / TP, p.Hkv, p.B);
         hipLaunchKernelGGL(score_finalize_kernel, gridC, dim3(256), 0, st, logits, p.H, p.Hkv, cw, p.window, p.window, w.Sp, p.kernel,
-                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, (int64_t)0,
-                           (uint32_t *)nullptr);
+                           p.pooling, c_out, c_row_stride, (uint32_t *)nullptr, (int64_t *)nullptr, (uint16_t *)nullptr, (int64_t)0);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (t_out) {
