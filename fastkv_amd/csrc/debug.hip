@@ -20,6 +20,17 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
     case 6: r = x * y; break;
     case 7: r = x + y; break;
     case 8: r = scale_div(x, y, 1.0f / y); break;
+    // packed twins (v_pk_*_f32): element i is paired with its neighbour i^1 so that both components are exercised
+    case 9: { const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i]; const f32x2 e = det_expf2((i & 1) ? (f32x2){x2, x} : (f32x2){x, x2}); r = (i & 1) ? e.y : e.x; break; }
+    case 10: {
+        const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i];
+        uint32_t h0, l0, h1, l1;
+        exp_to_fix2((i & 1) ? (f32x2){x2, x} : (f32x2){x, x2}, h0, l0, h1, l1);
+        r64 = (i & 1) ? ((uint64_t)h1 << 24) + l1 : ((uint64_t)h0 << 24) + l0;
+        r = fix_to_f32(r64);
+        break;
+    }
+    case 11: { const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i]; const f32x2 e = scale_div2((i & 1) ? (f32x2){x2, x} : (f32x2){x, x2}, y, 1.0f / y); r = (i & 1) ? e.y : e.x; break; }
     }
     out[i] = r;
     if (out64) out64[i] = r64;
@@ -28,7 +39,7 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
 
 extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream)
 {
-    if (!a || !out || n < 0 || op < 0 || op > 8) return FASTKV_EINVAL;
+    if (!a || !out || n < 0 || op < 0 || op > 11) return FASTKV_EINVAL;
     hipLaunchKernelGGL(fk::debug_contract_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, out64, n);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }

@@ -229,12 +229,16 @@ def test_arithmetic_contract_on_gpu(dev):
     g, _ = run(0, d)
     want = torch.tensor([Lo.fastkv_oracle_det_expf(float(x)) for x in d.tolist()])
     assert torch.equal(bits(g), bits(want))
+    g2, _ = run(9, d)                                                     # the two-per-instruction twin (v_pk_fma_f32)
+    assert torch.equal(bits(g2), bits(want))
     # logit scaling: scale_div == IEEE division for EVERY fp16 value, D = 64 / 128 / 256
     allh = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.float16).float()
     allh = allh[~torch.isnan(allh)]
     for D in (64, 128, 256):
         c = torch.full_like(allh, float(torch.tensor(math.sqrt(D), dtype=torch.float32)))
         g, _ = run(8, allh, c)
+        assert torch.equal(bits(g), bits(allh / c)), D
+        g, _ = run(11, allh, c)
         assert torch.equal(bits(g), bits(allh / c)), D
     # IEEE division / reciprocal as used for 1/sum and /kernel_size
     y = torch.rand(200000, generator=gen) * 4000 + 1e-3
@@ -253,6 +257,7 @@ def test_arithmetic_contract_on_gpu(dev):
     assert torch.equal(g64, w64)
     wf = torch.tensor([Lo.fastkv_oracle_fix_to_f32(int(v)) for v in w64.tolist()])
     assert torch.equal(bits(g), bits(wf))
+    assert torch.equal(run(10, e)[1], w64)
     big = torch.randint(0, 2 ** 62, (50000,), generator=gen, dtype=torch.int64)
     hi, lo = (big >> 32).to(torch.int32).view(torch.float32), (big & 0xFFFFFFFF).to(torch.int64).to(torch.int32).view(torch.float32)
     # NaN bit patterns survive the device copy, so op 5 sees exactly `big`
@@ -286,3 +291,52 @@ def test_large_and_unusual_shapes_bit_exact(shape, dev):
     assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])       # compacted K / V
     if s["tsp_len"]:
         assert torch.equal(got[2].cpu(), want[3])
+
+
+def _child(code, env_extra):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_three_kernel_path_is_bit_exact_too(dev):
+    """FASTKV_FUSED=0 (read once per process) takes score_logits + row_stats + score_finalize instead of the fused kernel:
+    same bits.  A child process runs the oracle comparison of this file on three cases."""
+    r = _child("import sys, pytest; sys.exit(pytest.main(['tests/test_hip_parity.py', '-q', '-x', '-m', 'gpu', '-k', "
+               "'bit_exact_vs_oracle and (tiny_avg or cfg1 or cfg2_max)']))", {"FASTKV_FUSED": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_uninitialised_workspace_fails_loudly(dev):
+    """include/fastkv_hip.h: a workspace that never saw fastkv_workspace_init makes the scoring kernel trap (the child
+    process dies with a HIP error); with the call the same code returns the oracle's result."""
+    code = """
+import ctypes, sys, torch
+sys.path.insert(0, 'tests')
+from gen_inputs import make_qkv
+from fastkv_amd._lib import Problem, load
+L = load(); dev = torch.device('cuda:0')
+q, k, v = make_qkv(3, 1, 32, 8, 4096, 128, 8)
+qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
+p = Problem(B=1, H=32, Hkv=8, S=4096, D=128, window=8, kernel=7, pooling=1, capacity=512, tsp_len=0, order=1, reserved=0)
+ws = torch.full((L.fastkv_workspace_bytes(ctypes.byref(p)),), 0xAB, dtype=torch.uint8, device=dev)
+if INIT:
+    assert L.fastkv_workspace_init(ws.data_ptr(), ws.numel(), None) == 0
+ko = torch.empty(1, 8, 512, 128, dtype=torch.float16, device=dev); vo = torch.empty_like(ko)
+S4 = ctypes.c_int64 * 4
+rc = L.fastkv_update_kv_f16(ctypes.byref(p), qd.data_ptr(), S4(*qd.stride()), kd.data_ptr(), S4(*kd.stride()), vd.data_ptr(),
+                            S4(*vd.stride()), ko.data_ptr(), vo.data_ptr(), None, None, None, ws.data_ptr(), ws.numel(), None)
+assert rc == 0
+torch.cuda.synchronize()
+from oracle import fastkv_oracle as O
+want = O.update_kv(q, k, v, 8, 7, 'maxpool', 512, 0, 'score')
+assert torch.equal(ko.cpu(), want[0]) and torch.equal(vo.cpu(), want[1])
+print('child ok')
+"""
+    good = _child("INIT = True\n" + code, {})
+    assert good.returncode == 0 and "child ok" in good.stdout, good.stdout[-1500:] + good.stderr[-1500:]
+    bad = _child("INIT = False\n" + code, {})
+    assert bad.returncode != 0 and "child ok" not in bad.stdout
