@@ -192,6 +192,13 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
+int fastkv_head_sum_f16(const void *c, int64_t B, int64_t R, int64_t n, void *t_out, void *stream)
+{
+    if (!c || !t_out || B < 0 || R < 1 || n < 0 || R > (1 << 20) || n >= (1ll << 31)) return FASTKV_EINVAL;
+    hipError_t e = launch_head_sum((const uint16_t *)c, B, R, n, (uint16_t *)t_out, (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
 // ---- sequence-sharded stages -------------------------------------------------------------------------------
 static size_t sp_qf_bytes(const fastkv_problem *p)
 {

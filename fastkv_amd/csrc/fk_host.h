@@ -84,6 +84,7 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *hs, int hs_stride, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx,
                         uint16_t *all_keys, int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
+hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
 hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,

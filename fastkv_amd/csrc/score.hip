@@ -629,6 +629,15 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     return hipSuccess;
 }
 
+hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st)
+{
+    if (B == 0 || n == 0) return hipSuccess;
+    ProfScope ps_(K_TSP_ROWSUM, st);
+    hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, st, c, n, (int)R, (int)n, t_out,
+                       n, (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ sequence-sharded stages
 // (fastkv_amd/dist.py; include/fastkv_hip.h "fastkv_sp_*").  `p` describes the rank-local call: p.S = keys in `k`.
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,

@@ -1,4 +1,5 @@
-"""Sequence-sharded FastKV hot path: ONE prompt split over P ranks on the sequence axis (BASELINE.json configs[2]).
+"""Sharded FastKV hot path.  sp_update_kv: ONE prompt split over P ranks on the sequence axis (BASELINE.json configs[2]).
+tp_update_kv (end of file): the KV heads split over P ranks (tensor parallel, configs[4]).
 
 The reference has no distributed code; the contract here is "same result as one GPU, bit for bit".
 That is possible because the arithmetic contract makes every global quantity exact:
@@ -235,3 +236,48 @@ def sp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_sta
         _all_reduce(both.view(torch.int32), dist.ReduceOp.SUM, group)
         k_out, v_out = both[0], both[1]
     return k_out, v_out, tsp_idx, kv_idx
+
+
+# ------------------------------------------------------------------------------------------------- tensor parallel
+class HipTPOps:
+    """Rank-local stages of tp_update_kv on the MI355X (the whole operator on the local heads + the head sum)."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def update_kv_local(self, q, k, v, window, kernel_size, pooling, capacity, order):
+        ko, vo, _, kv_idx, c = self.ops.update_kv(q, k, v, window, kernel_size, pooling, capacity, 0, order, return_indices=True,
+                                                   return_scores=True)
+        return ko, vo, kv_idx, c
+
+    def head_sum(self, c_all):
+        return self.ops.head_sum(c_all)
+
+    def select_tsp(self, t, k, window):
+        return self.ops.select(t, k, "index", append=window)
+
+
+def tp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_states: torch.Tensor, *, window_size: int,
+                 kernel_size: int, pooling: str, capacity: int, tsp_len: int = 0, order: str = "score", group=None,
+                 local_ops=None):
+    """Head-sharded (tensor-parallel) compress branch of FastKVCluster.update_kv (utils.py:93-132), e.g. Llama-3-70B over
+    8 ranks: rank r holds KV heads [r*Hkv/P, (r+1)*Hkv/P) and their query heads, the whole sequence.
+
+    Scoring, per-KV-head top-k and the K/V gather are local to the heads; only the TSP selection sums
+    over ALL KV heads (utils.py:127).  ONE all-gather of the ranks' fp16 score rows [B,Hkv_local,n] (64 KiB per head at
+    32k), then every rank adds the P*Hkv_local rows in head order (fp32 accumulate, one rounding: what the reference's
+    `sum(dim=-2)` does) and runs the same canonical selection, so tsp_idx is identical on every rank and equal to the
+    single-GPU result bit for bit.  Returns (k_out, v_out, tsp_idx | None, kv_idx) for the local heads."""
+    lo = local_ops or HipTPOps()
+    B, Hkv_l, S, D = key_states.shape
+    W = window_size
+    assert W < capacity <= S and (tsp_len == 0 or W < tsp_len < S)
+    ko, vo, kv_idx, c = lo.update_kv_local(query_states, key_states, value_states, W, kernel_size, pooling, capacity, order)
+    tsp = None
+    if tsp_len:
+        parts = _all_gather(c.contiguous(), group)                       # [B,Hkv_l,n] per rank, rank order = head order
+        c_all = torch.cat(parts, dim=1).contiguous()                     # [B,Hkv,n]
+        t = lo.head_sum(c_all)
+        tsp = lo.select_tsp(t, tsp_len - W, W)
+    return ko, vo, tsp, kv_idx

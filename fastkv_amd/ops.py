@@ -144,6 +144,15 @@ def select(scores2d: torch.Tensor, k: int, order: str = "index", append: int = 0
     return out
 
 
+def head_sum(c: torch.Tensor) -> torch.Tensor:
+    """t[b,j] = fp16(sum_r c[b,r,j]) for a contiguous fp16 [B,R,n] tensor (utils.py:127)."""
+    _require_cuda(c)
+    assert c.dim() == 3 and c.dtype == torch.float16 and c.is_contiguous()
+    t = torch.empty(c.shape[0], c.shape[2], dtype=torch.float16, device=c.device)
+    check(load().fastkv_head_sum_f16(c.data_ptr(), c.shape[0], c.shape[1], c.shape[2], t.data_ptr(), _stream()), "head_sum")
+    return t
+
+
 def compact(k: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, window: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """K/V gather + window append (utils.py:114-121) for given per-head indices [B,Hkv,cap-W] int64."""
     _check_qkv(k, k, v)

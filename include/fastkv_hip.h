@@ -139,6 +139,14 @@ typedef struct fastkv_sp_window {
     int32_t ncols, pos0, own_lo, own_hi, S_glob, Sp;
 } fastkv_sp_window;
 
+/*
+ * Head sum of score rows (utils.py:127: `attn_cache.sum(dim=-2)`): t[b,j] = fp16( sum_r c[b,r,j] ), fp32 accumulation in
+ * ascending r.  `c` is fp16 [B,R,n] contiguous.  The whole operator does this itself for the KV heads it holds; a
+ * tensor-parallel caller (one rank = a slice of the KV heads) all-gathers the ranks' score rows and sums them here
+ * (fastkv_amd/dist.py: tp_update_kv), then selects with fastkv_select_f16(append = window).
+ */
+int fastkv_head_sum_f16(const void *c, int64_t B, int64_t R, int64_t n, void *t_out, void *stream);
+
 /* scratch for the calls below: fp32 query block (vector-ALU engine) + B*H*window floats */
 size_t fastkv_sp_workspace_bytes(const fastkv_problem *p);
 /* raw fp16 logits of the p->S keys in `k` against the window queries q_win [B,H,window,D] (utils.py:94 matmul),

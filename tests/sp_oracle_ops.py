@@ -66,3 +66,19 @@ class OracleLocalOps:
         ko = torch.cat([torch.gather(k, 2, sel), k[:, :, S - window:]], dim=2)
         vo = torch.cat([torch.gather(v, 2, sel), v[:, :, S - window:]], dim=2)
         return ko.contiguous(), vo.contiguous()
+
+
+class OracleTPOps:
+    """Oracle-backed stand-in for fastkv_amd.dist.HipTPOps (CPU tests of tp_update_kv)."""
+
+    def update_kv_local(self, q, k, v, window, kernel_size, pooling, capacity, order):
+        ko, vo, idx, _, c, _ = O.update_kv(q, k, v, window, kernel_size, pooling, capacity, 0, order, return_scores=True)
+        return ko, vo, idx, c
+
+    def head_sum(self, c_all):
+        return c_all.float().sum(dim=1).to(torch.float16)               # <= 2^20 addends of 11-bit values: fp32 exact for these sizes
+
+    def select_tsp(self, t, k, window):
+        n = t.shape[1]
+        rows = [torch.cat([O.canonical_topk(t[b].contiguous(), k, "index"), torch.arange(n, n + window)]) for b in range(t.shape[0])]
+        return torch.stack(rows)

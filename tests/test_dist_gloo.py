@@ -74,3 +74,51 @@ def test_sequence_sharded_matches_single_process_oracle(case, lens):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] is True for r in res), res
+
+
+def _tp_worker(rank, world, port, case, q_out):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastkv_amd.dist import tp_update_kv
+        from gen_inputs import make_qkv
+        from oracle import fastkv_oracle as O
+        from sp_oracle_ops import OracleTPOps
+        O.set_threads(2)
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+        hl, G = case["Hkv"] // world, case["H"] // case["Hkv"]
+        ks, qs = slice(rank * hl, (rank + 1) * hl), slice(rank * hl * G, (rank + 1) * hl * G)
+        out = tp_update_kv(k[:, ks], q[:, qs], v[:, ks], window_size=case["W"], kernel_size=case["ks"], pooling=case["pooling"],
+                           capacity=case["cap"], tsp_len=case["tsp_len"], order=case["order"], local_ops=OracleTPOps())
+        want = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], case["order"])
+        ok = torch.equal(out[0], want[0][:, ks]) and torch.equal(out[1], want[1][:, ks]) and torch.equal(out[3], want[2][:, ks])
+        ok = ok and ((out[2] is None and want[3] is None) or torch.equal(out[2], want[3]))
+        q_out.put((rank, bool(ok)))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q_out.put((rank, "EXC " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [
+    (dict(seed=51, B=1, H=8, Hkv=2, S=600, D=128, W=8, ks=7, pooling="maxpool", cap=96, tsp_len=200, order="score"), 2),
+    (dict(seed=52, B=2, H=12, Hkv=3, S=400, D=64, W=8, ks=5, pooling="avgpool", cap=64, tsp_len=0, order="index"), 3),
+])
+def test_head_sharded_matches_single_process_oracle(case, world):
+    """Tensor-parallel operator (one slice of the KV heads per rank): local K/V and indices equal the single-process
+    oracle's slices; the TSP index (sum over ALL heads) is identical on every rank and equal to the oracle's."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, world, port, case, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] is True for r in res), res

@@ -72,3 +72,49 @@ def test_two_ranks_on_one_gpu_match_fused_operator(case, lens):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] is True for r in res), res
+
+
+def _tp_worker(rank, world, port, case, q_out):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastkv_amd import ops
+        from fastkv_amd.dist import tp_update_kv
+        from gen_inputs import make_qkv
+        dev = torch.device("cuda:0")
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+        qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
+        hl, G = case["Hkv"] // world, case["H"] // case["Hkv"]
+        ks, qs = slice(rank * hl, (rank + 1) * hl), slice(rank * hl * G, (rank + 1) * hl * G)
+        out = tp_update_kv(kd[:, ks], qd[:, qs], vd[:, ks], window_size=case["W"], kernel_size=case["ks"], pooling=case["pooling"],
+                           capacity=case["cap"], tsp_len=case["tsp_len"], order=case["order"])
+        want = ops.update_kv(qd, kd, vd, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], case["order"],
+                             return_indices=True)
+        torch.cuda.synchronize()
+        ok = torch.equal(out[0], want[0][:, ks]) and torch.equal(out[1], want[1][:, ks]) and torch.equal(out[3], want[3][:, ks])
+        ok = ok and ((out[2] is None and want[2] is None) or torch.equal(out[2], want[2]))
+        q_out.put((rank, bool(ok)))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q_out.put((rank, "EXC " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_sharded_on_gpu_matches_whole_operator():
+    """tp_update_kv (KV heads split over 2 ranks that share the test GPU; the score-row all-gather is staged through the
+    host): local K/V/indices equal the whole operator's head slices, tsp_idx equals its TSP index."""
+    case = dict(seed=61, B=1, H=32, Hkv=8, S=4096, D=128, W=8, ks=7, pooling="maxpool", cap=512, tsp_len=2048, order="score")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, case, q_out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] is True for r in res), res
