@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seq-sharded", action="store_true", help="N>1: also time ONE prompt of N*32k tokens sharded on the sequence "
+                                                                "axis (fastkv_amd.dist.sp_update_kv) and add it as `seq_sharded`")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented replay / roofline-shape / CPU legs")
     ap.add_argument("--no-ttft", action="store_true", help="skip the whole-model TTFT leg (random-init Llama-3-8B, fastkv vs fullkv)")
     a = ap.parse_args()
@@ -315,8 +317,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(work)
             if world == 1 and not a.no_ttft:
                 out["ttft"] = whole_model_ttft(work)
-    if dist is not None and not a.no_extras:
-        # The path with a real exchange step: ONE prompt of world*32768 tokens sharded on the sequence axis (rank r holds
+    if dist is not None and a.seq_sharded:
+        # (opt-in: `--seq-sharded`; the RCCL path of this leg has only been exercised with gloo so far, and a rank that fails
+        # inside a collective would take the contract line down with it.)  The path with a real exchange step: ONE prompt of world*32768 tokens sharded on the sequence axis (rank r holds
         # positions [r*S, (r+1)*S)), pre-TSP layers only (after TSP the 2048 surviving tokens fit one GPU).  Per layer:
         # window-query/K-halo all-gather, MAX and fixed-point SUM all-reduces, the candidate (index) all-gather, and the
         # all-reduce that replicates the compacted K/V rows.  Results are bit-identical to one GPU (tests/test_dist_*).
