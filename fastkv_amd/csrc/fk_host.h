@@ -64,7 +64,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
     L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
-    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * 32 * 12, 256);        // fused score: row max / row sum records
+    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 12 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum records, halo granules
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {
@@ -82,8 +82,8 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
                         int64_t all_key_stride = 0, uint32_t **epoch_bump_later = nullptr);
 // fused logits + softmax + window-row sum + pooling/head sum (fused.hip); false = shape not covered, take the three-kernel path
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
-                        const int64_t *ks, uint16_t *hs, int hs_stride, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx,
-                        uint16_t *all_keys, int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
+                        const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
+                        int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
 hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);

@@ -1,20 +1,23 @@
 // Fused window scoring for the common geometry (G*W == 32 query rows per KV head, W == 8, rows short enough that a wave
-// keeps the logits of all its tiles in registers): ONE launch replaces score_logits + row_stats and the window-row sum of
-// score_finalize (/root/reference/baselines/fastkv/utils.py:93-104).  The 16 MiB of logits of the 32k shape never leave
-// the registers; what reaches memory is hs[b,h,j] = fp16(sum over the W window rows of the fp16 probabilities), 2 MiB,
-// which score_finalize then pools and sums over the heads of the group (utils.py:105-112).
+// keeps the logits of all its tiles in registers): ONE launch replaces score_logits + row_stats + score_finalize
+// (/root/reference/baselines/fastkv/utils.py:93-112).  The 16 MiB of logits of the 32k shape never leave the registers
+// and the window-row sums never leave LDS; what reaches memory is the score tensor c[b,g,j] (0.5 MiB) and its histogram.
 //
-// Same arithmetic, operation for operation, as the unfused kernels (and as oracle/fastkv_oracle.c): fp32 fma chain
-// on the matrix pipe -> fp16 -> true division by sqrt(D) -> fp16 -> window mask -> row max -> det_expf -> 2^-40
-// fixed-point sum -> p = fp16(e * (1/sum)) -> sequential fp32 sum over the window rows -> fp16.
+// Same arithmetic, operation for operation, as the staged kernels (and as oracle/fastkv_oracle.c): fp32 fma chain on
+// the matrix pipe -> fp16 -> true division by sqrt(D) -> fp16 -> window mask -> row max -> det_expf -> 2^-40 fixed-point
+// sum -> p = fp16(e * (1/sum)) -> sequential fp32 sum over the window rows -> fp16 -> pool -> fp16 -> head sum -> fp16.
 //
-// The softmax needs two chip-wide reductions per query row (max, then sum).  All workgroups of the launch are resident
-// at once (the host takes this path only when grid <= 2 workgroups per CU and the occupancy query agrees), so the
-// reductions are in-kernel hand-offs instead of kernel boundaries:
-//   every workgroup publishes its 32 partial row maxima / sums as plain per-workgroup records and then a flag word
-//   carrying the launch TOKEN (a process-wide counter, so a flag left behind by an earlier launch or by uninitialised
-//   memory never matches); consumers poll the flags of the nblk workgroups of their (batch, kv head) and then read the
-//   records.  No atomics on shared words, nothing to zero beforehand, order-free integer / max combination.
+// A workgroup owns 4*PER consecutive 64-key tiles of one (batch, kv head).  The softmax needs two reductions over ALL
+// workgroups of the head (row max, then row sum) and the pooling needs `kernel/2` neighbouring positions from the two
+// adjacent workgroups.  All workgroups of the launch are resident at once (the host takes this path only when
+// grid <= 2 workgroups per CU and the occupancy query agrees), so these are in-kernel hand-offs, not kernel boundaries:
+//   * max / sum: every workgroup publishes its 32 partial values as a write-through record, drains the stores, then
+//     writes a flag word = the launch TOKEN; one wave polls the flags of the head's workgroups and everybody reads the
+//     records with sc1 loads.  No fences, no atomics on shared words, order-free integer / max combination.
+//   * halo: 8-byte {token, value} granules, one write-through store each -- the data is the flag.
+//   The token is the epoch in the workspace control block + 1 (fastkv_workspace_init zeroes the block once; the
+//   compaction kernel of the same operator call advances the epoch), never a launch argument that a graph replay would
+//   freeze: a flag or granule left by an earlier launch never matches.
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
@@ -54,7 +57,7 @@ template <int D, int PER>
 __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
-                                                             uint16_t *__restrict__ hs, int hs_stride, float *__restrict__ pmax,
+                                                             uint64_t *__restrict__ edges, float *__restrict__ pmax,
                                                              uint64_t *__restrict__ psum, const uint32_t *__restrict__ ctrl,
                                                              uint32_t *__restrict__ zero_area, int zero_words, int ksize, int pooling,
                                                              uint16_t *__restrict__ c_out, int64_t c_row_stride,
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     const int bg = b * Hkv + g, BG = gridDim.y * Hkv;
     const int n = S - W;
     const int nwt = (S + 63) / 64;
-    const int wave_id = blk * 4 + w, nwaves = nblk * 4;
+    const int wave_id = blk * 4 + w;
     const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
     unsigned char *my = slab[w];
     const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
@@ -110,7 +113,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         qv[u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(n + r) * qs_s + ch * 8);
     }
     KStage sA, sB;
-    k_fetch(sA, kb, ks_s, (wave_id < nwt ? wave_id : 0) * 64, S, 0, lane);
+    const int wt0 = wave_id * PER;                       // this wave's tiles: wt0 .. wt0 + PER - 1 (contiguous keys per workgroup)
+    k_fetch(sA, kb, ks_s, (wt0 < nwt ? wt0 : 0) * 64, S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < QV; ++u) {
@@ -124,9 +128,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     __syncthreads();
     {
-        const int first = (wave_id < nwt ? wave_id : 0) * 64;
+        const int first = (wt0 < nwt ? wt0 : 0) * 64;
         if (NPH >= 2) k_fetch(sB, kb, ks_s, first, S, 1, lane);
-        else if (wave_id + nwaves < nwt) k_fetch(sB, kb, ks_s, (wave_id + nwaves) * 64, S, 0, lane);
+        else if (PER > 1 && wt0 + 1 < nwt) k_fetch(sB, kb, ks_s, (wt0 + 1) * 64, S, 0, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     for (int t = 0; t < PER; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) lg[t][i] = 0;
-        const int wt = wave_id + t * nwaves;
+        const int wt = wt0 + t;
         if (wt < nwt) {
             const int key0 = wt * 64;
             f32x16 acc0, acc1;
@@ -151,9 +155,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             for (int ph = 0; ph < NPH; ++ph) {
                 const bool useA = NPH >= 2 ? ((ph & 1) == 0) : ((t & 1) == 0);
                 int nkey, nph;
-                if (NPH == 1) { nkey = (wt + 2 * nwaves) * 64; nph = 0; }
+                if (NPH == 1) { nkey = (wt + 2) * 64; nph = 0; }
                 else if (ph + 2 < NPH) { nkey = key0; nph = ph + 2; }
-                else { nkey = (wt + nwaves) * 64; nph = ph + 2 - NPH; }
+                else { nkey = (wt + 1) * 64; nph = ph + 2 - NPH; }
                 const bool more = nkey < nwt * 64 && (NPH == 1 ? t + 2 < PER : (ph + 2 < NPH || t + 1 < PER));
                 if (useA) { k_commit(sA, lane, my); if (more) k_fetch(sA, kb, ks_s, nkey, S, nph, lane); }
                 else { k_commit(sB, lane, my); if (more) k_fetch(sB, kb, ks_s, nkey, S, nph, lane); }
@@ -188,7 +192,6 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's histogram zeros have reached memory
     __syncthreads();
     uint32_t *flag1 = flags + (size_t)bg * nblk, *flag2 = flags + (size_t)(BG + bg) * nblk;
-    uint32_t *flag3 = flags + (size_t)(2 * BG + bg) * nblk;
     float *pm = pmax + (size_t)bg * nblk * 32;
     uint64_t *psu = psum + (size_t)bg * nblk * 32;
     if (w == 0) {
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; }
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int key0 = (wave_id + t * nwaves) * 64;          // >= S when the wave has no tile t: nothing is counted
+        const int key0 = (wt0 + t) * 64;                        // >= S when the wave has no tile t: nothing is counted
         const bool in0 = key0 + n31 < S, in1 = key0 + 32 + n31 < S;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -310,15 +313,25 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // Head i4 = i >> 2 of the group owns rows 8*i4 .. 8*i4+7; the lower half wave holds window rows 0-3 of every head,
     // the upper half rows 4-7.  The reference adds the 8 fp16 probabilities in ascending row order (fp32 accumulator,
     // utils.py:104): the lower half's partial sum crosses to the upper half, which finishes it and owns the result.
+    // The workgroup owns the contiguous positions [lo, lo + TWG): the window-row sums hs go to an LDS tile (the K slabs
+    // are free now), column pad + local position; candidates past n hold the pooling pad value (utils.py:106,108).
+    constexpr int TWG = 256 * PER, PADMAX = 31, TW = TWG + 2 * PADMAX;
+    static_assert(G * TW * sizeof(float) + HIST12 * sizeof(uint32_t) <= sizeof(slab), "phase C/D do not fit the K slabs");
+    float(*tile)[TW] = reinterpret_cast<float(*)[TW]>(&slab[0][0]);
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(&slab[0][0] + G * TW * sizeof(float));
+    const int pad = ksize / 2, lo = blk * TWG;
+    const bool avg = pooling == FASTKV_POOL_AVG;
+    const float padv = avg ? 0.0f : -INFINITY;
+    const bool want_hist = all_idx == nullptr;
     float ri[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ri[i] = s_row[(i & 3) + 8 * (i >> 2) + 4 * hi];
+    if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int key0 = (wave_id + t * nwaves) * 64;
 #pragma unroll
         for (int bk = 0; bk < 2; ++bk) {
-            const int j = key0 + bk * 32 + n31;
+            const int lp = (w * PER + t) * 64 + bk * 32 + n31;      // local position; global candidate lo + lp
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 float p[4];
@@ -328,84 +341,73 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
                 float c = __shfl_xor(a, 32, 64);                 // upper half: the lower half's sum of rows 0-3
                 c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
-                if (hi && j < n)
-                    __hip_atomic_store(hs + (size_t)(b * H + g * G + i4) * hs_stride + j, f2h(c), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);                         // write-through: read by other workgroups below
+                if (hi) tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c)) : padv;
             }
         }
     }
     FKF_STAMP(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (w == 0) {
-        if (lane == 0) __hip_atomic_store(flag3 + blk, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wait_flags(flag3, nblk, token, lane);
+
+    // ---------------------------------------------------------------- halo: `pad` positions from each neighbour
+    // Pooling reaches pad positions into the neighbouring workgroups of the head.  Every workgroup publishes its first
+    // and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the
+    // flag) and reads the neighbours' granules until their tag is this launch's token.  No neighbour = pooling padding.
+    {
+        uint64_t *eg = edges + ((size_t)bg * nblk + blk) * (2 * G * PADMAX);
+        const int t = threadIdx.x, per_side = G * pad;
+        if (t < 2 * per_side) {
+            const int side = t >= per_side, q2 = t - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
+            const float v = tile[i4][PADMAX + (side ? TWG - pad + e : e)];
+            __hip_atomic_store(eg + (side * G + i4) * PADMAX + e, ((uint64_t)token << 32) | f32_bits(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            // side 0 of this thread = the LEFT halo of this workgroup = the right edge (side 1) of workgroup blk - 1, and
+            // vice versa
+            const int nb = side ? blk + 1 : blk - 1;
+            float hv = padv;
+            if (nb >= 0 && nb < nblk) {
+                const uint64_t *src = edges + ((size_t)bg * nblk + nb) * (2 * G * PADMAX) + ((side ? 0 : 1) * G + i4) * PADMAX + e;
+                uint64_t x;
+                uint32_t spins = 0;
+                while (((x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 22)) __builtin_trap();
+                }
+                hv = bits_f32((uint32_t)x);
+            }
+            tile[i4][side ? PADMAX + TWG + e : PADMAX - pad + e] = hv;
+        }
     }
     __syncthreads();
     FKF_STAMP(6);
 
     // ---------------------------------------------------------------- phase D: pool, sum over the heads, scores + histogram
-    // (score_finalize of the three-kernel path, utils.py:105-112.)  This workgroup owns candidates [blk*CH, (blk+1)*CH);
-    // thread t of a pass <-> position p0 - pad + t, TP = 256 - 2*pad outputs per pass.  LDS: the K slabs are free now.
-    {
-        constexpr int PPT = 5, TW = 256 * PPT;                       // positions per thread and pass; [G][TW] floats + the histogram
-        static_assert(G * TW * sizeof(float) + HIST12 * sizeof(uint32_t) <= sizeof(slab), "phase D does not fit the K slabs");
-        float(*tile)[TW] = reinterpret_cast<float(*)[TW]>(&slab[0][0]);
-        uint32_t *s_hist = reinterpret_cast<uint32_t *>(&slab[0][0] + G * TW * sizeof(float));
-        const bool want_hist = all_idx == nullptr;
-        const int pad = ksize / 2, TP = TW - 2 * pad, t = threadIdx.x;
-        const int CH = (n + nblk - 1) / nblk, lo = blk * CH, hiC = min(n, lo + CH);
-        const bool avg = pooling == FASTKV_POOL_AVG;
-        const float padv = avg ? 0.0f : -INFINITY;
-        if (want_hist) for (int i = t; i < HIST12; i += 256) s_hist[i] = 0;
-        for (int p0 = lo; p0 < hiC; p0 += TP) {                      // one pass at the shapes this kernel takes (CH <= 1024)
-            const int need = min(TP, hiC - p0) + 2 * pad;            // tile columns in use
-            uint16_t x[PPT][G];
+    // (score_finalize of the three-kernel path, utils.py:105-112), PER positions per thread
 #pragma unroll
-            for (int u = 0; u < PPT; ++u) {                          // all loads of the pass in flight together
-                const int tt = u * 256 + t, j = p0 - pad + tt;
-                const bool inr = tt < need && j >= 0 && j < n;
+    for (int u = 0; u < PER; ++u) {
+        const int lp = u * 256 + threadIdx.x, j = lo + lp;
+        const bool is_out = j < n;
+        float gsum = 0.0f;
+        if (is_out) {
+            float pv[G];
 #pragma unroll
-                for (int i4 = 0; i4 < G; ++i4)
-                    x[u][i4] = __hip_atomic_load(hs + (size_t)(b * H + g * G + i4) * hs_stride + (inr ? j : 0), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], PADMAX + lp, pad, ksize, avg);
 #pragma unroll
-            for (int u = 0; u < PPT; ++u) {
-                const int tt = u * 256 + t, j = p0 - pad + tt;
-                const bool inr = tt < need && j >= 0 && j < n;
-#pragma unroll
-                for (int i4 = 0; i4 < G; ++i4) tile[i4][tt] = inr ? h2f(x[u][i4]) : padv;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < PPT; ++u) {
-                if (u * 256 >= need) break;
-                const int tt = u * 256 + t, j = p0 - pad + tt;
-                const bool is_out = tt >= pad && tt < need - pad && j < n;          // j >= p0 >= 0 here
-                float gsum = 0.0f;
-                if (is_out) {
-                    float pv[G];
-#pragma unroll
-                    for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], tt, pad, ksize, avg);
-#pragma unroll
-                    for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
-                }
-                const uint16_t c16 = f2h(gsum);
-                if (is_out) {
-                    c_out[(size_t)bg * c_row_stride + j] = c16;
-                    if (all_idx) {                           // capacity == S: identity selection + keys (see score_finalize)
-                        all_idx[(size_t)bg * n + j] = (int64_t)j;
-                        if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
-                    }
-                }
-                if (want_hist) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
-            }
-            __syncthreads();
+            for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
         }
-        if (all_keys && blk == 0 && t < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + t] = 0;
-        if (want_hist)
-            for (int i = t; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
+        const uint16_t c16 = f2h(gsum);
+        if (is_out) {
+            c_out[(size_t)bg * c_row_stride + j] = c16;
+            if (all_idx) {                                   // capacity == S: identity selection + keys (see score_finalize)
+                all_idx[(size_t)bg * n + j] = (int64_t)j;
+                if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
+            }
+        }
+        if (want_hist) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
+    }
+    if (all_keys && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
+    if (want_hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
     }
     FKF_STAMP(7);
 }
@@ -432,11 +434,11 @@ template <int D, int PER> static bool fused_resident(int grid_wgs)
 // Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
 // covered and the caller must take the three-kernel path.
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
-                        const int64_t *ks, uint16_t *hs, int hs_stride, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx,
-                        uint16_t *all_keys, int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err)
+                        const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
+                        int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err)
 {
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
-    if (disabled || L.engine != ENGINE_MFMA || L.R != 32 || p.window != 8 || p.H / p.Hkv != 4) return false;
+    if (disabled || L.engine != ENGINE_MFMA || L.R != 32 || p.window != 8 || p.H / p.Hkv != 4 || p.kernel > 63) return false;
     const int nwt = (p.S + 63) / 64;
     int nblk = (2 * 256) / (p.Hkv * p.B);
     if (nblk < 1) return false;
@@ -444,13 +446,14 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
     const int per = (nwt + nblk * 4 - 1) / (nblk * 4);
     if (per > 4) return false;
-    nblk = (nwt + per * 4 - 1) / (per * 4);
-    const int PERT = per <= 1 ? 1 : per <= 2 ? 2 : 4;
+    const int PERT = per <= 1 ? 1 : per <= 2 ? 2 : 4;          // tiles per wave the kernel is instantiated for
+    nblk = (nwt + PERT * 4 - 1) / (PERT * 4);                   // a workgroup owns 4*PERT consecutive tiles
     if ((size_t)p.B * p.Hkv * nblk > FUSED_MAX_WGS) return false;
     const float sqrtD = (float)sqrt((double)p.D);
     float *pmax = reinterpret_cast<float *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 4);
     const uint32_t *ctrl = reinterpret_cast<const uint32_t *>(ws);
+    uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 12);   // [wg][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
     dim3 grid(nblk * p.Hkv, p.B);
     const int wgs = nblk * p.Hkv * p.B;
@@ -462,7 +465,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     ProfScope ps_(K_FUSED, st);
 #define FK_FUSED(DV, PV)                                                                                                         \
     hipLaunchKernelGGL((score_fused_kernel<DV, PV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],           \
-                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, hs, hs_stride, pmax, psum, \
+                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, \
                        ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride)
 #define FK_FUSED_D(DV)                                                                             \
     do {                                                                                           \

@@ -589,8 +589,8 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     hipError_t e;
 
     if (epoch_bump_later) *epoch_bump_later = nullptr;
-    // one launch for the common geometry (the `logits` area then holds the window-row sums hs[b,h,:]) ...
-    const bool fused = launch_score_fused(p, L, q, qs, k, ks, logits, L.Sp, c_out, c_row_stride, all_idx, all_keys, all_key_stride,
+    // one launch for the common geometry (the `logits` area then only holds the workgroups' halo granules) ...
+    const bool fused = launch_score_fused(p, L, q, qs, k, ks, c_out, c_row_stride, all_idx, all_keys, all_key_stride,
                                           ws, st, &e);
     if (fused) {
         if (e != hipSuccess) return e;
