@@ -306,8 +306,8 @@ def main():
                                "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
                                "hbm_view": {"achieved_GBps": round(alg / (us * 1e-6) / 1e9, 1), "peak_GBps": HBM_PEAK_GBPS,
                                             "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
-                               "note": "score_fused = logits (fp32 MFMA) + softmax (2 in-kernel reductions over the chip) + "
-                                       "window-row sum in one launch; the logits never leave registers" if kname == "score_fused"
+                               "note": "score_fused = logits (fp32 MFMA) + softmax (2 in-kernel reductions over the head's workgroups) + window-row "
+                                       "sum + pooling + head sum in one launch; logits stay in registers, row sums in LDS" if kname == "score_fused"
                                        else "fp32 MFMA contraction; logits written as fp16"}
             cc, cms = prof["compact_kv"]
             out["compact"] = {"per_layer_avg_us": round(cms / cc * 1e3, 2),
