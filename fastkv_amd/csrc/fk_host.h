@@ -64,7 +64,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
     L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
-    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 12 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum records, halo granules
+    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum / halo granules
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {

@@ -35,29 +35,30 @@ __device__ unsigned long long g_fstamps[4096 * 8];
 
 constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the nblk partial records
 
-// One wave polls the nblk flag words (one 4-B sc1 load per lane and pass), sleeping between passes: pollers share the
-// memory channel of those words with the producers' stores.
-__device__ __forceinline__ void wait_flags(const uint32_t *flags, int nblk, uint32_t token, int lane)
+// Hand-off records are 8-byte {token, 32-bit value} granules, written by ONE write-through (sc1) store each: the data is
+// the flag (no drain, no separate flag word).  A consumer first lets one wave poll granule 0 of every producer (one 8-B
+// load per lane and pass, sleeping in between: pollers share those words' memory channel with the producers' stores),
+// then everybody reads the records and checks every tag (a record is one store instruction, so this almost never loops).
+__device__ __forceinline__ uint64_t granule(uint32_t token, uint32_t value) { return ((uint64_t)token << 32) | value; }
+__device__ __forceinline__ void wait_first_granules(const uint64_t *rec, int stride, int nblk, uint32_t token, int lane)
 {
     uint32_t spins = 0;
     for (;;) {
         bool ok = true;
         for (int l = lane; l < nblk; l += 64)
-            ok = ok && (__hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token);
+            ok = ok && ((uint32_t)(__hip_atomic_load(rec + (size_t)l * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 22)) __builtin_trap();          // seconds: a partner never arrived; fail loudly instead of hanging
     }
-    // every byte handed over is stored write-through (sc1) and drained before its flag, and every load of it is an sc1
-    // load: no cache invalidate is needed, only the compiler must keep those loads behind the poll
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: every load of handed-over bytes is an sc1 load
 }
 
 template <int D, int PER>
 __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
-                                                             uint64_t *__restrict__ edges, float *__restrict__ pmax,
+                                                             uint64_t *__restrict__ edges, uint64_t *__restrict__ pmax,
                                                              uint64_t *__restrict__ psum, const uint32_t *__restrict__ ctrl,
                                                              uint32_t *__restrict__ zero_area, int zero_words, int ksize, int pooling,
                                                              uint16_t *__restrict__ c_out, int64_t c_row_stride,
@@ -86,7 +87,6 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // graph replay would freeze; the flags still hold the previous token or the zeros of the initialisation.
     if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
     const uint32_t token = ctrl[2] + 1u ? ctrl[2] + 1u : 1u;
-    uint32_t *flags = const_cast<uint32_t *>(ctrl) + 16;
     FKF_STAMP(0);
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first flag, so
@@ -191,32 +191,36 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's histogram zeros have reached memory
     __syncthreads();
-    uint32_t *flag1 = flags + (size_t)bg * nblk, *flag2 = flags + (size_t)(BG + bg) * nblk;
-    float *pm = pmax + (size_t)bg * nblk * 32;
-    uint64_t *psu = psum + (size_t)bg * nblk * 32;
+    uint64_t *pm = pmax + (size_t)bg * nblk * 32;                    // [nblk][32] granules: row maxima
+    uint64_t *psu = psum + (size_t)bg * nblk * 64;                   // [nblk][32][2] granules: row sums, low / high word
     if (w == 0) {
         if (lane < 32)
-            __hip_atomic_store(pm + blk * 32 + lane, fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane])),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // write-through record
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       // ... drained before its flag
-        if (lane == 0) __hip_atomic_store(flag1 + blk, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wait_flags(flag1, nblk, token, lane);
+            __hip_atomic_store(pm + blk * 32 + lane,
+                               granule(token, f32_bits(fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane])))),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_first_granules(pm, 32, nblk, token, lane);
     }
     __syncthreads();
     {
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
-        float rec[FUSED_MAX_WGS / 8 / FUSED_PARTS];                  // nblk <= FUSED_MAX_WGS / 8 ... all loads in flight together
+        for (;;) {
+            uint64_t rec[FUSED_MAX_WGS / 8 / FUSED_PARTS];           // nblk <= FUSED_MAX_WGS / 8; all loads in flight together
 #pragma unroll
-        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-            const int bl = part + u * FUSED_PARTS;
-            rec[u] = __hip_atomic_load(pm + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+                const int bl = part + u * FUSED_PARTS;
+                rec[u] = __hip_atomic_load(pm + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            float v = -INFINITY;
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+                ok = ok && (uint32_t)(rec[u] >> 32) == token;
+                v = fmaxf(v, bits_f32((uint32_t)rec[u]));
+            }
+            s_f[part][row] = v;
+            if (__syncthreads_and(ok)) break;
         }
-        float v = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) v = fmaxf(v, rec[u]);
-        s_f[part][row] = v;
     }
-    __syncthreads();
     if (threadIdx.x < 32) {
         float v = s_f[0][threadIdx.x];
 #pragma unroll
@@ -271,34 +275,39 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     __syncthreads();
     if (w == 0) {
-        if (lane < 32) {
-            const uint32_t bad = s_bad[0][lane] | s_bad[1][lane] | s_bad[2][lane] | s_bad[3][lane];
-            __hip_atomic_store(psu + blk * 32 + lane, bad ? FK_SUM_POISON : s_u[0][lane] + s_u[1][lane] + s_u[2][lane] + s_u[3][lane],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(flag2 + blk, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wait_flags(flag2, nblk, token, lane);
+        const int row = lane >> 1;
+        const uint32_t bad = s_bad[0][row] | s_bad[1][row] | s_bad[2][row] | s_bad[3][row];
+        const uint64_t tot = bad ? FK_SUM_POISON : s_u[0][row] + s_u[1][row] + s_u[2][row] + s_u[3][row];
+        __hip_atomic_store(psu + blk * 64 + lane, granule(token, (uint32_t)((lane & 1) ? tot >> 32 : tot)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        wait_first_granules(psu, 64, nblk, token, lane);
     }
     __syncthreads();
     {
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
-        uint64_t rec[FUSED_MAX_WGS / 8 / FUSED_PARTS];
+        for (;;) {
+            uint64_t rl[FUSED_MAX_WGS / 8 / FUSED_PARTS], rh[FUSED_MAX_WGS / 8 / FUSED_PARTS];
 #pragma unroll
-        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-            const int bl = part + u * FUSED_PARTS;
-            rec[u] = __hip_atomic_load(psu + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        uint64_t s = 0;
-        uint32_t bad = 0;
+            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+                const int bl = part + u * FUSED_PARTS;
+                const uint64_t *g2 = psu + (bl < nblk ? bl : blk) * 64 + row * 2;
+                rl[u] = __hip_atomic_load(g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rh[u] = __hip_atomic_load(g2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint64_t s2 = 0;
+            uint32_t bad = 0;
+            bool ok = true;
 #pragma unroll
-        for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-            if (part + u * FUSED_PARTS < nblk) { if (rec[u] == FK_SUM_POISON) bad = 1; else s += rec[u]; }
+            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
+                ok = ok && (uint32_t)(rl[u] >> 32) == token && (uint32_t)(rh[u] >> 32) == token;
+                const uint64_t v = ((rh[u] & 0xffffffffull) << 32) | (rl[u] & 0xffffffffull);
+                if (part + u * FUSED_PARTS < nblk) { if (v == FK_SUM_POISON) bad = 1; else s2 += v; }
+            }
+            s_u[part][row] = s2;
+            s_bad[part][row] = bad;
+            if (__syncthreads_and(ok)) break;
         }
-        s_u[part][row] = s;
-        s_bad[part][row] = bad;
     }
-    __syncthreads();
     if (threadIdx.x < 32) {
         uint64_t s = 0;
         uint32_t bad = 0;
@@ -450,10 +459,10 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     nblk = (nwt + PERT * 4 - 1) / (PERT * 4);                   // a workgroup owns 4*PERT consecutive tiles
     if ((size_t)p.B * p.Hkv * nblk > FUSED_MAX_WGS) return false;
     const float sqrtD = (float)sqrt((double)p.D);
-    float *pmax = reinterpret_cast<float *>(ws + L.off_fpart);
-    uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 4);
+    uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
+    uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);
     const uint32_t *ctrl = reinterpret_cast<const uint32_t *>(ws);
-    uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 12);   // [wg][2][4][31] halo granules
+    uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [wg][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
     dim3 grid(nblk * p.Hkv, p.B);
     const int wgs = nblk * p.Hkv * p.B;

@@ -18,7 +18,7 @@ for S in (32768, 2048):
     st = buf.reshape(4096, 8)[:nw].astype(np.int64)
     t0 = st[:, 0].min()
     rel = (st - t0) * 10 / 1000.0
-    names = ["start", "MFMA + epilogue done", "max known (sync 1)", "(unordered stamp)", "sum known (sync 2)", "hs stored", "hs of the head visible (sync 3)", "end"]
+    names = ["start", "MFMA + epilogue done", "max known (hand-off 1)", "(unordered stamp)", "sum known (hand-off 2)", "row sums in LDS", "halo received", "end"]
     print(f"S={S}: waves={nw}")
     for i, nm in enumerate(names):
         col = rel[:, i]
