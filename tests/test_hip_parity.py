@@ -275,6 +275,12 @@ def test_arithmetic_contract_on_gpu(dev):
     dict(B=1, H=4, Hkv=2, S=40000, D=64, W=8, ks=5, pooling="avgpool", cap=20000, tsp_len=0),
     # wide window (W=32, G=2 -> 64 query rows = two MFMA row blocks), batch 3
     dict(B=3, H=4, Hkv=2, S=2100, D=128, W=32, ks=13, pooling="maxpool", cap=300, tsp_len=700),
+    # the fused scoring kernel's other instantiations (G=4, W=8): head_dim 64 and 256, four tiles per wave (S=65536 on 8 KV
+    # heads), batch 2 with a ragged last tile, a wide pooling kernel (halo of 15 positions from each neighbour)
+    dict(B=1, H=16, Hkv=4, S=3000, D=64, W=8, ks=7, pooling="avgpool", cap=400, tsp_len=900),
+    dict(B=1, H=8, Hkv=2, S=2500, D=256, W=8, ks=5, pooling="maxpool", cap=300, tsp_len=0),
+    dict(B=1, H=32, Hkv=8, S=65536, D=128, W=8, ks=7, pooling="maxpool", cap=4096, tsp_len=8192),
+    dict(B=2, H=16, Hkv=4, S=5003, D=128, W=8, ks=31, pooling="avgpool", cap=700, tsp_len=1500),
 ])
 def test_large_and_unusual_shapes_bit_exact(shape, dev):
     from fastkv_amd import ops
