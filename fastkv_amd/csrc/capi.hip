@@ -49,9 +49,13 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p)
     return make_layout(q).total;
 }
 
-// One 256-thread block: zero the control block, then magic + epoch 0.
+// One 256-thread block.  Idempotent: a block that already carries the magic word keeps its epoch (so an initialisation
+// that ends up inside a captured graph, or is repeated on a re-used allocation, cannot rewind the hand-off tokens).
 __global__ void fastkv_ctrl_init_kernel(uint32_t *ctrl)
 {
+    const bool live = ctrl[0] == (uint32_t)(CTRL_MAGIC & 0xffffffffu) && ctrl[1] == (uint32_t)(CTRL_MAGIC >> 32);
+    __syncthreads();
+    if (live) return;
     for (int i = threadIdx.x; i < (int)(CTRL_BYTES / 4); i += blockDim.x) ctrl[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) { ctrl[0] = (uint32_t)(CTRL_MAGIC & 0xffffffffu); ctrl[1] = (uint32_t)(CTRL_MAGIC >> 32); }

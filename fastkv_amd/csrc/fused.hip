@@ -86,7 +86,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // of this launch is the epoch left by the previous one + 1 (score_finalize bumps it): never a launch argument, which a
     // graph replay would freeze; the flags still hold the previous token or the zeros of the initialisation.
     if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
-    const uint32_t token = ctrl[2] + 1u ? ctrl[2] + 1u : 1u;
+    // (a bijective mix of the epoch, never 0: memory that was never written by this library -- zeros, small integers, fp16
+    // data -- does not look like a current granule)
+    uint32_t token = (ctrl[2] + 1u) * 0x9E3779B1u ^ 0x7F4A7C15u;
+    if (token == 0u) token = 0x6B43A9B5u;
     FKF_STAMP(0);
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first flag, so

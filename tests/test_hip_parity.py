@@ -346,3 +346,31 @@ print('child ok')
     assert good.returncode == 0 and "child ok" in good.stdout, good.stdout[-1500:] + good.stderr[-1500:]
     bad = _child("INIT = False\n" + code, {})
     assert bad.returncode != 0 and "child ok" not in bad.stdout
+
+
+def test_graph_replay_with_changing_inputs(dev):
+    """The operator captured in a HIP graph (workspace initialisation included in the capture: no warm-up on the capture
+    stream) and replayed on new data every time: the hand-off tokens of the fused scoring kernel come from the epoch in the
+    workspace, not from a launch argument, so every replay equals the eager result."""
+    from fastkv_amd import ops
+    case = CASES["cfg1"]
+    shapes = (case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+    q0, k0, v0 = make_qkv(900, *shapes)
+    qs, ks, vs = (_to_dev(t, dev) for t in (q0, k0, v0))
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            out = ops.update_kv(qs, ks, vs, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "score",
+                                return_indices=True)
+    for seed in (901, 902, 903, 901):
+        q, k, v = make_qkv(seed, *shapes)
+        qs.copy_(_to_dev(q, dev)); ks.copy_(_to_dev(k, dev)); vs.copy_(_to_dev(v, dev))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want = ops.update_kv(_to_dev(q, dev), _to_dev(k, dev), _to_dev(v, dev), case["W"], case["ks"], case["pooling"], case["cap"],
+                             case["tsp_len"], "score", return_indices=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and torch.equal(out[3], want[3]), seed
+        assert torch.equal(out[2], want[2])
