@@ -364,15 +364,18 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
     if (w == 0) {
         if (lane < 17)
             __hip_atomic_store(&tab[chunk * SPL_LINE + lane], lane < 16 ? sh.h4[lane] : sh.cg12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        // the counters were stored write-through (sc1) and are drained here; every later load of them is an sc1 load: no
+        // release / acquire fences (each would write back or invalidate a whole L2) -- relaxed arrive, relaxed polls
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            __hip_atomic_fetch_add(&arrive[rowi], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&arrive[rowi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t spins = 0;
-            while (__hip_atomic_load(&arrive[rowi], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)nchunks) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) __builtin_trap();          // seconds: the launch is broken, fail loudly instead of hanging
+            while (__hip_atomic_load(&arrive[rowi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)nchunks) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 23)) __builtin_trap();          // seconds: the launch is broken, fail loudly instead of hanging
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __syncthreads();
     // ---------------- phase 2: totals over the row and over the chunks before this one
