@@ -33,6 +33,7 @@ __device__ unsigned long long g_fstamps[4096 * 8];
 #define FKF_STAMP(slot) do { } while (0)
 #endif
 
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the nblk partial records
 
 // Hand-off records are 8-byte {token, 32-bit value} granules, written by ONE write-through (sc1) store each: the data is
@@ -142,8 +143,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // and key0 + 32 + n31 (high half); mx[i] = running maximum of row m(i) over this lane's columns
     uint32_t lg[PER][16];
     float mx[16];
+    uint32_t mx16[16];                                           // the same for full tiles: packed fp16 pair (column block 0, 1)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx[i] = -INFINITY;
+    for (int i = 0; i < 16; ++i) { mx[i] = -INFINITY; mx16[i] = 0xFC00FC00u; }
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
 #pragma unroll
@@ -171,20 +173,36 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int j0 = key0 + n31, j1 = j0 + 32;
+            if (key0 + 64 <= n) {
+                // tile entirely among the candidates: no window mask, every column counts; the running maxima stay packed
+                // fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf) -- vector instructions of this phase are
+                // not hidden behind the MFMAs of the SIMD's other wave, every one of them counts
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rw = (i & 3) + 4 * hi;                                         // window row of query row m(i): m % W
-                // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both columns of the pair in one packed sequence)
-                const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(acc1[i]))}, sqrtD, rsqrtD);
-                uint16_t s0 = f2h(sc.x), s1 = f2h(sc.y);
-                if (j0 >= n && (j0 - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));           // utils.py:95-101
-                if (j1 >= n && (j1 - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
-                if (j0 < S) mx[i] = fmaxf(mx[i], h2f(s0));
-                if (j1 < S) mx[i] = fmaxf(mx[i], h2f(s1));
-                lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
+                for (int i = 0; i < 16; ++i) {
+                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(acc1[i]))}, sqrtD, rsqrtD);   // utils.py:94
+                    const uint32_t wd = (uint32_t)f2h(sc.x) | ((uint32_t)f2h(sc.y) << 16);
+                    mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
+                                                                                      __builtin_bit_cast(h16x2, wd)));
+                    lg[t][i] = wd;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rw = (i & 3) + 4 * hi;                                     // window row of query row m(i): m % W
+                    // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both columns of the pair in one packed sequence)
+                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(acc1[i]))}, sqrtD, rsqrtD);
+                    uint16_t s0 = f2h(sc.x), s1 = f2h(sc.y);
+                    if (j0 >= n && (j0 - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));       // utils.py:95-101
+                    if (j1 >= n && (j1 - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
+                    if (j0 < S) mx[i] = fmaxf(mx[i], h2f(s0));
+                    if (j1 < S) mx[i] = fmaxf(mx[i], h2f(s1));
+                    lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
+                }
             }
         }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx[i] = fmaxf(mx[i], fmaxf(h2f((uint16_t)(mx16[i] & 0xffffu)), h2f((uint16_t)(mx16[i] >> 16))));
     FKF_STAMP(1);
     // row maxima: across the 32 lanes of a half wave, then across the 4 waves, then published
     {
