@@ -141,6 +141,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // ---------------------------------------------------------------- phase A: logits of this wave's tiles, row maxima
     // lg[t][i]: scaled + masked fp16 logits of query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns key0 + n31 (low half)
     // and key0 + 32 + n31 (high half); mx[i] = running maximum of row m(i) over this lane's columns
+    f16x8 pm0, pm1;
+    perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][16];
     float mx[16];
     uint32_t mx16[16];                                           // the same for full tiles: packed fp16 pair (column block 0, 1)
@@ -167,10 +169,36 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 if (useA) { k_commit(sA, lane, my); if (more) k_fetch(sA, kb, ks_s, nkey, S, nph, lane); }
                 else { k_commit(sB, lane, my); if (more) k_fetch(sB, kb, ks_s, nkey, S, nph, lane); }
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
+                mfma_phase_mx(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            // mfma_phase_mx is exact for finite K only: a NaN among the results (non-finite K or Q) sends the wave back over
+            // the tile with the vector-ALU conversion, whose results are the fmaf chain on any input
+            {
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bad = bad || acc0[i] != acc0[i] || acc1[i] != acc1[i];
+                if (__any(bad)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll 1
+                    for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll 1
+                        for (int i = 0; i < 8; ++i) {
+                            int jj = key0 + i * 8 + (lane >> 3);
+                            jj = jj < S ? jj : S - 1;
+                            *reinterpret_cast<u32x4 *>(my + (i * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16) =
+                                *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
             }
             const int j0 = key0 + n31, j1 = j0 + 32;
             if (key0 + 64 <= n) {

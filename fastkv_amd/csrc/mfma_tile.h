@@ -114,4 +114,51 @@ __device__ __forceinline__ void mfma_phase(f32x16 &acc0, f32x16 &acc1, const uns
     }
 }
 
+
+// The same phase with the fp16 -> fp32 conversion of K done by the matrix pipe itself: per 32-dim chunk and 32-key block two
+// v_mfma_f32_32x32x16_f16 multiply the K piece (the lane's ds_read_b128, already in B-operand layout) by a 0/1 permutation
+// matrix, which lands K[j][2i + hi] in accumulator register i of lane (j, hi) -- exactly the B operand of k-step i of the
+// fp32 MFMA.  Exact for finite K (one product 1*x, the rest 0*x = 0); a non-finite K element turns its whole chunk into NaN
+// (0 * inf), which the caller detects in the results and redoes with mfma_phase.  8 extra short MFMAs per phase instead of
+// 128 vector instructions that the fp32 MFMAs of the SIMD do not hide.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void perm_operands(int lane, f16x8 &p0, f16x8 &p1)
+{
+    const int r = lane & 31, h = lane >> 5;
+    const int i = (r & 3) + 4 * (r >> 3), delta = 2 * i + ((r >> 2) & 1);      // output row r <-> dim delta of the chunk
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        p0[e] = (_Float16)(delta == 8 * h + e ? 1.0f : 0.0f);
+        p1[e] = (_Float16)(delta == 16 + 8 * h + e ? 1.0f : 0.0f);
+    }
+}
+__device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const unsigned char *my, const float *Ap, int n31, int hi,
+                                              f16x8 p0, f16x8 p1)
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    auto conv = [&](int blk, int ch) {
+        const unsigned char *rowp = my + (blk * 32 + n31) * ROWB + ch * 64 + hi * 16;
+        const f16x8 s0 = *reinterpret_cast<const f16x8 *>(rowp), s1 = *reinterpret_cast<const f16x8 *>(rowp + 32);
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, s0, z, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, s1, d, 0, 0, 0);
+    };
+    f32x16 b0 = conv(0, 0), b1 = conv(1, 0);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        f32x16 n0 = b0, n1 = b1;
+        float av[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[i] = Ap[(ch * 16 + i) * 64];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
+            if (ch == 0 && i == 7) { n0 = conv(0, 1); n1 = conv(1, 1); }
+        }
+        b0 = n0; b1 = n1;
+    }
+}
+
 }  // namespace fk

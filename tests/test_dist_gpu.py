@@ -26,7 +26,9 @@ def _worker(rank, world, port, case, lens, q_out):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # two ranks share ONE GPU here, which include/fastkv_hip.h rules out for the fused scoring kernel (all its workgroups
+    # must be resident): the ranks take the staged kernels
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FASTKV_FUSED="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fastkv_amd import ops
@@ -78,7 +80,7 @@ def _tp_worker(rank, world, port, case, q_out):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FASTKV_FUSED="0")      # see _worker
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fastkv_amd import ops

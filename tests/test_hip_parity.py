@@ -374,3 +374,43 @@ def test_graph_replay_with_changing_inputs(dev):
         torch.cuda.synchronize()
         assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and torch.equal(out[3], want[3]), seed
         assert torch.equal(out[2], want[2])
+
+
+def test_fused_path_on_special_values(dev):
+    """The fused scoring kernel converts K to fp32 on the matrix pipe (fp16 MFMA x permutation matrix: exact for finite
+    values) and falls back to the vector-ALU conversion when a result is NaN.  Subnormal / signed-zero / huge K values must
+    give the oracle's bits; with Inf or NaN in K the scores must agree with the vector-ALU engine (a different kernel
+    family: score_logits + row_stats + score_finalize): NaN in the same places, every other value bit for bit."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    B, H, Hkv, S, D, W = 1, 16, 4, 2200, 128, 8
+    q, k, v = make_qkv(321, B, H, Hkv, S, D, W)
+    k = k.clone()
+    k[:, :, 100:400] *= 1e-5                      # fp16 subnormals
+    k[:, :, 500:520] = 0.0
+    k[:, 1, 500:520:2] = -0.0
+    k[:, :, 700:760] *= 200.0                     # large finite values
+    want = O.update_kv(q, k, v, W, 7, "avgpool", 300, 600, "score", return_scores=True)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    got = ops.update_kv(qd, kd, vd, W, 7, "avgpool", 300, 600, "score", return_indices=True, return_scores=True)
+    assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)) and torch.equal(got[3].cpu(), want[2])
+    assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[2].cpu(), want[3])
+    # non-finite K: fused (matrix-pipe conversion + fallback) against the vector-ALU engine, scores bit for bit
+    k2 = k.clone()
+    k2[0, 0, 1000, 5] = float("inf")
+    k2[0, 2, 1500, 77] = float("-inf")
+    k2[0, 3, 64, 0] = float("nan")
+    k2d = _to_dev(k2, dev)
+    c_f, t_f = ops.scores(qd, k2d, W, 7, "maxpool")
+    try:
+        ops.set_score_engine("valu")
+        c_v, t_v = ops.scores(qd, k2d, W, 7, "maxpool")
+    finally:
+        ops.set_score_engine("auto")
+    torch.cuda.synchronize()
+
+    def canon(x):                                   # NaN payloads / signs are not specified: same NaN positions, same other bits
+        return torch.where(torch.isnan(x), torch.full_like(x, float("nan")).view(torch.int16), x.view(torch.int16))
+
+    assert torch.equal(canon(c_f), canon(c_v)) and torch.equal(canon(t_f), canon(t_v))
+    assert torch.isnan(c_f[0, 0]).any() and not torch.isnan(c_f[0, 1]).any()
