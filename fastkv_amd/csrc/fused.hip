@@ -174,32 +174,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // mfma_phase_mx is exact for finite K only: a NaN among the results (non-finite K or Q) sends the wave back over
-            // the tile with the vector-ALU conversion, whose results are the fmaf chain on any input
-            {
-                bool bad = false;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) bad = bad || acc0[i] != acc0[i] || acc1[i] != acc1[i];
-                if (__any(bad)) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-#pragma unroll 1
-                    for (int ph = 0; ph < NPH; ++ph) {
-#pragma unroll 1
-                        for (int i = 0; i < 8; ++i) {
-                            int jj = key0 + i * 8 + (lane >> 3);
-                            jj = jj < S ? jj : S - 1;
-                            *reinterpret_cast<u32x4 *>(my + (i * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16) =
-                                *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-            }
+            redo_tile_if_nan<NPH>(acc0, acc1, kb, ks_s, key0, S, lane, my, As + lane, n31, sh);
             const int j0 = key0 + n31, j1 = j0 + 32;
             if (key0 + 64 <= n) {
                 // tile entirely among the candidates: no window mask, every column counts; the running maxima stay packed

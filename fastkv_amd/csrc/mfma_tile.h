@@ -161,4 +161,34 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
     }
 }
 
+// mfma_phase_mx is exact for finite K only: a NaN among a tile's results (non-finite K or Q) sends the wave back over the
+// tile with the vector-ALU conversion (synchronous staging through the wave's slab: rare), whose results are the fmaf chain
+// on any input.  `Ap` = the wave's A-operand pointer for phase 0 (As + lane).
+template <int NPH>
+__device__ __forceinline__ void redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, const uint16_t *__restrict__ kb, int64_t ks_s, int key0,
+                                                 int S, int lane, unsigned char *my, const float *Ap, int n31, int sh)
+{
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bad = bad || acc0[i] != acc0[i] || acc1[i] != acc1[i];
+    if (!__any(bad)) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            int jj = key0 + i * 8 + (lane >> 3);
+            jj = jj < S ? jj : S - 1;
+            *reinterpret_cast<u32x4 *>(my + (i * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16) =
+                *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        mfma_phase(acc0, acc1, my, Ap + ph * (DH / 2) * 64, n31, sh);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace fk
