@@ -160,6 +160,8 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     uint32_t *arrive = reinterpret_cast<uint32_t *>(ws + L.off_arrive), *seltab = reinterpret_cast<uint32_t *>(ws + L.off_seltab);
     const size_t nchunks = ((size_t)L.n + 2047) / 2048;
     uint32_t *epoch_bump = nullptr;                          // set when the fused score kernel ran: the compaction advances the epoch
+    // (all_idx != nullptr switches the scoring stage to "identity selection": with score order only the keys are needed, so
+    // the list goes to a scratch row area that nobody reads)
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
                                 select_all ? keys : nullptr, kal, &epoch_bump);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
@@ -179,7 +181,10 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
                           seltab + (size_t)p->B * p->Hkv * nchunks * 32, st);
         if (e != hipSuccess) return FASTKV_ELAUNCH;
     }
-    e = launch_compact(*p, k, k_strides, v, v_strides, idx_asc, keys, by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump);
+    // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction
+    // derives it instead of loading it)
+    e = launch_compact(*p, k, k_strides, v, v_strides, (select_all && by_score) ? nullptr : idx_asc, keys,
+                       by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -46,7 +46,9 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     const int rc = r < cap ? r : cap - 1;
     // selected row, or one of the window rows appended after them (utils.py:118-121); K and V rows of the same
     // position are fetched together (two independent 16-B loads per lane in flight)
-    const int64_t srow = rc < kk ? idx[(size_t)bg * kk + rc] : (int64_t)(n + (rc - kk));
+    // idx == nullptr: every candidate is kept in ascending position (capacity == S), the list is the identity: one
+    // dependent memory round trip less
+    const int64_t srow = rc < kk ? (idx ? idx[(size_t)bg * kk + rc] : (int64_t)rc) : (int64_t)(n + (rc - kk));
     const uint4 kval = *reinterpret_cast<const uint4 *>(ksrc + srow * ks_s + sub * 8);
     const uint4 vval = *reinterpret_cast<const uint4 *>(vsrc + srow * vs_s + sub * 8);
     int d = rc;
