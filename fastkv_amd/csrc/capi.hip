@@ -159,6 +159,12 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     const bool select_all = (kk == L.n);
     uint32_t *arrive = reinterpret_cast<uint32_t *>(ws + L.off_arrive), *seltab = reinterpret_cast<uint32_t *>(ws + L.off_seltab);
     const size_t nchunks = ((size_t)L.n + 2047) / 2048;
+    if (select_all && !by_score && p->tsp_len == 0 && !scores_out) {
+        // capacity == S, ascending order, nothing else asked for: the result does not depend on the scores at all -- K/V are
+        // copied (candidates in position order, then the window rows), one launch
+        hipError_t e0 = launch_compact(*p, k, k_strides, v, v_strides, nullptr, nullptr, kv_idx_out, k_out, v_out, st, nullptr);
+        return e0 == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+    }
     uint32_t *epoch_bump = nullptr;                          // set when the fused score kernel ran: the compaction advances the epoch
     // (all_idx != nullptr switches the scoring stage to "identity selection": with score order only the keys are needed, so
     // the list goes to a scratch row area that nobody reads)

@@ -74,6 +74,9 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
             if (idx_sorted && sub == 0) idx_sorted[(size_t)bg * kk + d] = srow;
         }
     }
+    else if (idx_sorted && !idx && rc < kk && sub == 0) {
+        idx_sorted[(size_t)bg * kk + rc] = srow;               // identity selection in ascending order: the list itself
+    }
     if (r < cap) {
         *reinterpret_cast<uint4 *>(kdst + (size_t)d * (LPR * 8) + sub * 8) = kval;
         *reinterpret_cast<uint4 *>(vdst + (size_t)d * (LPR * 8) + sub * 8) = vval;

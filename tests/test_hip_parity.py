@@ -414,3 +414,16 @@ def test_fused_path_on_special_values(dev):
 
     assert torch.equal(canon(c_f), canon(c_v)) and torch.equal(canon(t_f), canon(t_v))
     assert torch.isnan(c_f[0, 0]).any() and not torch.isnan(c_f[0, 1]).any()
+
+
+def test_keep_all_in_index_order_is_a_copy(dev):
+    """capacity == S with ascending-position order and no TSP: the output is the input's candidates followed by the window
+    rows -- the operator must still return exactly the oracle's K/V/indices (it skips the scoring kernels)."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    q, k, v = make_qkv(77, 2, 8, 2, 1536, 128, 8)
+    want = O.update_kv(q, k, v, 8, 7, "avgpool", 1536, 0, "index")
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    got = ops.update_kv(qd, kd, vd, 8, 7, "avgpool", 1536, 0, "index", return_indices=True)
+    assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1]) and torch.equal(got[3].cpu(), want[2])
+    assert got[2] is None and torch.equal(got[0].cpu(), k)
