@@ -309,6 +309,22 @@ def main():
                                "note": "score_fused = logits (fp32 MFMA) + softmax (2 in-kernel reductions over the head's workgroups) + window-row "
                                        "sum + pooling + head sum in one launch; logits stay in registers, row sums in LDS" if kname == "score_fused"
                                        else "fp32 MFMA contraction; logits written as fp16"}
+            # the same step with the K/V rows in ascending position (FASTKV_KV_ORDER=index; attention does not depend on the row
+            # order): the 16 post-TSP layers keep every candidate and become single copy launches
+            for c in work.clusters:
+                c.kv_order = "index"
+            for _ in range(2):
+                work.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                work.step()
+            torch.cuda.synchronize()
+            ms_idx = (time.perf_counter() - t0) / a.steps * 1e3
+            for c in work.clusters:
+                c.kv_order = "score"
+            out["kv_order_index"] = {"ms_per_step": round(ms_idx, 4), "tokens_per_s": round(CFG["S"] / (ms_idx * 1e-3), 1),
+                                     "note": "rows in ascending position instead of the reference's score order"}
             cc, cms = prof["compact_kv"]
             out["compact"] = {"per_layer_avg_us": round(cms / cc * 1e3, 2),
                               "per_layer_algorithmic_bytes": 2 * (2 * Hkv * CFG["budget"] * D * 2) + Hkv * (CFG["budget"] - W) * 8,
