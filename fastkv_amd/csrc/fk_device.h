@@ -102,12 +102,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
 
-__device__ __forceinline__ f32x2 det_expf2(f32x2 d)
+// NONPOS: the caller guarantees d <= 0 or NaN (softmax arguments x - max), which makes det_expf's clamp of positive
+// arguments dead code
+template <bool NONPOS = false> __device__ __forceinline__ f32x2 det_expf2(f32x2 d)
 {
     const bool ok0 = d.x >= -87.0f, ok1 = d.y >= -87.0f;
     f32x2 dc;
-    dc.x = ok0 ? (d.x > 0.0f ? 0.0f : d.x) : -1.0f;
-    dc.y = ok1 ? (d.y > 0.0f ? 0.0f : d.y) : -1.0f;
+    dc.x = ok0 ? (!NONPOS && d.x > 0.0f ? 0.0f : d.x) : -1.0f;
+    dc.y = ok1 ? (!NONPOS && d.y > 0.0f ? 0.0f : d.y) : -1.0f;
     f32x2 n = dc * splat2(1.44269504088896341f);
     n.x = __builtin_rintf(n.x);
     n.y = __builtin_rintf(n.y);

@@ -265,19 +265,36 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int key0 = (wt0 + t) * 64;                        // >= S when the wave has no tile t: nothing is counted
-        const bool in0 = key0 + n31 < S, in1 = key0 + 32 + n31 < S;
+        if (key0 + 64 <= S) {
+            // full tile: every column counts and x <= max, so no column masks and no clamp; a NaN poisons the row anyway,
+            // whatever its conversion adds to the sums
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-            const f32x2 e = det_expf2(x - splat2(gm[i]));
-            ev[t][0][i] = e.x;
-            ev[t][1][i] = e.y;
-            uint32_t h0, l0, h1, l1;
-            exp_to_fix2(e, h0, l0, h1, l1);
-            const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
-            if ((in0 && nan0) || (in1 && nan1)) nanbits |= 1u << i;
-            ahi[i] += (in0 && !nan0 ? h0 : 0u) + (in1 && !nan1 ? h1 : 0u);
-            alo[i] += (in0 && !nan0 ? l0 : 0u) + (in1 && !nan1 ? l1 : 0u);
+            for (int i = 0; i < 16; ++i) {
+                const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
+                const f32x2 e = det_expf2<true>(x - splat2(gm[i]));
+                ev[t][0][i] = e.x;
+                ev[t][1][i] = e.y;
+                uint32_t h0, l0, h1, l1;
+                exp_to_fix2(e, h0, l0, h1, l1);
+                if (__builtin_isunordered(e.x, e.y)) nanbits |= 1u << i;
+                ahi[i] += h0 + h1;
+                alo[i] += l0 + l1;
+            }
+        } else {
+            const bool in0 = key0 + n31 < S, in1 = key0 + 32 + n31 < S;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
+                const f32x2 e = det_expf2(x - splat2(gm[i]));
+                ev[t][0][i] = e.x;
+                ev[t][1][i] = e.y;
+                uint32_t h0, l0, h1, l1;
+                exp_to_fix2(e, h0, l0, h1, l1);
+                const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
+                if ((in0 && nan0) || (in1 && nan1)) nanbits |= 1u << i;
+                ahi[i] += (in0 && !nan0 ? h0 : 0u) + (in1 && !nan1 ? h1 : 0u);
+                alo[i] += (in0 && !nan0 ? l0 : 0u) + (in1 && !nan1 ? l1 : 0u);
+            }
         }
     }
     FKF_STAMP(3);
