@@ -379,19 +379,23 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
+        const int lp = (w * PER + t) * 64 + n31;                    // local position of column block 0; block 1 is 32 further
 #pragma unroll
-        for (int bk = 0; bk < 2; ++bk) {
-            const int lp = (w * PER + t) * 64 + bk * 32 + n31;      // local position; global candidate lo + lp
+        for (int i4 = 0; i4 < 4; ++i4) {
+            // both column blocks as one packed pair: every operation below is per component what the scalar chain does
+            f32x2 p[4];
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                float p[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) p[u] = h2f(f2h(ev[t][bk][4 * i4 + u] * ri[4 * i4 + u]));
-                float a = 0.0f;
-                a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
-                float c = __shfl_xor(a, 32, 64);                 // upper half: the lower half's sum of rows 0-3
-                c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
-                if (hi) tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c)) : padv;
+            for (int u = 0; u < 4; ++u) {
+                const f32x2 pr = (f32x2){ev[t][0][4 * i4 + u], ev[t][1][4 * i4 + u]} * splat2(ri[4 * i4 + u]);
+                p[u] = (f32x2){h2f(f2h(pr.x)), h2f(f2h(pr.y))};
+            }
+            f32x2 a = splat2(0.0f);
+            a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
+            f32x2 c = {__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
+            c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
+            if (hi) {
+                tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
+                tile[i4][PADMAX + lp + 32] = lo + lp + 32 < n ? h2f(f2h(c.y)) : padv;
             }
         }
     }
