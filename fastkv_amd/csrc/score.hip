@@ -301,13 +301,16 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
             const uint32_t wds[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
             uint32_t outw[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int j = j0 + e, jg = cw.pos0 + j;                              // column, global position
-                uint16_t l16 = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                uint16_t s16 = f2h(scale_div(h2f(l16), sqrtD, rsqrtD));
-                if (jg >= n && (jg - n) > rw) s16 = f2h(h2f(s16) + (-65504.0f));    // utils.py:95-101
-                if (j >= cw.own_lo && j < cw.own_hi) { const float xs = h2f(s16); m = fmaxf(m, xs); sawnan |= (xs != xs); }
-                outw[e >> 1] |= (uint32_t)s16 << ((e & 1) * 16);
+            for (int e = 0; e < 8; e += 2) {                                         // two columns per packed instruction
+                const f32x2 sc = scale_div2((f32x2){h2f((uint16_t)(wds[e >> 1] & 0xffffu)), h2f((uint16_t)(wds[e >> 1] >> 16))}, sqrtD, rsqrtD);
+                uint16_t s2[2] = {f2h(sc.x), f2h(sc.y)};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = j0 + e + h, jg = cw.pos0 + j;                      // column, global position
+                    if (jg >= n && (jg - n) > rw) s2[h] = f2h(h2f(s2[h]) + (-65504.0f));    // utils.py:95-101
+                    if (j >= cw.own_lo && j < cw.own_hi) { const float xs = h2f(s2[h]); m = fmaxf(m, xs); sawnan |= (xs != xs); }
+                }
+                outw[e >> 1] = (uint32_t)s2[0] | ((uint32_t)s2[1] << 16);
             }
             keep[u] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
             // (one GPU, row in one super chunk: the scaled values stay in registers; only the probabilities are stored)
@@ -344,13 +347,19 @@ __global__ void __launch_bounds__(RS_THREADS) row_stats_kernel(uint16_t *__restr
             const int j0 = base + u * (RS_THREADS * 8);
             const uint32_t wds[4] = {keep[u].x, keep[u].y, keep[u].z, keep[u].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                uint16_t hb = (uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                const float ex = det_expf(h2f(hb) - m);
-                ev[u * 8 + e] = ex;
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 ex = det_expf2((f32x2){h2f((uint16_t)(wds[e >> 1] & 0xffffu)), h2f((uint16_t)(wds[e >> 1] >> 16))} - splat2(m));
+                ev[u * 8 + e] = ex.x;
+                ev[u * 8 + e + 1] = ex.y;
+                uint32_t h0, l0, h1, l1;
+                exp_to_fix2(ex, h0, l0, h1, l1);
                 if (j0 + e >= cw.own_lo && j0 + e < cw.own_hi) {
-                    if (ex != ex) nan = 1;
-                    else { uint32_t hi, lo; exp_to_fix(ex, hi, lo); ahi += hi; alo += lo; }
+                    if (ex.x != ex.x) nan = 1;
+                    else { ahi += h0; alo += l0; }
+                }
+                if (j0 + e + 1 >= cw.own_lo && j0 + e + 1 < cw.own_hi) {
+                    if (ex.y != ex.y) nan = 1;
+                    else { ahi += h1; alo += l1; }
                 }
             }
         }
