@@ -10,9 +10,9 @@ namespace fk {
 constexpr int TKA = 256;        // keys per workgroup in score_logits (4 waves x 64 lanes, one key per lane)
 constexpr int SEL_THREADS = 1024;
 constexpr size_t CTRL_BYTES = 8192;  // control block at the start of every operator workspace (fastkv_workspace_init):
-                                     // u64 magic, u32 epoch, then at byte 64 the hand-off flags of the fused score kernel
+                                     // u64 magic, u32 epoch (the rest is reserved)
 constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
-constexpr int FUSED_MAX_WGS = 512;   // workgroups of one fused score launch (2 per CU): sizes its partial records and flags
+constexpr int FUSED_MAX_WGS = 512;   // workgroups of one fused score launch (2 per CU): sizes its hand-off records
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -11,13 +11,14 @@
 // workgroups of the head (row max, then row sum) and the pooling needs `kernel/2` neighbouring positions from the two
 // adjacent workgroups.  All workgroups of the launch are resident at once (the host takes this path only when
 // grid <= 2 workgroups per CU and the occupancy query agrees), so these are in-kernel hand-offs, not kernel boundaries:
-//   * max / sum: every workgroup publishes its 32 partial values as a write-through record, drains the stores, then
-//     writes a flag word = the launch TOKEN; one wave polls the flags of the head's workgroups and everybody reads the
-//     records with sc1 loads.  No fences, no atomics on shared words, order-free integer / max combination.
-//   * halo: 8-byte {token, value} granules, one write-through store each -- the data is the flag.
+//   * max / sum: every workgroup publishes its 32 partial values as 8-byte {token, value} granules, one write-through
+//     (sc1) store each -- the data is the flag; one wave polls granule 0 of the head's workgroups, then everybody reads
+//     the records with sc1 loads and checks the tags.  No fences, no atomics on shared words, order-free integer / max
+//     combination.
+//   * halo: the same granules, one-to-one between adjacent workgroups.
 //   The token is the epoch in the workspace control block + 1 (fastkv_workspace_init zeroes the block once; the
 //   compaction kernel of the same operator call advances the epoch), never a launch argument that a graph replay would
-//   freeze: a flag or granule left by an earlier launch never matches.
+//   freeze: a granule left by an earlier launch never matches.
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 
     // control block (fastkv_workspace_init): a missing initialisation must not turn into a silent wrong answer.  The token
     // of this launch is the epoch left by the previous one + 1 (score_finalize bumps it): never a launch argument, which a
-    // graph replay would freeze; the flags still hold the previous token or the zeros of the initialisation.
+    // graph replay would freeze; the granules in memory still carry earlier tokens (or whatever the allocation held).
     if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
     // (a bijective mix of the epoch, never 0: memory that was never written by this library -- zeros, small integers, fp16
     // data -- does not look like a current granule)
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     if (token == 0u) token = 0x6B43A9B5u;
     FKF_STAMP(0);
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
-    // workgroups of bg: they zero it themselves with write-through stores that are drained before their first flag, so
+    // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record is published, so
     // passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of the selection
     // are touched by later kernels only.
     uint32_t *hist_row = zero_area + (size_t)bg * HIST12;

@@ -65,7 +65,7 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
 /*
  * Call ONCE per workspace allocation (256-B aligned, any size >= 8 KiB), before its first use by
  * `fastkv_update_kv_f16` / `fastkv_score_f16`: the first 8 KiB of an operator workspace are a control block (magic word,
- * call epoch, hand-off flags of the fused scoring kernel) that the library keeps consistent from then on, so no per-call
+ * call epoch of the fused scoring kernel's hand-offs) that the library keeps consistent from then on, so no per-call
  * memset is needed and graph replays are safe.  The call is idempotent (a live control block keeps its epoch), so it may be
  * repeated or end up inside a captured graph.  A workspace that was never initialised makes the scoring kernel trap
  * (a loud HIP error at the next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
