@@ -51,7 +51,7 @@ __device__ __forceinline__ void wait_first_granules(const uint64_t *rec, int str
             ok = ok && ((uint32_t)(__hip_atomic_load(rec + (size_t)l * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 22)) __builtin_trap();          // seconds: a partner never arrived; fail loudly instead of hanging
+        if (++spins > (1u << 25)) __builtin_trap();          // ~10 s: a partner never arrived; fail loudly instead of hanging
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: every load of handed-over bytes is an sc1 load
 }
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 uint32_t spins = 0;
                 while (((x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1u << 22)) __builtin_trap();
+                    if (++spins > (1u << 25)) __builtin_trap();
                 }
                 hv = bits_f32((uint32_t)x);
             }
