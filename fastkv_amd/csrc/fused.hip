@@ -56,7 +56,7 @@ __device__ __forceinline__ void wait_first_granules(const uint64_t *rec, int str
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: every load of handed-over bytes is an sc1 load
 }
 
-template <int D, int PER>
+template <int D, int PER, int NB>
 __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride)
 {
-    constexpr int W = 8, G = 4, NPH = D / DH;
+    // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
+    // rows of one column instead of two columns of one row).  NW = packed words per tile.
+    constexpr int W = 8, G = 4, NPH = D / DH, TK = 32 * NB, NW = 8 * NB;
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
     __shared__ float As[(D / 2) * 64];
     __shared__ float s_f[FUSED_PARTS][32];
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     const int g = blockIdx.x % Hkv, blk = blockIdx.x / Hkv, nblk = gridDim.x / Hkv, b = blockIdx.y;
     const int bg = b * Hkv + g, BG = gridDim.y * Hkv;
     const int n = S - W;
-    const int nwt = (S + 63) / 64;
+    const int nwt = (S + TK - 1) / TK;
     const int wave_id = blk * 4 + w;
     const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
     unsigned char *my = slab[w];
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     KStage sA, sB;
     const int wt0 = wave_id * PER;                       // this wave's tiles: wt0 .. wt0 + PER - 1 (contiguous keys per workgroup)
-    k_fetch(sA, kb, ks_s, (wt0 < nwt ? wt0 : 0) * 64, S, 0, lane);
+    k_fetch<NB>(sA, kb, ks_s, (wt0 < nwt ? wt0 : 0) * TK, S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < QV; ++u) {
@@ -133,29 +135,32 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     __syncthreads();
     {
-        const int first = (wt0 < nwt ? wt0 : 0) * 64;
-        if (NPH >= 2) k_fetch(sB, kb, ks_s, first, S, 1, lane);
-        else if (PER > 1 && wt0 + 1 < nwt) k_fetch(sB, kb, ks_s, (wt0 + 1) * 64, S, 0, lane);
+        const int first = (wt0 < nwt ? wt0 : 0) * TK;
+        if (NPH >= 2) k_fetch<NB>(sB, kb, ks_s, first, S, 1, lane);
+        else if (PER > 1 && wt0 + 1 < nwt) k_fetch<NB>(sB, kb, ks_s, (wt0 + 1) * TK, S, 0, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------------------------------------------------------- phase A: logits of this wave's tiles, row maxima
-    // lg[t][i]: scaled + masked fp16 logits of query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns key0 + n31 (low half)
-    // and key0 + 32 + n31 (high half); mx[i] = running maximum of row m(i) over this lane's columns
+    // lg[t][i]: a packed pair of scaled + masked fp16 logits.  NB == 2: query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns
+    // key0 + n31 (low half) and key0 + 32 + n31 (high half).  NB == 1: rows m(i) (low) and m(i + 8) (high) at column
+    // key0 + n31.  mx[r] = running maximum of row m(r) over this lane's columns
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
-    uint32_t lg[PER][16];
+    uint32_t lg[PER][NW];
     float mx[16];
-    uint32_t mx16[16];                                           // the same for full tiles: packed fp16 pair (column block 0, 1)
+    uint32_t mx16[NW];                                           // the same for full tiles, as packed fp16 pairs
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mx[i] = -INFINITY; mx16[i] = 0xFC00FC00u; }
+    for (int i = 0; i < 16; ++i) mx[i] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mx16[i] = 0xFC00FC00u;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lg[t][i] = 0;
+        for (int i = 0; i < NW; ++i) lg[t][i] = 0;
         const int wt = wt0 + t;
         if (wt < nwt) {
-            const int key0 = wt * 64;
+            const int key0 = wt * TK;
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
@@ -163,27 +168,27 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             for (int ph = 0; ph < NPH; ++ph) {
                 const bool useA = NPH >= 2 ? ((ph & 1) == 0) : ((t & 1) == 0);
                 int nkey, nph;
-                if (NPH == 1) { nkey = (wt + 2) * 64; nph = 0; }
+                if (NPH == 1) { nkey = (wt + 2) * TK; nph = 0; }
                 else if (ph + 2 < NPH) { nkey = key0; nph = ph + 2; }
-                else { nkey = (wt + 1) * 64; nph = ph + 2 - NPH; }
-                const bool more = nkey < nwt * 64 && (NPH == 1 ? t + 2 < PER : (ph + 2 < NPH || t + 1 < PER));
-                if (useA) { k_commit(sA, lane, my); if (more) k_fetch(sA, kb, ks_s, nkey, S, nph, lane); }
-                else { k_commit(sB, lane, my); if (more) k_fetch(sB, kb, ks_s, nkey, S, nph, lane); }
+                else { nkey = (wt + 1) * TK; nph = ph + 2 - NPH; }
+                const bool more = nkey < nwt * TK && (NPH == 1 ? t + 2 < PER : (ph + 2 < NPH || t + 1 < PER));
+                if (useA) { k_commit<NB>(sA, lane, my); if (more) k_fetch<NB>(sA, kb, ks_s, nkey, S, nph, lane); }
+                else { k_commit<NB>(sB, lane, my); if (more) k_fetch<NB>(sB, kb, ks_s, nkey, S, nph, lane); }
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_phase_mx(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
+                mfma_phase_mx<NB>(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            redo_tile_if_nan<NPH>(acc0, acc1, kb, ks_s, key0, S, lane, my, As + lane, n31, sh);
-            const int j0 = key0 + n31, j1 = j0 + 32;
-            if (key0 + 64 <= n) {
+            redo_tile_if_nan<NPH, NB>(acc0, acc1, kb, ks_s, key0, S, lane, my, As + lane, n31, sh);
+            const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
+            if (key0 + TK <= n) {
                 // tile entirely among the candidates: no window mask, every column counts; the running maxima stay packed
                 // fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf) -- vector instructions of this phase are
                 // not hidden behind the MFMAs of the SIMD's other wave, every one of them counts
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(acc1[i]))}, sqrtD, rsqrtD);   // utils.py:94
+                for (int i = 0; i < NW; ++i) {
+                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[(i + 8) & 15]))}, sqrtD, rsqrtD);   // utils.py:94
                     const uint32_t wd = (uint32_t)f2h(sc.x) | ((uint32_t)f2h(sc.y) << 16);
                     mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
                                                                                       __builtin_bit_cast(h16x2, wd)));
@@ -191,22 +196,27 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int rw = (i & 3) + 4 * hi;                                     // window row of query row m(i): m % W
-                    // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both columns of the pair in one packed sequence)
-                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(acc1[i]))}, sqrtD, rsqrtD);
+                for (int i = 0; i < NW; ++i) {
+                    const int rw = (i & 3) + 4 * hi;                                     // window row of both rows of the word: m % W
+                    const int rB = NB == 2 ? i : (i + 8) & 15;
+                    // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both halves of the pair in one packed sequence)
+                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[rB]))}, sqrtD, rsqrtD);
                     uint16_t s0 = f2h(sc.x), s1 = f2h(sc.y);
-                    if (j0 >= n && (j0 - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));       // utils.py:95-101
-                    if (j1 >= n && (j1 - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
-                    if (j0 < S) mx[i] = fmaxf(mx[i], h2f(s0));
-                    if (j1 < S) mx[i] = fmaxf(mx[i], h2f(s1));
+                    if (jA >= n && (jA - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));       // utils.py:95-101
+                    if (jB >= n && (jB - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
+                    if (jA < S) mx[i] = fmaxf(mx[i], h2f(s0));
+                    if (jB < S) mx[rB] = fmaxf(mx[rB], h2f(s1));
                     lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
                 }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx[i] = fmaxf(mx[i], fmaxf(h2f((uint16_t)(mx16[i] & 0xffffu)), h2f((uint16_t)(mx16[i] >> 16))));
+    for (int i = 0; i < NW; ++i) {
+        const int rB = NB == 2 ? i : (i + 8) & 15;
+        mx[i] = fmaxf(mx[i], h2f((uint16_t)(mx16[i] & 0xffffu)));
+        mx[rB] = fmaxf(mx[rB], h2f((uint16_t)(mx16[i] >> 16)));
+    }
     FKF_STAMP(1);
     // row maxima: across the 32 lanes of a half wave, then across the 4 waves, then published
     {
@@ -259,42 +269,54 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     float gm[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) gm[i] = s_row[(i & 3) + 8 * (i >> 2) + 4 * hi];
-    float ev[PER][2][16];
+    float ev[PER][2][NW];
     uint32_t ahi[16], alo[16], nanbits = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; }
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int key0 = (wt0 + t) * 64;                        // >= S when the wave has no tile t: nothing is counted
-        if (key0 + 64 <= S) {
+        const int key0 = (wt0 + t) * TK;                        // >= S when the wave has no tile t: nothing is counted
+        if (key0 + TK <= S) {
             // full tile: every column counts and x <= max, so no column masks and no clamp; a NaN poisons the row anyway,
             // whatever its conversion adds to the sums
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NW; ++i) {
+                const int rB = NB == 2 ? i : (i + 8) & 15;
                 const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-                const f32x2 e = det_expf2<true>(x - splat2(gm[i]));
+                const f32x2 e = det_expf2<true>(x - (f32x2){gm[i], gm[rB]});
                 ev[t][0][i] = e.x;
                 ev[t][1][i] = e.y;
                 uint32_t h0, l0, h1, l1;
                 exp_to_fix2(e, h0, l0, h1, l1);
-                if (__builtin_isunordered(e.x, e.y)) nanbits |= 1u << i;
-                ahi[i] += h0 + h1;
-                alo[i] += l0 + l1;
+                if (NB == 2) {
+                    if (__builtin_isunordered(e.x, e.y)) nanbits |= 1u << i;
+                    ahi[i] += h0 + h1;
+                    alo[i] += l0 + l1;
+                } else {
+                    if (e.x != e.x) nanbits |= 1u << i;
+                    if (e.y != e.y) nanbits |= 1u << rB;
+                    ahi[i] += h0; alo[i] += l0;
+                    ahi[rB] += h1; alo[rB] += l1;
+                }
             }
         } else {
-            const bool in0 = key0 + n31 < S, in1 = key0 + 32 + n31 < S;
+            const bool inA = key0 + n31 < S, inB = NB == 2 ? key0 + 32 + n31 < S : inA;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NW; ++i) {
+                const int rB = NB == 2 ? i : (i + 8) & 15;
                 const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-                const f32x2 e = det_expf2(x - splat2(gm[i]));
+                const f32x2 e = det_expf2(x - (f32x2){gm[i], gm[rB]});
                 ev[t][0][i] = e.x;
                 ev[t][1][i] = e.y;
                 uint32_t h0, l0, h1, l1;
                 exp_to_fix2(e, h0, l0, h1, l1);
                 const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
-                if ((in0 && nan0) || (in1 && nan1)) nanbits |= 1u << i;
-                ahi[i] += (in0 && !nan0 ? h0 : 0u) + (in1 && !nan1 ? h1 : 0u);
-                alo[i] += (in0 && !nan0 ? l0 : 0u) + (in1 && !nan1 ? l1 : 0u);
+                if (inA && nan0) nanbits |= 1u << i;
+                if (inB && nan1) nanbits |= 1u << rB;
+                ahi[i] += inA && !nan0 ? h0 : 0u;
+                alo[i] += inA && !nan0 ? l0 : 0u;
+                ahi[rB] += inB && !nan1 ? h1 : 0u;
+                alo[rB] += inB && !nan1 ? l1 : 0u;
             }
         }
     }
@@ -366,7 +388,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // utils.py:104): the lower half's partial sum crosses to the upper half, which finishes it and owns the result.
     // The workgroup owns the contiguous positions [lo, lo + TWG): the window-row sums hs go to an LDS tile (the K slabs
     // are free now), column pad + local position; candidates past n hold the pooling pad value (utils.py:106,108).
-    constexpr int TWG = 256 * PER, PADMAX = 31, TW = TWG + 2 * PADMAX;
+    constexpr int TWG = 4 * PER * TK, PADMAX = 31, TW = TWG + 2 * PADMAX;
     static_assert(G * TW * sizeof(float) + HIST12 * sizeof(uint32_t) <= sizeof(slab), "phase C/D do not fit the K slabs");
     float(*tile)[TW] = reinterpret_cast<float(*)[TW]>(&slab[0][0]);
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(&slab[0][0] + G * TW * sizeof(float));
@@ -380,14 +402,16 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        const int lp = (w * PER + t) * 64 + n31;                    // local position of column block 0; block 1 is 32 further
+        const int lp = (w * PER + t) * TK + n31;                    // local position of the word's column (NB == 2: block 0; block 1 is 32 further)
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            // both column blocks as one packed pair: every operation below is per component what the scalar chain does
+        for (int i4 = 0; i4 < 2 * NB; ++i4) {
+            // one packed pair per step: every operation below is per component what the scalar chain does.  NB == 2: the two
+            // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
             f32x2 p[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const f32x2 pr = (f32x2){ev[t][0][4 * i4 + u], ev[t][1][4 * i4 + u]} * splat2(ri[4 * i4 + u]);
+                const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
+                const f32x2 pr = (f32x2){ev[t][0][wd], ev[t][1][wd]} * (f32x2){ri[wd], ri[rB]};
                 p[u] = (f32x2){h2f(f2h(pr.x)), h2f(f2h(pr.y))};
             }
             f32x2 a = splat2(0.0f);
@@ -395,8 +419,13 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             f32x2 c = {__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
             c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
             if (hi) {
-                tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
-                tile[i4][PADMAX + lp + 32] = lo + lp + 32 < n ? h2f(f2h(c.y)) : padv;
+                if (NB == 2) {
+                    tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
+                    tile[i4][PADMAX + lp + 32] = lo + lp + 32 < n ? h2f(f2h(c.y)) : padv;
+                } else {
+                    tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
+                    tile[(i4 + 2) & 3][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.y)) : padv;
+                }
             }
         }
     }
@@ -438,9 +467,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // ---------------------------------------------------------------- phase D: pool, sum over the heads, scores + histogram
     // (score_finalize of the three-kernel path, utils.py:105-112), PER positions per thread
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
+    for (int u = 0; u * 256 < TWG; ++u) {
         const int lp = u * 256 + threadIdx.x, j = lo + lp;
-        const bool is_out = j < n;
+        const bool is_out = lp < TWG && j < n;
         float gsum = 0.0f;
         if (is_out) {
             float pv[G];
@@ -468,14 +497,14 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <int D, int PER> static bool fused_resident(int grid_wgs)
+template <int D, int PER, int NB> static bool fused_resident(int grid_wgs)
 {
     static int wgs_per_cu = -1, cus = 0;
     if (wgs_per_cu < 0) {
         int dev = 0, nb = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER>), 256, 0) !=
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB>), 256, 0) !=
                 hipSuccess) {
             wgs_per_cu = 0;
         } else {
@@ -494,7 +523,9 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 {
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
     if (disabled || L.engine != ENGINE_MFMA || L.R != 32 || p.window != 8 || p.H / p.Hkv != 4 || p.kernel > 63) return false;
-    const int nwt = (p.S + 63) / 64;
+    // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
+    const int NBV = (int64_t)p.B * p.Hkv * ((p.S + 63) / 64) <= 512 ? 1 : 2;
+    const int nwt = (p.S + 32 * NBV - 1) / (32 * NBV);
     int nblk = (2 * 256) / (p.Hkv * p.B);
     if (nblk < 1) return false;
     if (nblk > FUSED_MAX_WGS / 8) nblk = FUSED_MAX_WGS / 8;
@@ -513,23 +544,30 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     dim3 grid(nblk * p.Hkv, p.B);
     const int wgs = nblk * p.Hkv * p.B;
     bool resident = false;
-#define FK_RES(DV) (PERT == 1 ? fused_resident<DV, 1>(wgs) : PERT == 2 ? fused_resident<DV, 2>(wgs) : fused_resident<DV, 4>(wgs))
+#define FK_RES2(DV, NBX) (PERT == 1 ? fused_resident<DV, 1, NBX>(wgs) : PERT == 2 ? fused_resident<DV, 2, NBX>(wgs) : fused_resident<DV, 4, NBX>(wgs))
+#define FK_RES(DV) (NBV == 1 ? FK_RES2(DV, 1) : FK_RES2(DV, 2))
     resident = p.D == 64 ? FK_RES(64) : p.D == 128 ? FK_RES(128) : FK_RES(256);
 #undef FK_RES
+#undef FK_RES2
     if (!resident) return false;
     ProfScope ps_(K_FUSED, st);
-#define FK_FUSED(DV, PV)                                                                                                         \
-    hipLaunchKernelGGL((score_fused_kernel<DV, PV>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],           \
-                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, \
+#define FK_FUSED(DV, PV, NBX)                                                                                                    \
+    hipLaunchKernelGGL((score_fused_kernel<DV, PV, NBX>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],      \
+                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum,        \
                        ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride)
-#define FK_FUSED_D(DV)                                                                             \
-    do {                                                                                           \
-        if (PERT == 1) FK_FUSED(DV, 1); else if (PERT == 2) FK_FUSED(DV, 2); else FK_FUSED(DV, 4);  \
+#define FK_FUSED_P(DV, NBX)                                                                                 \
+    do {                                                                                                    \
+        if (PERT == 1) FK_FUSED(DV, 1, NBX); else if (PERT == 2) FK_FUSED(DV, 2, NBX); else FK_FUSED(DV, 4, NBX);  \
+    } while (0)
+#define FK_FUSED_D(DV)                                                   \
+    do {                                                                 \
+        if (NBV == 1) FK_FUSED_P(DV, 1); else FK_FUSED_P(DV, 2);         \
     } while (0)
     if (p.D == 64) FK_FUSED_D(64);
     else if (p.D == 128) FK_FUSED_D(128);
     else FK_FUSED_D(256);
 #undef FK_FUSED_D
+#undef FK_FUSED_P
 #undef FK_FUSED
     *err = hipGetLastError();
     return true;

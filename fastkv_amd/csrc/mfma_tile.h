@@ -35,35 +35,41 @@ struct KStage { u32x4 r0, r1, r2, r3, r4, r5, r6, r7; };
 // One phase of a 64-key tile: 8 x 16 B per lane (lane l: key row i*8 + (l>>3), bytes (l&7)*16 of the 128-B phase slice).
 // Full tiles are buffer loads: ONE per-lane 32-bit offset, the tile base in a wave-uniform descriptor and the row block
 // in the scalar offset; only the ragged last tile clamps the row per lane.  Per-load 64-bit vector addresses for two stages cost 64 VGPRs and spilled.
+// NB = 32-key column blocks per tile: 2 (64-key tiles, the default) or 1 (32-key tiles: twice the waves on short prompts;
+// only registers r0-r3 of a stage are used).
+template <int NB = 2>
 __device__ __forceinline__ void k_fetch(KStage &st, const uint16_t *__restrict__ kb, int64_t ks_s, int key0, int S, int ph, int lane)
 {
-    if (key0 + 64 <= S) {
+    if (key0 + 32 * NB <= S) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint16_t *>(kb + (int64_t)key0 * ks_s + ph * DH), 0, 0x7fffffff, 0x00020000);        // wave-uniform
         const int loff = ((lane >> 3) * (int)ks_s + (lane & 7) * 8) * 2;
         const int step = (int)ks_s * 16;                                                                     // 8 rows, bytes
 #define FK_KLD(i) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (i) * step, 0))
         st.r0 = FK_KLD(0); st.r1 = FK_KLD(1); st.r2 = FK_KLD(2); st.r3 = FK_KLD(3);
-        st.r4 = FK_KLD(4); st.r5 = FK_KLD(5); st.r6 = FK_KLD(6); st.r7 = FK_KLD(7);
+        if (NB == 2) { st.r4 = FK_KLD(4); st.r5 = FK_KLD(5); st.r6 = FK_KLD(6); st.r7 = FK_KLD(7); }
 #undef FK_KLD
     } else {
-        u32x4 t[8];
+        u32x4 t[4 * NB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * NB; ++i) {
             int jj = key0 + i * 8 + (lane >> 3);
             jj = jj < S ? jj : S - 1;
             t[i] = *reinterpret_cast<const u32x4 *>(kb + (int64_t)jj * ks_s + ph * DH + (lane & 7) * 8);
         }
-        st.r0 = t[0]; st.r1 = t[1]; st.r2 = t[2]; st.r3 = t[3]; st.r4 = t[4]; st.r5 = t[5]; st.r6 = t[6]; st.r7 = t[7];
+        st.r0 = t[0]; st.r1 = t[1]; st.r2 = t[2]; st.r3 = t[3];
+        if (NB == 2) { st.r4 = t[4 % (4 * NB)]; st.r5 = t[5 % (4 * NB)]; st.r6 = t[6 % (4 * NB)]; st.r7 = t[7 % (4 * NB)]; }
     }
 }
-__device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned char *my)
+template <int NB = 2> __device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned char *my)
 {
     unsigned char *base = my + (lane >> 3) * ROWB + (lane & 7) * 16;
     *reinterpret_cast<u32x4 *>(base + 0 * 8 * ROWB) = st.r0; *reinterpret_cast<u32x4 *>(base + 1 * 8 * ROWB) = st.r1;
     *reinterpret_cast<u32x4 *>(base + 2 * 8 * ROWB) = st.r2; *reinterpret_cast<u32x4 *>(base + 3 * 8 * ROWB) = st.r3;
-    *reinterpret_cast<u32x4 *>(base + 4 * 8 * ROWB) = st.r4; *reinterpret_cast<u32x4 *>(base + 5 * 8 * ROWB) = st.r5;
-    *reinterpret_cast<u32x4 *>(base + 6 * 8 * ROWB) = st.r6; *reinterpret_cast<u32x4 *>(base + 7 * 8 * ROWB) = st.r7;
+    if (NB == 2) {
+        *reinterpret_cast<u32x4 *>(base + 4 * 8 * ROWB) = st.r4; *reinterpret_cast<u32x4 *>(base + 5 * 8 * ROWB) = st.r5;
+        *reinterpret_cast<u32x4 *>(base + 6 * 8 * ROWB) = st.r6; *reinterpret_cast<u32x4 *>(base + 7 * 8 * ROWB) = st.r7;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -75,19 +81,20 @@ __device__ __forceinline__ void k_commit(const KStage &st, int lane, unsigned ch
 // MFMA make a solo wave run at 85 cycles per MFMA instead of 66 -- so the loop carries nothing else and a SIMD hosts two
 // waves, each filling the other's conversion slots (34 ns per MFMA and SIMD against 29 ns of pure issue).
 struct KGroup { uint4 k0, k1; float a0, a1, a2, a3; };
-__device__ __forceinline__ KGroup read_group(const unsigned char *my, const float *Ap, int n31, int c)
+template <int NB = 2> __device__ __forceinline__ KGroup read_group(const unsigned char *my, const float *Ap, int n31, int c)
 {
     KGroup g;
     g.k0 = *reinterpret_cast<const uint4 *>(my + n31 * ROWB + c * 16);
-    g.k1 = *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16);
+    g.k1 = NB == 2 ? *reinterpret_cast<const uint4 *>(my + (32 + n31) * ROWB + c * 16) : g.k0;
     g.a0 = Ap[(c * 4 + 0) * 64]; g.a1 = Ap[(c * 4 + 1) * 64]; g.a2 = Ap[(c * 4 + 2) * 64]; g.a3 = Ap[(c * 4 + 3) * 64];
     return g;
 }
 struct BGroup { float b0[4], b1[4], a[4]; };
 __device__ __forceinline__ float cvt_lo_hi(uint32_t wd, int sh) { return h2f((uint16_t)((wd >> sh) & 0xffffu)); }
+template <int NB = 2>
 __device__ __forceinline__ void mfma_phase(f32x16 &acc0, f32x16 &acc1, const unsigned char *my, const float *Ap, int n31, int sh)
 {
-    KGroup r1 = read_group(my, Ap, n31, 0), r2 = read_group(my, Ap, n31, 1);
+    KGroup r1 = read_group<NB>(my, Ap, n31, 0), r2 = read_group<NB>(my, Ap, n31, 1);
     BGroup cur;
     {
         const uint32_t w0[4] = {r1.k0.x, r1.k0.y, r1.k0.z, r1.k0.w}, w1[4] = {r1.k1.x, r1.k1.y, r1.k1.z, r1.k1.w};
@@ -99,13 +106,13 @@ __device__ __forceinline__ void mfma_phase(f32x16 &acc0, f32x16 &acc1, const uns
     for (int c = 0; c < 8; ++c) {
         // r2 = raw operands of group c+1 (already requested); request group c+2
         KGroup r3 = r2;
-        if (c + 2 < 8) r3 = read_group(my, Ap, n31, c + 2);
+        if (c + 2 < 8) r3 = read_group<NB>(my, Ap, n31, c + 2);
         BGroup nxt = cur;
         const uint32_t w0[4] = {r2.k0.x, r2.k0.y, r2.k0.z, r2.k0.w}, w1[4] = {r2.k1.x, r2.k1.y, r2.k1.z, r2.k1.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                            // k-step 4c+u: dims 2s (lanes 0-31), 2s+1 (lanes 32-63)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b0[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b1[u], acc1, 0, 0, 0);
+            if (NB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b1[u], acc1, 0, 0, 0);
             if (c + 1 < 8) { nxt.b0[u] = cvt_lo_hi(w0[u], sh); nxt.b1[u] = cvt_lo_hi(w1[u], sh); }
         }
         if (c + 1 < 8) { nxt.a[0] = r2.a0; nxt.a[1] = r2.a1; nxt.a[2] = r2.a2; nxt.a[3] = r2.a3; }
@@ -132,6 +139,7 @@ __device__ __forceinline__ void perm_operands(int lane, f16x8 &p0, f16x8 &p1)
         p1[e] = (_Float16)(delta == 16 + 8 * h + e ? 1.0f : 0.0f);
     }
 }
+template <int NB = 2>
 __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const unsigned char *my, const float *Ap, int n31, int hi,
                                               f16x8 p0, f16x8 p1)
 {
@@ -144,7 +152,7 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
         f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, s0, z, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, s1, d, 0, 0, 0);
     };
-    f32x16 b0 = conv(0, 0), b1 = conv(1, 0);
+    f32x16 b0 = conv(0, 0), b1 = NB == 2 ? conv(1, 0) : z;
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
         f32x16 n0 = b0, n1 = b1;
@@ -154,8 +162,8 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
-            if (ch == 0 && i == 7) { n0 = conv(0, 1); n1 = conv(1, 1); }
+            if (NB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
+            if (ch == 0 && i == 7) { n0 = conv(0, 1); if (NB == 2) n1 = conv(1, 1); }
         }
         b0 = n0; b1 = n1;
     }
@@ -164,20 +172,20 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
 // mfma_phase_mx is exact for finite K only: a NaN among a tile's results (non-finite K or Q) sends the wave back over the
 // tile with the vector-ALU conversion (synchronous staging through the wave's slab: rare), whose results are the fmaf chain
 // on any input.  `Ap` = the wave's A-operand pointer for phase 0 (As + lane).
-template <int NPH>
+template <int NPH, int NB = 2>
 __device__ __forceinline__ void redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, const uint16_t *__restrict__ kb, int64_t ks_s, int key0,
                                                  int S, int lane, unsigned char *my, const float *Ap, int n31, int sh)
 {
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bad = bad || acc0[i] != acc0[i] || acc1[i] != acc1[i];
+    for (int i = 0; i < 16; ++i) bad = bad || acc0[i] != acc0[i] || (NB == 2 && acc1[i] != acc1[i]);
     if (!__any(bad)) return;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
 #pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * NB; ++i) {
             int jj = key0 + i * 8 + (lane >> 3);
             jj = jj < S ? jj : S - 1;
             *reinterpret_cast<u32x4 *>(my + (i * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16) =
@@ -185,7 +193,7 @@ __device__ __forceinline__ void redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, con
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        mfma_phase(acc0, acc1, my, Ap + ph * (DH / 2) * 64, n31, sh);
+        mfma_phase<NB>(acc0, acc1, my, Ap + ph * (DH / 2) * 64, n31, sh);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
