@@ -14,7 +14,7 @@ for S in (32768, 2048):
     torch.cuda.synchronize()
     buf = np.zeros(4096 * 8, dtype=np.uint64)
     lib.fastkv_debug_read_fused_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.size))
-    nw = 2048 if S == 32768 else 8 * 8 * 4
+    nw = 2048 if S == 32768 else 16 * 8 * 4
     st = buf.reshape(4096, 8)[:nw].astype(np.int64)
     t0 = st[:, 0].min()
     rel = (st - t0) * 10 / 1000.0
