@@ -24,7 +24,7 @@ struct Layout {
     int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
     int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
     int ntA;                         // tiles of score_logits
-    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_fpart, off_idx, off_keys, total;
+    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_fpart, off_fchain, off_idx, off_keys, total;
     int zero_words;                  // u32 words from off_hist that row_stats zeroes: histograms + arrival counters
 };
 
@@ -65,6 +65,8 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.zero_words = (int)((o - L.off_hist) / 4);
     L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
     L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum / halo granules
+    // fused score with more than 4 query heads per KV head: per-position head-sum granules between virtual heads
+    L.off_fchain = o; o += (p.H / p.Hkv > 4) ? align_up((size_t)FUSED_MAX_WGS * 1024 * 8, 256) : 0;
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {

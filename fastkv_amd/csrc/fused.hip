@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              uint32_t *__restrict__ zero_area, int zero_words, int ksize, int pooling,
                                                              uint16_t *__restrict__ c_out, int64_t c_row_stride,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
-                                                             int64_t all_key_stride)
+                                                             int64_t all_key_stride, int VH, uint64_t *__restrict__ chain)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.
@@ -77,8 +77,13 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     __shared__ uint32_t s_bad[FUSED_PARTS][32];
     __shared__ float s_row[32];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x % Hkv, blk = blockIdx.x / Hkv, nblk = gridDim.x / Hkv, b = blockIdx.y;
+    // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
+    // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
+    // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
+    const int hv = blockIdx.x % (Hkv * VH), g = hv / VH, vh = hv - g * VH;
+    const int blk = blockIdx.x / (Hkv * VH), nblk = gridDim.x / (Hkv * VH), b = blockIdx.y;
     const int bg = b * Hkv + g, BG = gridDim.y * Hkv;
+    const int bgv = bg * VH + vh;                            // hand-off records are per virtual head
     const int n = S - W;
     const int nwt = (S + TK - 1) / TK;
     const int wave_id = blk * 4 + w;
@@ -100,8 +105,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of the selection
     // are touched by later kernels only.
     uint32_t *hist_row = zero_area + (size_t)bg * HIST12;
-    for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
-        __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (vh == VH - 1)                                        // the group that fills the histogram in phase D
+        for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
+            __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         const int first = BG * HIST12, rest = zero_words - first;
         const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     for (int u = 0; u < QV; ++u) {
         const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
         const int i = rowl / W, r = rowl - i * W;
-        qv[u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)(g * G + i) * qs_h + (int64_t)(n + r) * qs_s + ch * 8);
+        qv[u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)((g * VH + vh) * G + i) * qs_h + (int64_t)(n + r) * qs_s + ch * 8);
     }
     KStage sA, sB;
     const int wt0 = wave_id * PER;                       // this wave's tiles: wt0 .. wt0 + PER - 1 (contiguous keys per workgroup)
@@ -226,8 +232,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's histogram zeros have reached memory
     __syncthreads();
-    uint64_t *pm = pmax + (size_t)bg * nblk * 32;                    // [nblk][32] granules: row maxima
-    uint64_t *psu = psum + (size_t)bg * nblk * 64;                   // [nblk][32][2] granules: row sums, low / high word
+    uint64_t *pm = pmax + (size_t)bgv * nblk * 32;                   // [nblk][32] granules: row maxima
+    uint64_t *psu = psum + (size_t)bgv * nblk * 64;                  // [nblk][32][2] granules: row sums, low / high word
     if (w == 0) {
         if (lane < 32)
             __hip_atomic_store(pm + blk * 32 + lane,
@@ -437,7 +443,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the
     // flag) and reads the neighbours' granules until their tag is this launch's token.  No neighbour = pooling padding.
     {
-        uint64_t *eg = edges + ((size_t)bg * nblk + blk) * (2 * G * PADMAX);
+        uint64_t *eg = edges + ((size_t)bgv * nblk + blk) * (2 * G * PADMAX);
         const int t = threadIdx.x, per_side = G * pad;
         if (t < 2 * per_side) {
             const int side = t >= per_side, q2 = t - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             const int nb = side ? blk + 1 : blk - 1;
             float hv = padv;
             if (nb >= 0 && nb < nblk) {
-                const uint64_t *src = edges + ((size_t)bg * nblk + nb) * (2 * G * PADMAX) + ((side ? 0 : 1) * G + i4) * PADMAX + e;
+                const uint64_t *src = edges + ((size_t)bgv * nblk + nb) * (2 * G * PADMAX) + ((side ? 0 : 1) * G + i4) * PADMAX + e;
                 uint64_t x;
                 uint32_t spins = 0;
                 while (((x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
@@ -466,30 +472,43 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 
     // ---------------------------------------------------------------- phase D: pool, sum over the heads, scores + histogram
     // (score_finalize of the three-kernel path, utils.py:105-112), PER positions per thread
+    uint64_t *chain_in = chain + ((size_t)(bgv - 1) * nblk + blk) * TWG;      // written by virtual head vh - 1 (vh > 0 only)
+    uint64_t *chain_out = chain + ((size_t)bgv * nblk + blk) * TWG;
+    const bool last_vh = vh == VH - 1;
 #pragma unroll
     for (int u = 0; u * 256 < TWG; ++u) {
         const int lp = u * 256 + threadIdx.x, j = lo + lp;
         const bool is_out = lp < TWG && j < n;
         float gsum = 0.0f;
+        if (is_out && vh > 0) {                              // the head sum so far: {token, fp32 bits} granule of this position
+            uint64_t x;
+            uint32_t spins = 0;
+            while ((uint32_t)((x = __hip_atomic_load(chain_in + lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 25)) __builtin_trap();
+            }
+            gsum = bits_f32((uint32_t)x);
+        }
         if (is_out) {
             float pv[G];
 #pragma unroll
             for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], PADMAX + lp, pad, ksize, avg);
 #pragma unroll
             for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
+            if (!last_vh) __hip_atomic_store(chain_out + lp, granule(token, f32_bits(gsum)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint16_t c16 = f2h(gsum);
-        if (is_out) {
+        if (is_out && last_vh) {
             c_out[(size_t)bg * c_row_stride + j] = c16;
             if (all_idx) {                                   // capacity == S: identity selection + keys (see score_finalize)
                 all_idx[(size_t)bg * n + j] = (int64_t)j;
                 if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
             }
         }
-        if (want_hist) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
+        if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
     }
-    if (all_keys && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
-    if (want_hist) {
+    if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
+    if (want_hist && last_vh) {
         __syncthreads();
         for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
     }
@@ -522,11 +541,12 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err)
 {
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
-    if (disabled || L.engine != ENGINE_MFMA || L.R != 32 || p.window != 8 || p.H / p.Hkv != 4 || p.kernel > 63) return false;
+    const int G = p.H / p.Hkv, VH = G / 4;                     // virtual heads of 4 query heads per KV head
+    if (disabled || L.engine != ENGINE_MFMA || p.window != 8 || G % 4 != 0 || VH > 8 || p.kernel > 63) return false;
     // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
-    const int NBV = (int64_t)p.B * p.Hkv * ((p.S + 63) / 64) <= 512 ? 1 : 2;
+    const int NBV = (int64_t)p.B * p.Hkv * VH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
     const int nwt = (p.S + 32 * NBV - 1) / (32 * NBV);
-    int nblk = (2 * 256) / (p.Hkv * p.B);
+    int nblk = (2 * 256) / (p.Hkv * p.B * VH);
     if (nblk < 1) return false;
     if (nblk > FUSED_MAX_WGS / 8) nblk = FUSED_MAX_WGS / 8;
     if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
@@ -534,15 +554,16 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     if (per > 4) return false;
     const int PERT = per <= 1 ? 1 : per <= 2 ? 2 : 4;          // tiles per wave the kernel is instantiated for
     nblk = (nwt + PERT * 4 - 1) / (PERT * 4);                   // a workgroup owns 4*PERT consecutive tiles
-    if ((size_t)p.B * p.Hkv * nblk > FUSED_MAX_WGS) return false;
+    if ((size_t)p.B * p.Hkv * VH * nblk > FUSED_MAX_WGS) return false;
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);
     const uint32_t *ctrl = reinterpret_cast<const uint32_t *>(ws);
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [wg][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
-    dim3 grid(nblk * p.Hkv, p.B);
-    const int wgs = nblk * p.Hkv * p.B;
+    dim3 grid(nblk * p.Hkv * VH, p.B);
+    const int wgs = nblk * p.Hkv * VH * p.B;
+    uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [wg][positions of a workgroup] head-sum granules (VH > 1)
     bool resident = false;
 #define FK_RES2(DV, NBX) (PERT == 1 ? fused_resident<DV, 1, NBX>(wgs) : PERT == 2 ? fused_resident<DV, 2, NBX>(wgs) : fused_resident<DV, 4, NBX>(wgs))
 #define FK_RES(DV) (NBV == 1 ? FK_RES2(DV, 1) : FK_RES2(DV, 2))
@@ -554,7 +575,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 #define FK_FUSED(DV, PV, NBX)                                                                                                    \
     hipLaunchKernelGGL((score_fused_kernel<DV, PV, NBX>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],      \
                        (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum,        \
-                       ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride)
+                       ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain)
 #define FK_FUSED_P(DV, NBX)                                                                                 \
     do {                                                                                                    \
         if (PERT == 1) FK_FUSED(DV, 1, NBX); else if (PERT == 2) FK_FUSED(DV, 2, NBX); else FK_FUSED(DV, 4, NBX);  \

@@ -281,6 +281,11 @@ def test_arithmetic_contract_on_gpu(dev):
     dict(B=1, H=8, Hkv=2, S=2500, D=256, W=8, ks=5, pooling="maxpool", cap=300, tsp_len=0),
     dict(B=1, H=32, Hkv=8, S=65536, D=128, W=8, ks=7, pooling="maxpool", cap=4096, tsp_len=8192),
     dict(B=2, H=16, Hkv=4, S=5003, D=128, W=8, ks=31, pooling="avgpool", cap=700, tsp_len=1500),
+    # 8 and 12 query heads per KV head (Llama-3-70B geometry; one tensor-parallel rank of it at 32k): the fused kernel runs
+    # two / three virtual heads per KV head and chains their head sums
+    dict(B=1, H=16, Hkv=2, S=3100, D=128, W=8, ks=7, pooling="maxpool", cap=500, tsp_len=1000),
+    dict(B=2, H=12, Hkv=1, S=1500, D=64, W=8, ks=5, pooling="avgpool", cap=1500, tsp_len=0),
+    dict(B=1, H=8, Hkv=1, S=32768, D=128, W=8, ks=7, pooling="maxpool", cap=2048, tsp_len=2048),
 ])
 def test_large_and_unusual_shapes_bit_exact(shape, dev):
     from fastkv_amd import ops
