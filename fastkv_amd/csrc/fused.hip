@@ -245,18 +245,20 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     {
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
-            uint64_t rec[FUSED_MAX_WGS / 8 / FUSED_PARTS];           // nblk <= FUSED_MAX_WGS / 8; all loads in flight together
-#pragma unroll
-            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-                const int bl = part + u * FUSED_PARTS;
-                rec[u] = __hip_atomic_load(pm + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             float v = -INFINITY;
             bool ok = true;
+            for (int base = 0; base < nblk; base += 8 * FUSED_PARTS) {    // 64 producers per round, 8 loads per thread in flight
+                uint64_t rec[8];
 #pragma unroll
-            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-                ok = ok && (uint32_t)(rec[u] >> 32) == token;
-                v = fmaxf(v, bits_f32((uint32_t)rec[u]));
+                for (int u = 0; u < 8; ++u) {
+                    const int bl = base + part + u * FUSED_PARTS;
+                    rec[u] = __hip_atomic_load(pm + (bl < nblk ? bl : blk) * 32 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ok = ok && (uint32_t)(rec[u] >> 32) == token;
+                    v = fmaxf(v, bits_f32((uint32_t)rec[u]));
+                }
             }
             s_f[part][row] = v;
             if (__syncthreads_and(ok)) break;
@@ -356,22 +358,24 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     {
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
-            uint64_t rl[FUSED_MAX_WGS / 8 / FUSED_PARTS], rh[FUSED_MAX_WGS / 8 / FUSED_PARTS];
-#pragma unroll
-            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-                const int bl = part + u * FUSED_PARTS;
-                const uint64_t *g2 = psu + (bl < nblk ? bl : blk) * 64 + row * 2;
-                rl[u] = __hip_atomic_load(g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rh[u] = __hip_atomic_load(g2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             uint64_t s2 = 0;
             uint32_t bad = 0;
             bool ok = true;
+            for (int base = 0; base < nblk; base += 8 * FUSED_PARTS) {
+                uint64_t rl[8], rh[8];
 #pragma unroll
-            for (int u = 0; u < FUSED_MAX_WGS / 8 / FUSED_PARTS; ++u) {
-                ok = ok && (uint32_t)(rl[u] >> 32) == token && (uint32_t)(rh[u] >> 32) == token;
-                const uint64_t v = ((rh[u] & 0xffffffffull) << 32) | (rl[u] & 0xffffffffull);
-                if (part + u * FUSED_PARTS < nblk) { if (v == FK_SUM_POISON) bad = 1; else s2 += v; }
+                for (int u = 0; u < 8; ++u) {
+                    const int bl = base + part + u * FUSED_PARTS;
+                    const uint64_t *g2 = psu + (bl < nblk ? bl : blk) * 64 + row * 2;
+                    rl[u] = __hip_atomic_load(g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rh[u] = __hip_atomic_load(g2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ok = ok && (uint32_t)(rl[u] >> 32) == token && (uint32_t)(rh[u] >> 32) == token;
+                    const uint64_t v = ((rh[u] & 0xffffffffull) << 32) | (rl[u] & 0xffffffffull);
+                    if (base + part + u * FUSED_PARTS < nblk) { if (v == FK_SUM_POISON) bad = 1; else s2 += v; }
+                }
             }
             s_u[part][row] = s2;
             s_bad[part][row] = bad;
@@ -548,7 +552,6 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     const int nwt = (p.S + 32 * NBV - 1) / (32 * NBV);
     int nblk = (2 * 256) / (p.Hkv * p.B * VH);
     if (nblk < 1) return false;
-    if (nblk > FUSED_MAX_WGS / 8) nblk = FUSED_MAX_WGS / 8;
     if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
     const int per = (nwt + nblk * 4 - 1) / (nblk * 4);
     if (per > 4) return false;
