@@ -178,7 +178,7 @@ __device__ __forceinline__ void redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, con
 {
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bad = bad || acc0[i] != acc0[i] || (NB == 2 && acc1[i] != acc1[i]);
+    for (int i = 0; i < 16; ++i) bad = bad || (NB == 2 ? __builtin_isunordered(acc0[i], acc1[i]) : acc0[i] != acc0[i]);   // one compare per pair
     if (!__any(bad)) return;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
