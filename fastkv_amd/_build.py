@@ -38,11 +38,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get("FASTKV_CXXFLAGS", "").split()          # measurement builds only (e.g. -DFK_STAMP)
-    cmd = [hipcc(), *HIPCC_FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # several ranks of one node may get here together: one builds (to a temporary name, then an atomic rename), the others
+    # wait on the lock and find the library up to date
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            extra = os.environ.get("FASTKV_CXXFLAGS", "").split()          # measurement builds only (e.g. -DFK_STAMP)
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            cmd = [hipcc(), *HIPCC_FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
