@@ -24,6 +24,7 @@
 #include "prof.h"
 #include "mfma_tile.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace fk {
 
@@ -574,6 +575,30 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 #undef FK_RES
 #undef FK_RES2
     if (!resident) return false;
+    // Two fused launches must never overlap on a GPU (each needs ALL its workgroups resident).  Within this process the
+    // library sees to it: when a launch comes on another stream than the previous one, an event recorded on the previous
+    // stream (now: behind everything submitted there so far) makes the new stream wait.  Nothing is added while the
+    // caller stays on one stream; inside a stream capture the chain is skipped (see include/fastkv_hip.h).
+    {
+        static std::mutex mtx;
+        static hipStream_t last_stream[16];
+        static bool have_last[16];
+        static hipEvent_t chain_ev[16];
+        int dev = 0;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && hipStreamIsCapturing(st, &cs) == hipSuccess &&
+            cs == hipStreamCaptureStatusNone) {
+            std::lock_guard<std::mutex> lk(mtx);
+            if (have_last[dev] && last_stream[dev] != st) {
+                if (!chain_ev[dev]) (void)hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming);
+                if (chain_ev[dev] && hipEventRecord(chain_ev[dev], last_stream[dev]) == hipSuccess)
+                    (void)hipStreamWaitEvent(st, chain_ev[dev], 0);
+                (void)hipGetLastError();                         // a destroyed previous stream is not this call's error
+            }
+            last_stream[dev] = st;
+            have_last[dev] = true;
+        }
+    }
     ProfScope ps_(K_FUSED, st);
 #define FK_FUSED(DV, PV, NBX)                                                                                                    \
     hipLaunchKernelGGL((score_fused_kernel<DV, PV, NBX>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],      \

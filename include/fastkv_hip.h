@@ -69,8 +69,10 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  * memset is needed and graph replays are safe.  The call is idempotent (a live control block keeps its epoch), so it may be
  * repeated or end up inside a captured graph.  A workspace that was never initialised makes the scoring kernel trap
  * (a loud HIP error at the next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
- * The fused scoring kernel also needs all its workgroups resident at once: do not run two scoring calls concurrently on
- * one GPU (set FASTKV_FUSED=0 to take the three-kernel path if you must).
+ * The fused scoring kernel also needs all its workgroups resident at once, so two of them must not overlap on one GPU:
+ * calls on different streams of ONE process are chained by the library (an event dependency when the stream changes);
+ * calls from different processes sharing a GPU, or graphs replayed concurrently on several streams, must set
+ * FASTKV_FUSED=0 (the three-kernel path).
  */
 int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 

@@ -464,3 +464,25 @@ def test_randomised_shapes_bit_exact(dev):
         assert torch.equal(got[3].cpu(), want[2]), tag
         assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1]), tag
         assert (got[2] is None and want[3] is None) or torch.equal(got[2].cpu(), want[3]), tag
+
+
+def test_two_streams_are_serialised_by_the_library(dev):
+    """The fused scoring kernel of one call must not overlap with another one's on the GPU; calls issued on two streams of
+    this process without any synchronisation between them still give the oracle's result (an event chain in the library)."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    case = CASES["cfg2_max"]
+    shapes = (case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+    data = [make_qkv(910 + i, *shapes) for i in range(2)]
+    devd = [tuple(_to_dev(t, dev) for t in d) for d in data]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(3):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = ops.update_kv(*devd[i], case["W"], case["ks"], case["pooling"], case["cap"], 0, "score", return_indices=True)
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        want = O.update_kv(*data[i], case["W"], case["ks"], case["pooling"], case["cap"], 0, "score")
+        assert torch.equal(outs[i][0].cpu(), want[0]) and torch.equal(outs[i][3].cpu(), want[2])
