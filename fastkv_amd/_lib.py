@@ -25,7 +25,7 @@ class SPWindow(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("ncols", "pos0", "own_lo", "own_hi", "S_glob", "Sp")]
 
 
-EXPORTS = ["fastkv_workspace_bytes", "fastkv_workspace_init", "fastkv_update_kv_f16", "fastkv_score_f16", "fastkv_select_f16",
+EXPORTS = ["fastkv_workspace_bytes", "fastkv_workspace_init", "fastkv_update_kv_f16", "fastkv_update_kv_strided_f16", "fastkv_score_f16", "fastkv_select_f16",
            "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_head_sum_f16", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
            "fastkv_sp_scores_f16", "fastkv_debug_contract", "fastkv_profile_enable",
            "fastkv_profile_kernels", "fastkv_profile_kernel_name", "fastkv_profile_read", "fastkv_strerror", "fastkv_version"]
@@ -53,6 +53,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_workspace_init.restype = ctypes.c_int
     L.fastkv_update_kv_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, vp, vp, vp, vp, vp, sz, vp]
     L.fastkv_update_kv_f16.restype = ci
+    L.fastkv_update_kv_strided_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, vp, i64p, vp, vp, vp, vp, sz, vp]
+    L.fastkv_update_kv_strided_f16.restype = ci
     L.fastkv_score_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, vp, vp, sz, vp]
     L.fastkv_score_f16.restype = ci
     L.fastkv_select_f16.argtypes = [vp, i64, i64, i64, i64, ci, ci, vp, vp, sz, vp]

@@ -131,6 +131,17 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
                          int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out, void *workspace,
                          size_t workspace_bytes, void *stream)
 {
+    return fastkv_update_kv_strided_f16(p, q, q_strides, k, k_strides, v, v_strides, k_out, v_out, nullptr, kv_idx_out, tsp_idx_out,
+                                        scores_out, workspace, workspace_bytes, stream);
+}
+
+int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
+                                 const int64_t k_strides[4], const void *v, const int64_t v_strides[4], void *k_out, void *v_out,
+                                 const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (out_strides && ((out_strides[0] & 7) || (out_strides[1] & 7) || (out_strides[2] & 7) || out_strides[2] < (p ? p->D : 0)))
+        return FASTKV_EINVAL;                                  // 16-B aligned rows, at least D elements apart
     int rc;
     if ((rc = check_problem(p)) != FASTKV_OK) return rc;
     if ((rc = check_select(p)) != FASTKV_OK) return rc;
@@ -162,7 +173,7 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     if (select_all && !by_score && p->tsp_len == 0 && !scores_out) {
         // capacity == S, ascending order, nothing else asked for: the result does not depend on the scores at all -- K/V are
         // copied (candidates in position order, then the window rows), one launch
-        hipError_t e0 = launch_compact(*p, k, k_strides, v, v_strides, nullptr, nullptr, kv_idx_out, k_out, v_out, st, nullptr);
+        hipError_t e0 = launch_compact(*p, k, k_strides, v, v_strides, nullptr, nullptr, kv_idx_out, k_out, v_out, st, nullptr, out_strides);
         return e0 == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
     }
     uint32_t *epoch_bump = nullptr;                          // set when the fused score kernel ran: the compaction advances the epoch
@@ -190,7 +201,7 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
     // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction
     // derives it instead of loading it)
     e = launch_compact(*p, k, k_strides, v, v_strides, (select_all && by_score) ? nullptr : idx_asc, keys,
-                       by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump);
+                       by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump, out_strides);
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

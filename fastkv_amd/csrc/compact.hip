@@ -26,7 +26,8 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
                                                          const int64_t *__restrict__ idx, const uint16_t *__restrict__ keys,
                                                          int64_t *__restrict__ idx_sorted, int Hkv, int S, int W, int cap,
                                                          int keys_in_lds, uint16_t *__restrict__ k_out,
-                                                         uint16_t *__restrict__ v_out, uint32_t *__restrict__ epoch_bump)
+                                                         uint16_t *__restrict__ v_out, uint32_t *__restrict__ epoch_bump,
+                                                         int64_t os_b, int64_t os_h, int64_t os_r)
 {
     // last kernel of the operator: advance the workspace epoch after a fused score launch (fused.hip)
     if (epoch_bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -38,8 +39,9 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     const int bg = blockIdx.y, b = bg / Hkv, g = bg % Hkv;
     const uint16_t *ksrc = k + b * ks_b + (int64_t)g * ks_h;
     const uint16_t *vsrc = v + b * vs_b + (int64_t)g * vs_h;
-    uint16_t *kdst = k_out + (size_t)bg * cap * (LPR * 8);
-    uint16_t *vdst = v_out + (size_t)bg * cap * (LPR * 8);
+    // output [B,Hkv,cap,D] with element strides (os_b, os_h, os_r): contiguous, or a window of a larger cache slab
+    uint16_t *kdst = k_out + b * os_b + g * os_h;
+    uint16_t *vdst = v_out + b * os_b + g * os_h;
     const int kk = cap - W, n = S - W;
     const int sub = threadIdx.x % LPR;
     const int r = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -78,18 +80,20 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
         idx_sorted[(size_t)bg * kk + rc] = srow;               // identity selection in ascending order: the list itself
     }
     if (r < cap) {
-        *reinterpret_cast<uint4 *>(kdst + (size_t)d * (LPR * 8) + sub * 8) = kval;
-        *reinterpret_cast<uint4 *>(vdst + (size_t)d * (LPR * 8) + sub * 8) = vval;
+        *reinterpret_cast<uint4 *>(kdst + (int64_t)d * os_r + sub * 8) = kval;
+        *reinterpret_cast<uint4 *>(vdst + (int64_t)d * os_r + sub * 8) = vval;
     }
 }
 
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
-                          hipStream_t st, uint32_t *epoch_bump)
+                          hipStream_t st, uint32_t *epoch_bump, const int64_t *out_strides)
 {
     const int lpr = p.D / 8;
     const int rows_per_block = 256 / lpr;
     dim3 grid((p.capacity + rows_per_block - 1) / rows_per_block, p.B * p.Hkv);
+    const int64_t os_r = out_strides ? out_strides[2] : p.D, os_h = out_strides ? out_strides[1] : (int64_t)p.capacity * p.D;
+    const int64_t os_b = out_strides ? out_strides[0] : (int64_t)p.Hkv * p.capacity * p.D;
     ProfScope ps_(K_COMPACT, st);
     const size_t kal = ((size_t)(p.capacity - p.window) + 7) & ~(size_t)7;
     const int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                // 32 KiB of LDS at most
@@ -97,7 +101,7 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
 #define FK_COMPACT(LPRV)                                                                                                   \
     hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), dyn, st, (const uint16_t *)k, ks[0], ks[1], ks[2],       \
                        (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \
-                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out, epoch_bump)
+                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out, epoch_bump, os_b, os_h, os_r)
     if (lpr == 8) FK_COMPACT(8);
     else if (lpr == 16) FK_COMPACT(16);
     else FK_COMPACT(32);

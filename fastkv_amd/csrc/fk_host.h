@@ -103,7 +103,7 @@ hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, c
 // idx_sorted_out (optional) receives the indices in that order
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
-                          hipStream_t st, uint32_t *epoch_bump = nullptr);
+                          hipStream_t st, uint32_t *epoch_bump = nullptr, const int64_t *out_strides = nullptr);
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
                               int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st);
 

@@ -83,17 +83,27 @@ def _check_qkv(q, k, v=None):
 
 def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, kernel_size: int, pooling: str,
               capacity: int, tsp_len: int = 0, order: str = "score", return_indices: bool = False,
-              return_scores: bool = False):
+              return_scores: bool = False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Compress branch of FastKVCluster.update_kv (utils.py:93-132) in one stream-ordered call.
 
-    Returns (k_out [B,Hkv,cap,D], v_out, tsp_idx [B,tsp_len] int64 | None[, kv_idx][, scores])."""
+    Returns (k_out [B,Hkv,cap,D], v_out, tsp_idx [B,tsp_len] int64 | None[, kv_idx][, scores]).
+    `out` = (k_buf, v_buf): write the compacted rows into these [B,Hkv,cap,D] fp16 views instead of fresh tensors (unit
+    head_dim stride, other strides multiples of 8 -- e.g. `slab[:, :, :cap]` of a pre-sized cache slab)."""
     _check_qkv(q, k, v)
     L = load()
     p = _problem(q, k, window, kernel_size, pooling, capacity, tsp_len, order)
     B, Hkv, D = p.B, p.Hkv, p.D
     dev = q.device
-    ko = torch.empty(B, Hkv, capacity, D, dtype=torch.float16, device=dev)
-    vo = torch.empty_like(ko)
+    if out is None:
+        ko = torch.empty(B, Hkv, capacity, D, dtype=torch.float16, device=dev)
+        vo = torch.empty_like(ko)
+    else:
+        ko, vo = out
+        _require_cuda(ko, vo)
+        if tuple(ko.shape) != (B, Hkv, capacity, D) or ko.shape != vo.shape or ko.stride() != vo.stride() or ko.stride(3) != 1 \
+                or ko.dtype != torch.float16 or vo.dtype != torch.float16:
+            raise ValueError("fastkv_amd: out must be two [B,Hkv,capacity,D] fp16 views with equal strides and unit head_dim stride")
+    ostr = (ctypes.c_int64 * 3)(*ko.stride()[:3])
     tsp = torch.empty(B, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
     kv_idx = torch.empty(B, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
     sc = torch.empty(B, Hkv, p.S - window, dtype=torch.float16, device=dev) if return_scores else None
@@ -101,8 +111,8 @@ def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, ke
     if nbytes == 0:
         check(-1, "workspace_bytes")
     ws = _workspace(nbytes, dev)
-    rc = L.fastkv_update_kv_f16(ctypes.byref(p), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), v.data_ptr(),
-                                _strides(v), ko.data_ptr(), vo.data_ptr(),
+    rc = L.fastkv_update_kv_strided_f16(ctypes.byref(p), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), v.data_ptr(),
+                                _strides(v), ko.data_ptr(), vo.data_ptr(), ostr,
                                 kv_idx.data_ptr() if kv_idx is not None else None,
                                 tsp.data_ptr() if tsp is not None else None,
                                 sc.data_ptr() if sc is not None else None, ws.data_ptr(), ws.numel(), _stream())

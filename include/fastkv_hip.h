@@ -94,6 +94,19 @@ int fastkv_update_kv_f16(const fastkv_problem *p,
                          void *scores_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The same with strided outputs: k_out / v_out are [B,Hkv,capacity,D] views with element strides out_strides =
+ * {batch, head, row} (row >= D, all multiples of 8; NULL = contiguous), e.g. the first `capacity` rows of a pre-sized
+ * per-layer cache slab [B,Hkv,capacity + max_new_tokens,D]: the compaction then IS the cache write (the reference goes
+ * through `past_key_value.update(...)`, a torch.cat copy, baselines/fastkv/llama_model.py:142).
+ */
+int fastkv_update_kv_strided_f16(const fastkv_problem *p,
+                                 const void *q, const int64_t q_strides[4],
+                                 const void *k, const int64_t k_strides[4],
+                                 const void *v, const int64_t v_strides[4],
+                                 void *k_out, void *v_out, const int64_t out_strides[3], int64_t *kv_idx_out,
+                                 int64_t *tsp_idx_out, void *scores_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Stage 1 alone: window-attention scores (utils.py:93-112 [+ :127 head sum]).
  *   scores_out      fp16 [B,Hkv,S-window] contiguous
  *   tsp_scores_out  optional fp16 [B,S-window]

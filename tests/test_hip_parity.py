@@ -486,3 +486,24 @@ def test_two_streams_are_serialised_by_the_library(dev):
     for i in (0, 1):
         want = O.update_kv(*data[i], case["W"], case["ks"], case["pooling"], case["cap"], 0, "score")
         assert torch.equal(outs[i][0].cpu(), want[0]) and torch.equal(outs[i][3].cpu(), want[2])
+
+
+def test_compaction_into_a_cache_slab(dev):
+    """out=(k_view, v_view): the compacted rows land directly in the first `capacity` rows of a pre-sized cache slab
+    [B,Hkv,capacity+64,D] (SURVEY 8(f)#1: the compaction is the cache write); the rest of the slab is untouched."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    case = CASES["cfg1"]
+    q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+    want = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "score")
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    cap = case["cap"]
+    kslab = torch.full((case["B"], case["Hkv"], cap + 64, case["D"]), 7.0, dtype=torch.float16, device=dev)
+    vslab = torch.full_like(kslab, -3.0)
+    got = ops.update_kv(qd, kd, vd, case["W"], case["ks"], case["pooling"], cap, case["tsp_len"], "score",
+                        out=(kslab[:, :, :cap], vslab[:, :, :cap]))
+    torch.cuda.synchronize()
+    assert got[0].data_ptr() == kslab.data_ptr()
+    assert torch.equal(kslab[:, :, :cap].cpu(), want[0]) and torch.equal(vslab[:, :, :cap].cpu(), want[1])
+    assert torch.all(kslab[:, :, cap:] == 7.0) and torch.all(vslab[:, :, cap:] == -3.0)
+    assert torch.equal(got[2].cpu(), want[3])
