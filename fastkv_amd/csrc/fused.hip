@@ -1,5 +1,5 @@
-// Fused window scoring for the common geometry (G*W == 32 query rows per KV head, W == 8, rows short enough that a wave
-// keeps the logits of all its tiles in registers): ONE launch replaces score_logits + row_stats + score_finalize
+// Fused window scoring for the common geometries (window W == 8, G = 4, 8, 12, ... query heads per KV head, rows short
+// enough that a wave keeps the logits of all its tiles in registers): ONE launch replaces score_logits + row_stats + score_finalize
 // (/root/reference/baselines/fastkv/utils.py:93-112).  The 16 MiB of logits of the 32k shape never leave the registers
 // and the window-row sums never leave LDS; what reaches memory is the score tensor c[b,g,j] (0.5 MiB) and its histogram.
 //
@@ -7,7 +7,9 @@
 // the matrix pipe -> fp16 -> true division by sqrt(D) -> fp16 -> window mask -> row max -> det_expf -> 2^-40 fixed-point
 // sum -> p = fp16(e * (1/sum)) -> sequential fp32 sum over the window rows -> fp16 -> pool -> fp16 -> head sum -> fp16.
 //
-// A workgroup owns 4*PER consecutive 64-key tiles of one (batch, kv head).  The softmax needs two reductions over ALL
+// A workgroup owns 4*PER consecutive tiles (64 keys, or 32 on short prompts: NB) of one (batch, kv head, virtual head of
+// 4 query heads = the 32 rows of one fp32 MFMA block; more query heads per KV head are more virtual heads, chained in
+// phase D).  The softmax needs two reductions over ALL
 // workgroups of the head (row max, then row sum) and the pooling needs `kernel/2` neighbouring positions from the two
 // adjacent workgroups.  All workgroups of the launch are resident at once (the host takes this path only when
 // grid <= 2 workgroups per CU and the occupancy query agrees), so these are in-kernel hand-offs, not kernel boundaries:
@@ -16,7 +18,7 @@
 //     the records with sc1 loads and checks the tags.  No fences, no atomics on shared words, order-free integer / max
 //     combination.
 //   * halo: the same granules, one-to-one between adjacent workgroups.
-//   The token is the epoch in the workspace control block + 1 (fastkv_workspace_init zeroes the block once; the
+//   The token is a mix of the epoch in the workspace control block (fastkv_workspace_init zeroes the block once; the
 //   compaction kernel of the same operator call advances the epoch), never a launch argument that a graph replay would
 //   freeze: a granule left by an earlier launch never matches.
 #include "fk_device.h"
