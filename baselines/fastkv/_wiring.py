@@ -14,8 +14,19 @@ import torch
 from transformers.cache_utils import DynamicCache
 from transformers.modeling_outputs import BaseModelOutputWithPast
 
+import os
+
 from fastkv_amd import ops
+from fastkv_amd.cache import FastKVSlabCache, SlabLayer
 from fastkv_amd.cluster import init_fastkv
+
+
+def make_cache(config):
+    """DynamicCache as in the reference, or (FASTKV_SLAB_CACHE=1) pre-sized per-layer slabs that the compaction writes
+    into directly and decode steps append to in place (fastkv_amd/cache.py)."""
+    if os.environ.get("FASTKV_SLAB_CACHE", "0") == "1":
+        return FastKVSlabCache(config.num_hidden_layers, reserve=int(os.environ.get("FASTKV_SLAB_RESERVE", "256")))
+    return DynamicCache(config=config)
 
 
 def make_attention_class(base_cls, modeling, extra_attn_kwargs):
@@ -39,8 +50,16 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
 
             if past_key_values is not None:
                 if q_len > 1:                                     # prefill: compress what goes into the cache
-                    k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
-                                                                       self.num_key_value_groups, self.layer_idx)
+                    layers = getattr(past_key_values, "layers", None)
+                    slab = layers[self.layer_idx] if layers is not None and self.layer_idx < len(layers) else None
+                    if isinstance(slab, SlabLayer) and key_states.is_cuda and getattr(self.kv_cluster, "supports_out_factory", False):
+                        # the compaction writes straight into the layer's cache slab; `update` then only adopts the rows
+                        k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
+                                                                           self.num_key_value_groups, self.layer_idx,
+                                                                           out_factory=slab.prefill_views)
+                    else:
+                        k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
+                                                                           self.num_key_value_groups, self.layer_idx)
                     past_key_values.update(k_c, v_c, self.layer_idx)
                 else:                                             # decode: plain append
                     key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
@@ -92,7 +111,7 @@ def make_model_forward(modeling, mask_fn_for):
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
         if use_cache and past_key_values is None:
-            past_key_values = DynamicCache(config=self.config)
+            past_key_values = make_cache(self.config)
         if position_ids is None:
             past_seen = past_key_values.get_seq_length() if past_key_values is not None else 0
             position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + past_seen).unsqueeze(0)

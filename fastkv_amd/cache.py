@@ -1,0 +1,81 @@
+"""Pre-sized per-layer K/V cache slabs.
+
+The reference hands the compressed K/V to `past_key_value.update(...)` (/root/reference/baselines/fastkv/llama_model.py:142),
+which in transformers' DynamicLayer is a `torch.cat` -- one more copy of every kept row at prefill, and a re-allocation +
+copy of the WHOLE layer cache at every decode step.  `SlabLayer` owns one `[B,Hkv,capacity + reserve,D]` buffer per layer:
+the HIP compaction writes its rows straight into it (`FastKVCluster.update_kv(..., out_factory=layer.prefill_views)` ->
+`fastkv_update_kv_strided_f16`), decode steps append one row in place, and attention reads the `[:, :, :len]` view.
+Drop-in for `DynamicCache` in greedy decoding (`update`, `get_seq_length`, `get_mask_sizes`); pure torch, device-agnostic.
+"""
+from __future__ import annotations
+
+import torch
+from transformers.cache_utils import Cache, DynamicLayer
+
+
+class SlabLayer(DynamicLayer):
+    def __init__(self, reserve: int = 256):
+        super().__init__()
+        self.reserve = reserve
+        self.kslab = self.vslab = None
+        self.len = 0
+
+    def _alloc(self, B, H, rows, D, dtype, device):
+        self.kslab = torch.empty(B, H, rows, D, dtype=dtype, device=device)
+        self.vslab = torch.empty_like(self.kslab)
+        self.dtype, self.device = dtype, device
+        self.is_initialized = True
+
+    def _views(self):
+        self.keys = self.kslab[:, :, :self.len]
+        self.values = self.vslab[:, :, :self.len]
+        return self.keys, self.values
+
+    def prefill_views(self, B, H, rows, D, dtype, device):
+        """[B,H,rows,D] views of the slab at the current end, for a producer that writes the rows itself; they become part
+        of the cache when passed to `update`."""
+        if self.kslab is None:
+            self._alloc(B, H, rows + self.reserve, D, dtype, device)
+        elif self.len + rows > self.kslab.shape[2]:
+            self._grow(self.len + rows + self.reserve)
+        return self.kslab[:, :, self.len:self.len + rows], self.vslab[:, :, self.len:self.len + rows]
+
+    def _grow(self, rows):
+        k, v = self.kslab, self.vslab
+        self._alloc(k.shape[0], k.shape[1], rows, k.shape[3], k.dtype, k.device)
+        self.kslab[:, :, :self.len].copy_(k[:, :, :self.len])
+        self.vslab[:, :, :self.len].copy_(v[:, :, :self.len])
+
+    def update(self, key_states, value_states, *args, **kwargs):
+        n = key_states.shape[-2]
+        if self.kslab is None:
+            B, H, _, D = key_states.shape
+            self._alloc(B, H, n + self.reserve, D, key_states.dtype, key_states.device)
+        elif self.len > 0 and (self.keys is None or self.keys.shape[-2] != self.len or
+                               self.keys.data_ptr() != self.kslab.data_ptr()):
+            # someone replaced keys / values through the base-class API (crop, reorder, ...): rebuild the slab from them
+            k, v = self.keys, self.values
+            self.len = k.shape[-2]
+            self._alloc(k.shape[0], k.shape[1], self.len + n + self.reserve, k.shape[3], k.dtype, k.device)
+            self.kslab[:, :, :self.len].copy_(k)
+            self.vslab[:, :, :self.len].copy_(v)
+        if self.len + n > self.kslab.shape[2]:
+            self._grow(2 * (self.len + n))
+        dst_k = self.kslab[:, :, self.len:self.len + n]
+        in_place = key_states.data_ptr() == dst_k.data_ptr() and key_states.stride() == dst_k.stride() and \
+            value_states.data_ptr() == self.vslab[:, :, self.len:self.len + n].data_ptr()
+        if not in_place:
+            dst_k.copy_(key_states)
+            self.vslab[:, :, self.len:self.len + n].copy_(value_states)
+        self.len += n
+        return self._views()
+
+    def get_seq_length(self) -> int:
+        return self.len
+
+
+class FastKVSlabCache(Cache):
+    """`DynamicCache` stand-in made of `SlabLayer`s (one per decoder layer)."""
+
+    def __init__(self, num_layers: int, reserve: int = 256):
+        super().__init__(layers=[SlabLayer(reserve) for _ in range(num_layers)])

@@ -79,17 +79,26 @@ class FastKVCluster:
         return Plan(False, self.max_capacity_prompt, tsp)
 
     # ------------------------------------------------------------------ the operator
-    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups, layer_idx):
-        # `attention_mask` and `layer_idx` are accepted and ignored, as in the reference (utils.py:99)
+    supports_out_factory = True
+
+    def update_kv(self, key_states, query_states, value_states, attention_mask, num_key_value_groups, layer_idx, *,
+                  out_factory=None):
+        # `attention_mask` and `layer_idx` are accepted and ignored, as in the reference (utils.py:99).
+        # out_factory (keyword only, not in the reference): callable (B, Hkv, capacity, D, dtype, device) -> (k_view, v_view)
+        # asked for the output buffers once the capacity is known, e.g. fastkv_amd.cache.SlabLayer.prefill_views
         assert key_states.shape[-2] == query_states.shape[-2]
         q_len = query_states.shape[2]
         plan = self.plan(q_len)
         if plan.early_out:
             return key_states, value_states, None
         assert query_states.shape[1] == key_states.shape[1] * num_key_value_groups
+        out = None
+        if out_factory is not None:
+            B, Hkv, _, D = key_states.shape
+            out = out_factory(B, Hkv, plan.capacity, D, key_states.dtype, key_states.device)
         k_out, v_out, tsp_indices = ops.update_kv(query_states, key_states, value_states, self.window_size,
                                                   self.kernel_size, self.pooling, plan.capacity, plan.tsp_len,
-                                                  self.kv_order)
+                                                  self.kv_order, out=out)
         return k_out, v_out, tsp_indices
 
 

@@ -167,3 +167,41 @@ def test_e2e_driver_cpu():
     res = e2e.run(a)[0]
     assert res["final_cache_len_layer0"] == 48 + 4                   # budget + the 4 decoded tokens
     assert res["throughput_tok_s"] > 0
+
+
+def test_slab_cache_matches_dynamic_cache(monkeypatch):
+    """FASTKV_SLAB_CACHE=1 (fastkv_amd/cache.py: pre-sized per-layer slabs, decode appends in place) must be invisible:
+    prefill + three greedy decode steps give the same logits and cache lengths as with DynamicCache."""
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import prefill
+    from fastkv_amd.cache import FastKVSlabCache, SlabLayer
+    ids = torch.randint(0, 1000, (1, 150))
+    runs = {}
+    for slab in ("0", "1"):
+        monkeypatch.setenv("FASTKV_SLAB_CACHE", slab)
+        monkeypatch.setenv("FASTKV_SLAB_RESERVE", "2")                  # forces a slab growth during the decode steps
+        a = _args(method="fastkv", max_capacity_prompts=40, tsp_len=80, tsp_idx=1)
+        a.context_lengths = [150]
+        replace_llama("fastkv")
+        torch.manual_seed(11)
+        model = prefill.build_model(a, "cpu")
+        set_model(model, a)
+        for layer in model.model.layers:
+            layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+        logits, lens = [], []
+        with torch.no_grad():
+            out = model(ids, attention_mask=torch.ones_like(ids))
+            pkv = out.past_key_values
+            logits.append(out.logits)
+            for step in range(3):
+                nxt = logits[-1][:, -1].argmax(-1, keepdim=True)
+                out = model(nxt, past_key_values=pkv, position_ids=torch.tensor([[150 + step]]))
+                logits.append(out.logits)
+                lens.append([int(pkv.layers[i].keys.shape[-2]) for i in range(4)])
+        runs[slab] = (logits, lens, pkv)
+    assert isinstance(runs["1"][2], FastKVSlabCache) and isinstance(runs["1"][2].layers[0], SlabLayer)
+    assert not isinstance(runs["0"][2], FastKVSlabCache)
+    assert runs["0"][1] == runs["1"][1] and runs["1"][1][-1] == [43, 43, 43, 43]
+    for x, y in zip(runs["0"][0], runs["1"][0]):
+        assert torch.equal(x, y)
+    assert runs["1"][2].get_seq_length() == 43
