@@ -507,3 +507,32 @@ def test_compaction_into_a_cache_slab(dev):
     assert torch.equal(kslab[:, :, :cap].cpu(), want[0]) and torch.equal(vslab[:, :, :cap].cpu(), want[1])
     assert torch.all(kslab[:, :, cap:] == 7.0) and torch.all(vslab[:, :, cap:] == -3.0)
     assert torch.equal(got[2].cpu(), want[3])
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=1, H=32, Hkv=8, S=2048, D=128, ks=7, pooling="maxpool"),          # the post-TSP layers of the 32k configuration
+    dict(B=2, H=16, Hkv=4, S=1111, D=64, ks=5, pooling="avgpool"),
+    dict(B=1, H=16, Hkv=2, S=3000, D=128, ks=7, pooling="maxpool"),          # 8 query heads per KV head (two virtual heads)
+    dict(B=1, H=8, Hkv=2, S=700, D=256, ks=3, pooling="avgpool"),
+])
+def test_keep_all_layers_bit_exact(shape, dev):
+    """capacity == S without a TSP index (the post-TSP layers): same K/V, same index order as the oracle, in both row orders,
+    also into a strided cache slab."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    s = shape
+    q, k, v = make_qkv(4242, s["B"], s["H"], s["Hkv"], s["S"], s["D"], 8)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    for order in ("score", "index"):
+        want = O.update_kv(q, k, v, 8, s["ks"], s["pooling"], s["S"], 0, order, return_scores=True)
+        got = ops.update_kv(qd, kd, vd, 8, s["ks"], s["pooling"], s["S"], 0, order, return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), order
+        assert torch.equal(got[3].cpu(), want[2]), order
+        assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1]), order
+    kslab = torch.zeros(s["B"], s["Hkv"], s["S"] + 40, s["D"], dtype=torch.float16, device=dev)
+    vslab = torch.zeros_like(kslab)
+    ops.update_kv(qd, kd, vd, 8, s["ks"], s["pooling"], s["S"], 0, "score", out=(kslab[:, :, :s["S"]], vslab[:, :, :s["S"]]))
+    want = O.update_kv(q, k, v, 8, s["ks"], s["pooling"], s["S"], 0, "score")
+    assert torch.equal(kslab[:, :, :s["S"]].cpu(), want[0]) and torch.equal(vslab[:, :, :s["S"]].cpu(), want[1])
+    assert not kslab[:, :, s["S"]:].any()
