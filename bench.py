@@ -17,6 +17,10 @@ Extra objects in the JSON line:
   kernels       every kernel: launches per step, average microseconds (same instrumented replay).
   compact       the KV gather/compact kernel: per-layer latency at this config and GB/s at the "roofline shape"
                 (same row geometry, 32 layers' worth in one launch, beyond the 256 MiB Infinity Cache).
+  fp32_pipe_view  the same dominant-kernel launches priced against the FP32 matrix pipe (the contraction is an fp32 fma chain).
+  seq_sharded_weak / seq_sharded_128k / tp  (N>1 only, by default) the paths with a real exchange step, each run in a freshly
+                spawned child process per rank (own rendezvous port), so that a failing collective cannot take this line down:
+                ONE prompt of N*32k tokens sharded on the sequence axis; ONE 128k prompt over N shards; Llama-3-70B heads over N ranks.
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's update_kv) timed on this box's host cores on a
                 bounded sample of the same workload.
 """
@@ -98,28 +102,34 @@ def profile_read(lib):
 
 def compact_roofline_shape(lib, dev, steps):
     """Same row geometry as the 32k config (256-B rows at 2 KiB pitch, 2040+8 rows per head) but 32 'layers' in one
-    launch: 2 x 2 GiB sources, 539 MB of algorithmic traffic, nothing served from the 256 MiB Infinity Cache."""
+    launch: 2 x 2 GiB sources, 539 MB of algorithmic traffic, nothing served from the 256 MiB Infinity Cache.
+    Both row orders: `index` (rows in ascending position: a pure gather) and `score` (the reference's order, utils.py:113:
+    the kernel also ranks the winners by their keys -- what the product's default path runs)."""
     from fastkv_amd import ops
     B, Hkv, S, D, W, cap = 32, CFG["Hkv"], CFG["S"], CFG["D"], CFG["window"], CFG["budget"]
     k = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
     v = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
     sc = torch.rand(B * Hkv, S - W, device=dev).half()
-    idx = ops.select(sc, cap - W, "score").view(B, Hkv, cap - W).contiguous()     # realistic per-head index sets
-    for _ in range(2):
-        ops.compact(k, v, idx, W)
-    torch.cuda.synchronize()
-    profile_read(lib)
-    lib.fastkv_profile_enable(1)
-    for _ in range(steps):
-        ops.compact(k, v, idx, W)
-    torch.cuda.synchronize()
-    lib.fastkv_profile_enable(0)
-    cnt, ms = profile_read(lib)["compact_kv"]
+    idx = ops.select(sc, cap - W, "index").view(B, Hkv, cap - W).contiguous()     # realistic per-head index sets
+    sc3 = sc.view(B, Hkv, S - W)
     nbytes = 2 * (2 * B * Hkv * cap * D * 2) + B * Hkv * (cap - W) * 8
-    us = ms / cnt * 1e3
+    res = {"shape": f"B={B} (32 layers stacked), Hkv={Hkv}, S={S}, D={D}, cap={cap}", "bytes": nbytes}
+    for order, kw in (("index", {}), ("score", {"scores": sc3})):
+        for _ in range(2):
+            ops.compact(k, v, idx, W, **kw)
+        torch.cuda.synchronize()
+        profile_read(lib)
+        lib.fastkv_profile_enable(1)
+        for _ in range(steps):
+            ops.compact(k, v, idx, W, **kw)
+        torch.cuda.synchronize()
+        lib.fastkv_profile_enable(0)
+        cnt, ms = profile_read(lib)["compact_kv"]
+        us = ms / cnt * 1e3
+        res[order] = {"avg_us": round(us, 2), "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1),
+                      "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
     del k, v
-    return {"shape": f"B={B} (32 layers stacked), Hkv={Hkv}, S={S}, D={D}, cap={cap}", "bytes": nbytes, "avg_us": round(us, 2),
-            "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1), "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+    return res
 
 
 def cpu_baseline(work: HotPathPrefill):
@@ -204,14 +214,128 @@ def whole_model_ttft(work):
     return res
 
 
+# ------------------------------------------------------------------------------------------------- multi-GPU legs
+LEGS = ("seq_sharded_weak", "seq_sharded_128k", "tp")
+N_LEG_LAYERS = CFG["tsp_idx"] + 1          # the 16 layers that see the whole prompt; the last one is the TSP layer
+
+
+def _leg_inputs(H, Hkv, S, dev, gen):
+    D = CFG["D"]
+    return [(torch.randn(1, S, H, D, generator=gen, device=dev, dtype=torch.float16).transpose(1, 2),
+             torch.randn(1, S, Hkv, D, generator=gen, device=dev, dtype=torch.float16).transpose(1, 2),
+             torch.randn(1, S, Hkv, D, generator=gen, device=dev, dtype=torch.float16).transpose(1, 2)) for _ in range(N_LEG_LAYERS)]
+
+
+def run_leg(name, steps, rank, world, dev, dist):
+    """One multi-GPU leg inside an initialised process group; returns the leg's JSON object (every rank computes it,
+    rank 0 reports it).  Timing: barrier + synchronize on both sides of exactly `steps` steps, max over ranks."""
+    import fastkv_amd.dist as FD
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2000 + rank)
+    W, ks, pooling, cap, tsp = CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], CFG["tsp_len"]
+    if name.startswith("seq_sharded"):
+        S_r = CFG["S"] if name == "seq_sharded_weak" else 131072 // world
+        S_glob = S_r * world
+        layers = _leg_inputs(CFG["H"], CFG["Hkv"], S_r, dev, gen)
+        lo = FD.HipLocalOps()
+        lens = [S_r] * world
+
+        def step():
+            for i, (q, k, v) in enumerate(layers):
+                FD.sp_update_kv(k, q, v, window_size=W, kernel_size=ks, pooling=pooling, capacity=cap,
+                                tsp_len=tsp if i == N_LEG_LAYERS - 1 else 0, order="score", local_ops=lo, shard_lengths=lens)
+        info = {"prompt_tokens": S_glob, "tokens_per_rank": S_r, "scaling": "weak" if name == "seq_sharded_weak" else "strong",
+                "collectives_per_layer": 4, "kv_rows": "stay on the rank that owns them (no K/V bytes on the fabric)"}
+    else:
+        if 8 % world:
+            return {"skipped": f"8 KV heads do not split over {world} ranks"}
+        Hkv_l, H_l, S_glob = 8 // world, 64 // world, CFG["S"]
+        layers = _leg_inputs(H_l, Hkv_l, S_glob, dev, gen)
+        lo = FD.HipTPOps()
+
+        def step():
+            for i, (q, k, v) in enumerate(layers):
+                FD.tp_update_kv(k, q, v, window_size=W, kernel_size=ks, pooling=pooling, capacity=cap,
+                                tsp_len=tsp if i == N_LEG_LAYERS - 1 else 0, order="score", local_ops=lo)
+        info = {"prompt_tokens": S_glob, "geometry": f"Llama-3-70B heads (H=64, Hkv=8) over {world} ranks: {H_l} query / {Hkv_l} KV heads each",
+                "scaling": "strong", "collectives_per_step": 1}
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    c0 = sum(FD.COLLECTIVES.values())
+    for _ in range(2):
+        step()
+    barrier()
+    c1 = sum(FD.COLLECTIVES.values())
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ms = float(tt.item()) / steps * 1e3
+    info.update({"layers": N_LEG_LAYERS, "steps": steps, "ms_per_step": round(ms, 3), "tokens_per_s": round(S_glob / (ms * 1e-3), 1),
+                 "collectives_per_step_measured": (c1 - c0) // 2, "backend": dist.get_backend()})
+    return info
+
+
+def leg_child_main(a):
+    """`bench.py --leg NAME`: one rank of one leg, started by a rank of the main run (same RANK / WORLD_SIZE, own port)."""
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    try:
+        res = run_leg(a.leg, a.steps, rank, world, dev, dist)
+    finally:
+        dist.destroy_process_group()
+    if rank == 0:
+        print("LEG_JSON " + json.dumps(res), flush=True)
+
+
+def spawn_leg(name, idx, steps, rank, timeout_s=240):
+    """Start this rank's child for leg `name` and wait for it; returns the leg object (rank 0) or a status."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 101 + idx)
+    for key in list(env):
+        # the child is NOT a worker of the launcher's agent: with TORCHELASTIC_USE_AGENT_STORE inherited it would look for the
+        # agent's store on the new port and wait for ever; without it rank 0's child hosts a fresh store there
+        if key.startswith("TORCHELASTIC_"):
+            env.pop(key)
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--gpus", os.environ.get("WORLD_SIZE", "1"), "--steps", str(steps)]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()                                                  # exactly the child this rank started
+        so, se = proc.communicate()
+        return {"error": f"leg timed out after {timeout_s} s on rank {rank}", "stderr_tail": se[-400:]}
+    if proc.returncode != 0:
+        return {"error": f"leg exited with code {proc.returncode} on rank {rank}", "stderr_tail": se[-600:]}
+    for line in so.splitlines():
+        if line.startswith("LEG_JSON "):
+            return json.loads(line[len("LEG_JSON "):])
+    return {"status": "ok (no report on this rank)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seq-sharded", action="store_true", help="N>1: also time ONE prompt of N*32k tokens sharded on the sequence "
-                                                                "axis (fastkv_amd.dist.sp_update_kv) and add it as `seq_sharded`")
+    ap.add_argument("--no-legs", action="store_true", help="N>1: skip the sequence-sharded / tensor-parallel legs")
+    ap.add_argument("--leg", choices=LEGS, default=None, help="internal: run ONE multi-GPU leg in this (child) process")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented replay / roofline-shape / CPU legs")
     ap.add_argument("--no-ttft", action="store_true", help="skip the whole-model TTFT leg (random-init Llama-3-8B, fastkv vs fullkv)")
     a = ap.parse_args()
@@ -221,13 +345,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback for the product path)"
+    if a.leg:
+        return leg_child_main(a)
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo": two ranks on one GPU (test boxes with a single device)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo": several ranks on one GPU (test boxes with a single device)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -277,11 +403,10 @@ def main():
         kern = {n: {"launches_per_step": c / a.steps, "avg_us": round(ms / c * 1e3, 2), "us_per_step": round(ms / a.steps * 1e3, 1)}
                 for n, (c, ms) in prof.items() if c}
         out["kernels"] = kern
-        # dominant kernel: score_logits at S=32768 (the 16 post-TSP launches stream only 4 MiB each -> time-weighted split)
+        # dominant kernel: the scoring launch at S=32768 (the 16 post-TSP launches stream only 4 MiB each)
         S, Hkv, D, H, W = CFG["S"], CFG["Hkv"], CFG["D"], CFG["H"], CFG["window"]
         if rank == 0:
             lib.fastkv_profile_enable(1)
-            q, k, v = work.layers_in[0]
             from fastkv_amd import ops
             for i in range(8):
                 ops.scores(*work.layers_in[i][:2], W, CFG["kernel"], CFG["pooling"], want_tsp=False)
@@ -291,24 +416,30 @@ def main():
             kname = "score_fused" if p2.get("score_fused", (0, 0))[0] else "score_logits"
             c, ms = p2[kname]
             us = ms / c * 1e3
-            alg = Hkv * S * D * 2 + H * W * D * 2
+            alg = Hkv * S * D * 2 + H * W * D * 2                # K once + the window queries
             flops = 2.0 * H * W * D * S                         # fp32 fma chain: H*W query rows x S keys x D
-            traffic = None
+            traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(kname + "_hbm_bytes_per_launch")
-            # The contraction must be an fp32 fma chain in ascending head-dim order (bit-exact parity with the CPU oracle), so
-            # it runs on v_mfma_f32_32x32x2_f32: 32 flop per K byte -> the matrix pipe (157.3 TFLOP/s), not HBM, is the
-            # resource that bounds this kernel; the HBM view of the same launch is reported beside it.
-            out["roofline"] = {"kernel": kname + " (S=32768 launches)", "bound": "mfma",
-                               "achieved": round(flops / (us * 1e-6) / 1e12, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
-                               "hbm_view": {"achieved_GBps": round(alg / (us * 1e-6) / 1e9, 1), "peak_GBps": HBM_PEAK_GBPS,
-                                            "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
+                tj = json.load(open(tpath))
+                traffic, tsrc = tj.get(kname + "_hbm_bytes_per_launch"), tj.get("source")
+            # Headline = the HBM view SURVEY.md 8(d) names: algorithmic bytes of the dominant kernel / its average launch
+            # duration (HIP events on the launch stream, measured in THIS run) against the 8 TB/s peak.
+            out["roofline"] = {"kernel": kname + " (S=32768 launches)", "bound": "hbm",
+                               "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                               "traffic_static": True, "traffic_source": tsrc or "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                               "WRITE_SIZE passes, corrected per guide; NOT measured in this run)",
+                               "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
                                "note": "score_fused = logits (fp32 MFMA) + softmax (2 in-kernel reductions over the head's workgroups) + window-row "
                                        "sum + pooling + head sum in one launch; logits stay in registers, row sums in LDS" if kname == "score_fused"
                                        else "fp32 MFMA contraction; logits written as fp16"}
+            # The contraction must be an fp32 fma chain in ascending head-dim order (bit-exact parity with the CPU oracle), so it
+            # runs on v_mfma_f32_32x32x2_f32 (32 flop per K byte): the FP32 pipe saturates long before HBM does.  Measured
+            # (tools/probes/probe_overlap.hip): vector-ALU work does not overlap the fp32 MFMAs of a SIMD, the two add up.
+            out["fp32_pipe_view"] = {"kernel": kname, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
+                                     "peak_TFLOPs": FP32_MATRIX_PEAK_TFLOPS, "frac": round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                     "flop_per_launch": flops}
             # the same step with the K/V rows in ascending position (FASTKV_KV_ORDER=index; attention does not depend on the row
             # order): the 16 post-TSP layers keep every candidate and become single copy launches
             for c in work.clusters:
@@ -328,45 +459,27 @@ def main():
             cc, cms = prof["compact_kv"]
             out["compact"] = {"per_layer_avg_us": round(cms / cc * 1e3, 2),
                               "per_layer_algorithmic_bytes": 2 * (2 * Hkv * CFG["budget"] * D * 2) + Hkv * (CFG["budget"] - W) * 8,
+                              "per_layer_order": "score (the reference's row order: the product default)",
                               "roofline_shape": compact_roofline_shape(lib, dev, 10)}
             if world == 1 and not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(work)
             if world == 1 and not a.no_ttft:
                 out["ttft"] = whole_model_ttft(work)
-    if dist is not None and a.seq_sharded:
-        # (opt-in: `--seq-sharded`; the RCCL path of this leg has only been exercised with gloo so far, and a rank that fails
-        # inside a collective would take the contract line down with it.)  The path with a real exchange step: ONE prompt of world*32768 tokens sharded on the sequence axis (rank r holds
-        # positions [r*S, (r+1)*S)), pre-TSP layers only (after TSP the 2048 surviving tokens fit one GPU).  Per layer:
-        # window-query/K-halo all-gather, MAX and fixed-point SUM all-reduces, the candidate (index) all-gather, and the
-        # all-reduce that replicates the compacted K/V rows.  Results are bit-identical to one GPU (tests/test_dist_*).
-        from fastkv_amd.dist import HipLocalOps, sp_update_kv
-        lo = HipLocalOps()
-        lens = [CFG["S"]] * world
-
-        def seq_step():
-            for i in range(CFG["tsp_idx"] + 1):
-                q, k, v = work.layers_in[i]
-                sp_update_kv(k, q, v, window_size=CFG["window"], kernel_size=CFG["kernel"], pooling=CFG["pooling"],
-                             capacity=CFG["budget"], tsp_len=CFG["tsp_len"] if i == CFG["tsp_idx"] else 0, order="score",
-                             local_ops=lo, shard_lengths=lens)
-        for _ in range(2):
-            seq_step()
-        barrier()
-        t0 = time.perf_counter()
-        nseq = max(3, a.steps // 4)
-        for _ in range(nseq):
-            seq_step()
-        barrier()
-        dts = time.perf_counter() - t0
-        tt = torch.tensor([dts], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms_seq = float(tt.item()) / nseq * 1e3
-        out["seq_sharded"] = {"prompt_tokens": world * CFG["S"], "layers": CFG["tsp_idx"] + 1, "ms_per_step": round(ms_seq, 3),
-                              "tokens_per_s": round(world * CFG["S"] / (ms_seq * 1e-3), 1), "collectives_per_layer": 5,
-                              "note": "one prompt sharded on the sequence axis; bit-identical to single GPU"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and not a.no_legs:
+        # The paths with a real exchange step, each in a freshly spawned child process per rank: a rank that
+        # dies or hangs inside a collective costs that leg, never the contract line.  This process has released its process
+        # group and its tensors; it only waits.
+        del work
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        for i, name in enumerate(LEGS):
+            res = spawn_leg(name, i, max(3, a.steps // 4), rank)
+            if rank == 0:
+                out[name] = res
     if rank == 0:
         print(json.dumps(out))
 

@@ -12,11 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfastkv_hip.so")
-SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "capi.hip", "debug.hip", "prof.hip"]
+SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "sp.hip", "capi.hip", "debug.hip", "prof.hip"]
 HEADERS = ["fk_device.h", "fk_host.h", "prof.h", "rank.h", "mfma_tile.h", os.path.join("..", "..", "include", "fastkv_hip.h")]
 # -ffp-contract=off: the arithmetic contract (csrc/fk_device.h) spells every fma out; nothing may be fused or split
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-result"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-result"]
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 
 def hipcc() -> str:
@@ -26,29 +26,55 @@ def hipcc() -> str:
     return exe
 
 
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def _compile_one(src: str, extra, verbose: bool) -> str:
+    """One translation unit -> object file (kept under lib/obj so that an edit of one kernel file recompiles that file only)."""
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    stamp = obj + ".flags"
+    flags = " ".join(HIPCC_FLAGS + list(extra))
+    newest = max(os.path.getmtime(d) for d in [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS])
+    if os.path.exists(obj) and os.path.getmtime(obj) >= newest and os.path.exists(stamp) and open(stamp).read() == flags:
+        return obj
+    cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(flags)
+    return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     # several ranks of one node may get here together: one builds (to a temporary name, then an atomic rename), the others
     # wait on the lock and find the library up to date
     import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not needs_build():
                 return LIB
             extra = os.environ.get("FASTKV_CXXFLAGS", "").split()          # measurement builds only (e.g. -DFK_STAMP)
+            if force:
+                for f in os.listdir(OBJDIR):
+                    os.remove(os.path.join(OBJDIR, f))
+            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+                objs = list(ex.map(lambda s: _compile_one(s, extra, verbose), SOURCES))
             tmp = LIB + ".tmp.%d" % os.getpid()
-            cmd = [hipcc(), *HIPCC_FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
+            cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -26,8 +26,9 @@ class SPWindow(ctypes.Structure):
 
 
 EXPORTS = ["fastkv_workspace_bytes", "fastkv_workspace_init", "fastkv_update_kv_f16", "fastkv_update_kv_strided_f16", "fastkv_score_f16", "fastkv_select_f16",
-           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_gather_rows", "fastkv_head_sum_f16", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
-           "fastkv_sp_scores_f16", "fastkv_debug_contract", "fastkv_profile_enable",
+           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_compact_ranked_f16", "fastkv_gather_rows", "fastkv_head_sum_f16", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
+           "fastkv_sp_scores_f16", "fastkv_sp_pack_f16", "fastkv_sp_unpack_f16", "fastkv_sp_pick",
+           "fastkv_sp_compact_f16", "fastkv_debug_contract", "fastkv_debug_occupy", "fastkv_last_status", "fastkv_profile_enable",
            "fastkv_profile_kernels", "fastkv_profile_kernel_name", "fastkv_profile_read", "fastkv_strerror", "fastkv_version"]
 
 _lib = None
@@ -65,6 +66,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_select_workspace_bytes.restype = sz
     L.fastkv_compact_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, vp, vp, vp]
     L.fastkv_compact_f16.restype = ci
+    L.fastkv_compact_ranked_f16.argtypes = [pp, vp, i64p, vp, i64p, vp, vp, i64, vp, vp, vp, vp, sz, vp]
+    L.fastkv_compact_ranked_f16.restype = ci
     L.fastkv_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp]
     L.fastkv_gather_rows.restype = ci
     wp = ctypes.POINTER(SPWindow)
@@ -78,6 +81,18 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_sp_rowsum_f16.restype = ci
     L.fastkv_sp_scores_f16.argtypes = [pp, vp, wp, vp, vp, vp, vp, vp, sz, vp]
     L.fastkv_sp_scores_f16.restype = ci
+    L.fastkv_sp_pack_f16.argtypes = [vp, i64, i64, vp, i64, i64, i64, vp, vp]
+    L.fastkv_sp_pack_f16.restype = ci
+    L.fastkv_sp_unpack_f16.argtypes = [vp, i64, i64, ci, i64, i64, vp, i64, vp]
+    L.fastkv_sp_unpack_f16.restype = ci
+    L.fastkv_sp_pick.argtypes = [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp]
+    L.fastkv_sp_pick.restype = ci
+    L.fastkv_sp_compact_f16.argtypes = [ci, ci, ci, ci, ci, ci, vp, i64p, vp, i64p, vp, i64, ci, vp, vp, vp]
+    L.fastkv_sp_compact_f16.restype = ci
+    L.fastkv_debug_occupy.argtypes = [ci, ci, i64, vp]
+    L.fastkv_debug_occupy.restype = ci
+    L.fastkv_last_status.argtypes = []
+    L.fastkv_last_status.restype = ci
     L.fastkv_debug_contract.argtypes = [ci, vp, vp, vp, vp, ci, vp]
     L.fastkv_debug_contract.restype = ci
     L.fastkv_profile_enable.argtypes = [ci]

@@ -3,7 +3,45 @@
 // No allocation, no synchronisation, no exceptions; everything goes on the caller's stream.
 #include "fk_host.h"
 
+#include <cstdlib>
+#include <mutex>
+
 using namespace fk;
+
+// ---- abandoned in-launch waits (fk_device.h SpinCtl) ---------------------------------------------------------------
+// One word of pinned, host-coherent memory per process: a workgroup that gives up a hand-off wait stores 1 there.  The next
+// call of an operator entry point (or fastkv_last_status) reads and clears it on the host -- no synchronisation, no copy.
+namespace fk {
+static uint32_t *g_abort_host = nullptr, *g_abort_dev = nullptr;
+static std::once_flag g_abort_once;
+uint32_t *abort_flag_device()
+{
+    std::call_once(g_abort_once, []() {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        *reinterpret_cast<volatile uint32_t *>(h) = 0;
+        g_abort_host = reinterpret_cast<uint32_t *>(h);
+        g_abort_dev = reinterpret_cast<uint32_t *>(d);
+    });
+    return g_abort_dev;
+}
+uint64_t spin_limit_ticks()
+{
+    static const uint64_t ticks = []() {
+        double ms = 2000.0;                                     // default: two seconds of wall clock per launch
+        if (const char *e = getenv("FASTKV_SPIN_LIMIT_MS")) { const double v = atof(e); if (v > 0.0) ms = v; }
+        return (uint64_t)(ms * 1e5);                            // s_memrealtime runs at 100 MHz
+    }();
+    return ticks;
+}
+static int take_abort_status()
+{
+    if (!g_abort_host) return FASTKV_OK;
+    if (__atomic_load_n(g_abort_host, __ATOMIC_ACQUIRE) == 0u) return FASTKV_OK;
+    return __atomic_exchange_n(g_abort_host, 0u, __ATOMIC_ACQ_REL) ? FASTKV_EABORTED : FASTKV_OK;
+}
+}  // namespace fk
 
 namespace {
 
@@ -71,11 +109,14 @@ int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
 
 size_t fastkv_select_workspace_bytes(int64_t rows, int64_t n, int64_t k) { return select_ws_bytes(rows, n, k); }
 
+int fastkv_last_status(void) { return take_abort_status(); }
+
 int fastkv_score_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
                      const int64_t k_strides[4], void *scores_out, void *tsp_scores_out, void *workspace,
                      size_t workspace_bytes, void *stream)
 {
     int rc;
+    if ((rc = take_abort_status()) != FASTKV_OK) return rc;      // an EARLIER launch gave up (see the header)
     if ((rc = check_problem(p)) != FASTKV_OK) return rc;
     if ((rc = check_strides(q, q_strides)) != FASTKV_OK) return rc;
     if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
@@ -126,6 +167,32 @@ int fastkv_compact_f16(const fastkv_problem *p, const void *k, const int64_t k_s
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
+int fastkv_compact_ranked_f16(const fastkv_problem *p, const void *k, const int64_t k_strides[4], const void *v,
+                              const int64_t v_strides[4], const int64_t *idx_asc, const void *scores, int64_t score_row_stride,
+                              int64_t *idx_sorted_out, void *k_out, void *v_out, void *workspace, size_t workspace_bytes,
+                              void *stream)
+{
+    int rc;
+    if ((rc = check_problem(p)) != FASTKV_OK) return rc;
+    if (p->capacity <= p->window || p->capacity > p->S) return FASTKV_EINVAL;          // distinct winners: at most S - window of them
+    if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
+    if ((rc = check_strides(v, v_strides)) != FASTKV_OK) return rc;
+    const int kk = p->capacity - p->window, n = p->S - p->window;
+    if (!idx_asc || !scores || !k_out || !v_out || !workspace || score_row_stride < n) return FASTKV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(k_out) & 15) || (reinterpret_cast<uintptr_t>(v_out) & 15) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return FASTKV_EINVAL;
+    if (kk > 131064) return FASTKV_EUNSUPPORTED;
+    const size_t rows = (size_t)p->B * p->Hkv, kal = ((size_t)kk + 7) & ~(size_t)7;
+    if (workspace_bytes < rows * kal * 2) return FASTKV_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t *keys = reinterpret_cast<uint16_t *>(workspace);
+    hipError_t e = launch_winner_keys((const uint16_t *)scores, score_row_stride, n, idx_asc, (int64_t)rows, kk, keys, st);
+    if (e != hipSuccess) return FASTKV_ELAUNCH;
+    e = launch_compact(*p, k, k_strides, v, v_strides, idx_asc, keys, idx_sorted_out, k_out, v_out, st);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
 int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
                          const int64_t k_strides[4], const void *v, const int64_t v_strides[4], void *k_out, void *v_out,
                          int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out, void *workspace,
@@ -143,6 +210,7 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     if (out_strides && ((out_strides[0] & 7) || (out_strides[1] & 7) || (out_strides[2] & 7) || out_strides[2] < (p ? p->D : 0)))
         return FASTKV_EINVAL;                                  // 16-B aligned rows, at least D elements apart
     int rc;
+    if ((rc = take_abort_status()) != FASTKV_OK) return rc;      // an EARLIER launch gave up (see the header)
     if ((rc = check_problem(p)) != FASTKV_OK) return rc;
     if ((rc = check_select(p)) != FASTKV_OK) return rc;
     if ((rc = check_strides(q, q_strides)) != FASTKV_OK) return rc;
@@ -182,27 +250,34 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
                                 select_all ? keys : nullptr, kal, &epoch_bump);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
+    // From here on a fused scoring launch may be in the stream (epoch_bump set): if a later stage cannot be launched the epoch
+    // is advanced by a one-thread kernel before returning, so that the next call never re-uses this launch's hand-off token.
+    auto fail = [&]() {
+        if (epoch_bump) (void)launch_epoch_bump(epoch_bump, st);
+        return FASTKV_ELAUNCH;
+    };
     if (scores_out) {
         e = hipMemcpy2DAsync(scores_out, (size_t)L.n * 2, c, (size_t)L.n_pad * 2, (size_t)L.n * 2, (size_t)p->B * p->Hkv,
                              hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return FASTKV_ELAUNCH;
+        if (e != hipSuccess) return fail();
     }
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(ws);
     if (!select_all) {
         e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
-                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, st);
-        if (e != hipSuccess) return FASTKV_ELAUNCH;
+                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, st, ctrl);
+        if (e != hipSuccess) return fail();
     }
     if (p->tsp_len) {
         e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
                           reinterpret_cast<const uint32_t *>(ws + L.off_thist), arrive + (size_t)p->B * p->Hkv,
-                          seltab + (size_t)p->B * p->Hkv * nchunks * 32, st);
-        if (e != hipSuccess) return FASTKV_ELAUNCH;
+                          seltab + (size_t)p->B * p->Hkv * nchunks * 32, st, ctrl);
+        if (e != hipSuccess) return fail();
     }
     // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction
     // derives it instead of loading it)
     e = launch_compact(*p, k, k_strides, v, v_strides, (select_all && by_score) ? nullptr : idx_asc, keys,
                        by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump, out_strides);
-    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+    return e == hipSuccess ? FASTKV_OK : fail();
 }
 
 int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t src_row_stride_bytes, const int64_t *idx,
@@ -309,6 +384,10 @@ const char *fastkv_strerror(int code)
     case FASTKV_EINVAL: return "invalid argument (shape, stride, alignment, pooling or order)";
     case FASTKV_EWORKSPACE: return "workspace missing or too small (see fastkv_workspace_bytes)";
     case FASTKV_ELAUNCH: return "HIP kernel launch failed";
+    case FASTKV_EABORTED:
+        return "an earlier fused launch gave up waiting for its co-resident workgroups (another kernel held compute units longer "
+               "than FASTKV_SPIN_LIMIT_MS, or two such launches overlapped): the outputs of that call are invalid -- repeat it, "
+               "with FASTKV_FUSED=0 if the GPU is shared";
     case FASTKV_EUNSUPPORTED: return "unsupported configuration (head_dim must be 64/128/256, S < 2^24)";
     default: return "unknown error";
     }

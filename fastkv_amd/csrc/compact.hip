@@ -50,7 +50,13 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     // position are fetched together (two independent 16-B loads per lane in flight)
     // idx == nullptr: every candidate is kept in ascending position (capacity == S), the list is the identity: one
     // dependent memory round trip less
-    const int64_t srow = rc < kk ? (idx ? idx[(size_t)bg * kk + rc] : (int64_t)rc) : (int64_t)(n + (rc - kk));
+    int64_t srow = rc < kk ? (idx ? idx[(size_t)bg * kk + rc] : (int64_t)rc) : (int64_t)(n + (rc - kk));
+    // one policy for every gather of the library (here, gather_rows, sp_compact): an index outside [0, S) never faults, it
+    // reads a clamped row; -DFK_DEBUG_BOUNDS makes it loud instead
+#ifdef FK_DEBUG_BOUNDS
+    if (srow < 0 || srow >= S) __builtin_trap();
+#endif
+    srow = srow < 0 ? 0 : (srow >= S ? (int64_t)S - 1 : srow);
     const uint4 kval = *reinterpret_cast<const uint4 *>(ksrc + srow * ks_s + sub * 8);
     const uint4 vval = *reinterpret_cast<const uint4 *>(vsrc + srow * vs_s + sub * 8);
     int d = rc;
@@ -109,6 +115,31 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
     return hipGetLastError();
 }
 
+// keys[row, i] = order-preserving 16-bit key of scores[row, idx[row, i]] (zero padded to a multiple of 8): what the
+// selection kernels hand to compact_kv inside the operator, for the stand-alone ORDER_SCORE compaction.
+__global__ void __launch_bounds__(256) winner_keys_kernel(const uint16_t *__restrict__ scores, int64_t row_stride, int64_t n,
+                                                          const int64_t *__restrict__ idx, int kk, int kal,
+                                                          uint16_t *__restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (i >= kal) return;
+    uint16_t key = 0;
+    if (i < kk) {
+        int64_t j = idx[(size_t)row * kk + i];
+        j = (j >= 0 && j < n) ? j : 0;
+        key = (uint16_t)mono16(scores[(size_t)row * row_stride + j]);
+    }
+    keys[(size_t)row * kal + i] = key;
+}
+
+hipError_t launch_winner_keys(const uint16_t *scores, int64_t row_stride, int64_t n, const int64_t *idx, int64_t rows, int kk,
+                              uint16_t *keys, hipStream_t st)
+{
+    const int kal = (kk + 7) & ~7;
+    hipLaunchKernelGGL(winner_keys_kernel, dim3((kal + 255) / 256, (unsigned)rows), dim3(256), 0, st, scores, row_stride, n, idx, kk, kal, keys);
+    return hipGetLastError();
+}
+
 // Generic row gather, rows of `row_bytes` (multiple of 16).  `lpr` lanes (power of two <= 256) cooperate on a row,
 // 256/lpr rows per workgroup, one 16-B piece per lane per iteration; grid (ceil(rows_out/rpb), batches).
 __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *__restrict__ src, int64_t sbs, int64_t srs,
@@ -122,7 +153,10 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *_
     const int64_t r = (int64_t)blockIdx.x * (256 >> lpr_shift) + (threadIdx.x >> lpr_shift);
     if (r >= rows_out) return;
     int64_t s = idx[b * ibs + r];
-    s = (s >= 0 && s < rows_in) ? s : 0;                       // out-of-range indices read row 0 (never faults)
+#ifdef FK_DEBUG_BOUNDS
+    if (s < 0 || s >= rows_in) __builtin_trap();
+#endif
+    s = s < 0 ? 0 : (s >= rows_in ? rows_in - 1 : s);          // out-of-range indices read a clamped row (never faults)
     const unsigned char *sp = src + b * sbs + s * srs;
     unsigned char *dp = dst + (b * rows_out + r) * row_bytes;
     const int64_t pieces = row_bytes >> 4;

@@ -35,7 +35,31 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
     out[i] = r;
     if (out64) out64[i] = r64;
 }
+// Test hook: `wgs` workgroups that each hold `lds_bytes` of LDS and spin for `usec` microseconds of wall clock -- "another
+// kernel is holding compute units" for the residency tests.
+__global__ void __launch_bounds__(256) debug_occupy_kernel(uint64_t ticks, uint32_t *sink)
+{
+    extern __shared__ uint32_t hold[];
+    hold[threadIdx.x] = threadIdx.x;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (hold[(threadIdx.x + 1) & 255] == 0xffffffffu) *sink = 1;
+}
 }  // namespace fk
+
+extern "C" int fastkv_debug_occupy(int wgs, int lds_bytes, int64_t usec, void *stream)
+{
+    if (wgs < 1 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || usec < 0) return FASTKV_EINVAL;
+    static uint32_t *sink = nullptr;
+    if (!sink && hipMalloc(&sink, 64) != hipSuccess) return FASTKV_ELAUNCH;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fk::debug_occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(fk::debug_occupy_kernel, dim3(wgs), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (uint64_t)usec * 100u, sink);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
 
 extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream)
 {

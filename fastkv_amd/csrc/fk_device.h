@@ -242,6 +242,47 @@ __device__ __forceinline__ void hist12_add(uint32_t *hist, uint32_t bin, bool ac
     }
 }
 
+// ---- bounded waits of the in-launch hand-offs (fused.hip, select.hip) ----------------------------------------------
+// A workgroup that waits for a partner can only be served if the partner is resident.  When another kernel holds compute
+// units (another stream, another process) the partner may be scheduled late -- the wait then simply takes longer -- or, if
+// two such launches overlap, never.  Every wait is therefore bounded by wall-clock time (s_memrealtime, 100 MHz); a
+// workgroup that gives up publishes the launch's token in the workspace's abort word (so that every other workgroup of the
+// launch stops waiting at its next poll) and raises the process-wide flag in pinned host memory that the next API call
+// reports as FASTKV_EABORTED.  Nothing traps, nothing hangs, the HIP context stays usable.
+struct SpinCtl {
+    uint32_t *abort_word;     // control block word 3 of the operator workspace
+    uint32_t *host_flag;      // pinned, host-coherent
+    uint32_t token;           // this launch's hand-off token
+    uint64_t deadline;        // s_memrealtime tick after which a wait gives up
+};
+__device__ __forceinline__ SpinCtl make_spin(uint32_t *ctrl, uint32_t *host_flag, uint32_t token, uint64_t limit_ticks)
+{
+    SpinCtl sp;
+    sp.abort_word = ctrl + 3;
+    sp.host_flag = host_flag;
+    sp.token = token;
+    sp.deadline = __builtin_amdgcn_s_memrealtime() + limit_ticks;
+    return sp;
+}
+// one call per poll iteration of a waiting lane: true = stop waiting, the launch is abandoned
+__device__ __forceinline__ bool spin_failed(const SpinCtl &sp)
+{
+    if (__hip_atomic_load(sp.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sp.token) return true;
+    if (__builtin_amdgcn_s_memrealtime() > sp.deadline) {
+        __hip_atomic_store(sp.abort_word, sp.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sp.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
+    }
+    return false;
+}
+// the hand-off token of the launch that follows epoch `e` (a bijective mix, never 0: memory this library never wrote --
+// zeros, small integers, fp16 data -- does not look like a current granule)
+__device__ __forceinline__ uint32_t handoff_token(uint32_t epoch)
+{
+    const uint32_t t = (epoch + 1u) * 0x9E3779B1u ^ 0x7F4A7C15u;
+    return t ? t : 0x6B43A9B5u;
+}
+
 #define FK_SUM_POISON 0xffffffffffffffffull   // a NaN was seen in the row (oracle: rinv = NaN)
 
 __device__ __forceinline__ float wave_max(float v)

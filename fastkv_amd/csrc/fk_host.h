@@ -11,6 +11,7 @@ constexpr int TKA = 256;        // keys per workgroup in score_logits (4 waves x
 constexpr int SEL_THREADS = 1024;
 constexpr size_t CTRL_BYTES = 8192;  // control block at the start of every operator workspace (fastkv_workspace_init):
                                      // u64 magic, u32 epoch (the rest is reserved)
+                                     // u64 magic, u32 epoch, u32 abort word (token of a launch that gave up waiting)
 constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
 constexpr int FUSED_MAX_WGS = 512;   // workgroups of one fused score launch (2 per CU): sizes its hand-off records
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
@@ -77,6 +78,11 @@ static inline Layout make_layout(const fastkv_problem &p)
     return L;
 }
 
+// bounded hand-off waits (fk_device.h SpinCtl): the process-wide abort flag in pinned host memory (device view; nullptr if
+// the allocation failed: the launchers then take the staged path) and the wall-clock limit in s_memrealtime ticks
+uint32_t *abort_flag_device();
+uint64_t spin_limit_ticks();
+
 // launchers (defined in score.hip / select.hip / compact.hip); all return hipError_t of the launch
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
@@ -86,6 +92,7 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
+hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st);
 hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
@@ -96,7 +103,7 @@ hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fas
                             int64_t t_row_stride, int n_own, hipStream_t st);
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
-                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st);
+                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl = nullptr);
 hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, const uint16_t *keys, int64_t key_row_stride,
                                int64_t rows, int64_t k, int64_t *out, int64_t out_row_stride, hipStream_t st);
 // idx: ascending-position winners; keys != nullptr => rows are placed in ORDER_SCORE (rank by comparison counting) and
@@ -104,6 +111,8 @@ hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, c
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
                           hipStream_t st, uint32_t *epoch_bump = nullptr, const int64_t *out_strides = nullptr);
+hipError_t launch_winner_keys(const uint16_t *scores, int64_t row_stride, int64_t n, const int64_t *idx, int64_t rows, int kk,
+                              uint16_t *keys, hipStream_t st);
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
                               int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st);
 

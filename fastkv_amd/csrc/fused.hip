@@ -45,18 +45,19 @@ constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the n
 // load per lane and pass, sleeping in between: pollers share those words' memory channel with the producers' stores),
 // then everybody reads the records and checks every tag (a record is one store instruction, so this almost never loops).
 __device__ __forceinline__ uint64_t granule(uint32_t token, uint32_t value) { return ((uint64_t)token << 32) | value; }
-__device__ __forceinline__ void wait_first_granules(const uint64_t *rec, int stride, int nblk, uint32_t token, int lane)
+// Returns false when the wait was given up (fk_device.h: SpinCtl) -- the caller leaves the kernel.
+__device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int stride, int nblk, uint32_t token, int lane, const SpinCtl &sp)
 {
-    uint32_t spins = 0;
     for (;;) {
         bool ok = true;
         for (int l = lane; l < nblk; l += 64)
             ok = ok && ((uint32_t)(__hip_atomic_load(rec + (size_t)l * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 25)) __builtin_trap();          // ~10 s: a partner never arrived; fail loudly instead of hanging
+        if (__builtin_amdgcn_readfirstlane((int)spin_failed(sp))) return false;     // a partner never arrived: give up, loudly (host flag)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: every load of handed-over bytes is an sc1 load
+    return true;
 }
 
 template <int D, int PER, int NB>
@@ -64,11 +65,12 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
                                                              uint64_t *__restrict__ edges, uint64_t *__restrict__ pmax,
-                                                             uint64_t *__restrict__ psum, const uint32_t *__restrict__ ctrl,
+                                                             uint64_t *__restrict__ psum, uint32_t *__restrict__ ctrl,
                                                              uint32_t *__restrict__ zero_area, int zero_words, int ksize, int pooling,
                                                              uint16_t *__restrict__ c_out, int64_t c_row_stride,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
-                                                             int64_t all_key_stride, int VH, uint64_t *__restrict__ chain)
+                                                             int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
+                                                             uint32_t *__restrict__ host_flag, uint64_t spin_ticks)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.
@@ -79,6 +81,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     __shared__ uint64_t s_u[FUSED_PARTS][32];
     __shared__ uint32_t s_bad[FUSED_PARTS][32];
     __shared__ float s_row[32];
+    __shared__ uint32_t s_abort;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
@@ -98,10 +101,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // of this launch is the epoch left by the previous one + 1 (score_finalize bumps it): never a launch argument, which a
     // graph replay would freeze; the granules in memory still carry earlier tokens (or whatever the allocation held).
     if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
-    // (a bijective mix of the epoch, never 0: memory that was never written by this library -- zeros, small integers, fp16
-    // data -- does not look like a current granule)
-    uint32_t token = (ctrl[2] + 1u) * 0x9E3779B1u ^ 0x7F4A7C15u;
-    if (token == 0u) token = 0x6B43A9B5u;
+    const uint32_t token = handoff_token(ctrl[2]);
+    const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
+    if (threadIdx.x == 0) s_abort = 0;
     FKF_STAMP(0);
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record is published, so
@@ -242,9 +244,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             __hip_atomic_store(pm + blk * 32 + lane,
                                granule(token, f32_bits(fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane])))),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wait_first_granules(pm, 32, nblk, token, lane);
+        if (!wait_first_granules(pm, 32, nblk, token, lane, sp)) s_abort = 1;
     }
     __syncthreads();
+    if (s_abort) return;
     {
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
@@ -265,6 +268,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             }
             s_f[part][row] = v;
             if (__syncthreads_and(ok)) break;
+            if (threadIdx.x == 0 && spin_failed(sp)) s_abort = 1;      // a record behind a current granule 0 is still old: rare
+            __syncthreads();
+            if (s_abort) return;
         }
     }
     if (threadIdx.x < 32) {
@@ -355,9 +361,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         const uint64_t tot = bad ? FK_SUM_POISON : s_u[0][row] + s_u[1][row] + s_u[2][row] + s_u[3][row];
         __hip_atomic_store(psu + blk * 64 + lane, granule(token, (uint32_t)((lane & 1) ? tot >> 32 : tot)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        wait_first_granules(psu, 64, nblk, token, lane);
+        if (!wait_first_granules(psu, 64, nblk, token, lane, sp)) s_abort = 1;
     }
     __syncthreads();
+    if (s_abort) return;
     {
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
@@ -383,6 +390,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             s_u[part][row] = s2;
             s_bad[part][row] = bad;
             if (__syncthreads_and(ok)) break;
+            if (threadIdx.x == 0 && spin_failed(sp)) s_abort = 1;
+            __syncthreads();
+            if (s_abort) return;
         }
     }
     if (threadIdx.x < 32) {
@@ -464,10 +474,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             if (nb >= 0 && nb < nblk) {
                 const uint64_t *src = edges + ((size_t)bgv * nblk + nb) * (2 * G * PADMAX) + ((side ? 0 : 1) * G + i4) * PADMAX + e;
                 uint64_t x;
-                uint32_t spins = 0;
                 while (((x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1u << 25)) __builtin_trap();
+                    if (spin_failed(sp)) { s_abort = 1; break; }
                 }
                 hv = bits_f32((uint32_t)x);
             }
@@ -475,6 +484,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         }
     }
     __syncthreads();
+    if (s_abort) return;
     FKF_STAMP(6);
 
     // ---------------------------------------------------------------- phase D: pool, sum over the heads, scores + histogram
@@ -489,10 +499,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         float gsum = 0.0f;
         if (is_out && vh > 0) {                              // the head sum so far: {token, fp32 bits} granule of this position
             uint64_t x;
-            uint32_t spins = 0;
             while ((uint32_t)((x = __hip_atomic_load(chain_in + lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 25)) __builtin_trap();
+                if (spin_failed(sp)) break;                  // abandoned launch: the value is never used (the host reports the call)
             }
             gsum = bits_f32((uint32_t)x);
         }
@@ -525,20 +534,20 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 // ------------------------------------------------------------------------------------------ host side
 template <int D, int PER, int NB> static bool fused_resident(int grid_wgs)
 {
-    static int wgs_per_cu = -1, cus = 0;
-    if (wgs_per_cu < 0) {
+    struct Info { int wgs_per_cu, cus; };
+    static const Info info = []() {                            // initialised once, thread-safe (C++11 static)
+        Info r = {0, 0};
         int dev = 0, nb = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB>), 256, 0) !=
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB>), 256, 0) ==
                 hipSuccess) {
-            wgs_per_cu = 0;
-        } else {
-            wgs_per_cu = nb;
-            cus = prop.multiProcessorCount;
+            r.wgs_per_cu = nb;
+            r.cus = prop.multiProcessorCount;
         }
-    }
-    return wgs_per_cu >= 1 && grid_wgs <= (wgs_per_cu < 2 ? wgs_per_cu : 2) * cus;
+        return r;
+    }();
+    return info.wgs_per_cu >= 1 && grid_wgs <= (info.wgs_per_cu < 2 ? info.wgs_per_cu : 2) * info.cus;
 }
 
 // Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
@@ -564,7 +573,10 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);
-    const uint32_t *ctrl = reinterpret_cast<const uint32_t *>(ws);
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(ws);
+    uint32_t *host_flag = abort_flag_device();
+    if (!host_flag) return false;                                // no way to report an abandoned launch: staged path
+    const uint64_t spin_ticks = spin_limit_ticks();
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [wg][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
     dim3 grid(nblk * p.Hkv * VH, p.B);
@@ -577,20 +589,22 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 #undef FK_RES
 #undef FK_RES2
     if (!resident) return false;
-    // Two fused launches must never overlap on a GPU (each needs ALL its workgroups resident).  Within this process the
-    // library sees to it: when a launch comes on another stream than the previous one, an event recorded on the previous
-    // stream (now: behind everything submitted there so far) makes the new stream wait.  Nothing is added while the
-    // caller stays on one stream; inside a stream capture the chain is skipped (see include/fastkv_hip.h).
+    // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
+    // for each other until the spin limit and be reported as FASTKV_EABORTED).  Within this process the library sees to it:
+    // when a launch comes on another stream than the previous one, an event recorded on the previous stream (now: behind
+    // everything submitted there so far) makes the new stream wait.  The lock is held from the chaining to the enqueue of the
+    // kernel, so that a second thread cannot slip its own launch in between.  Nothing is added while the caller stays on
+    // one stream; inside a stream capture the chain is skipped (see include/fastkv_hip.h).
+    static std::mutex mtx;
+    static hipStream_t last_stream[16];
+    static bool have_last[16];
+    static hipEvent_t chain_ev[16];
+    std::lock_guard<std::mutex> lk(mtx);
     {
-        static std::mutex mtx;
-        static hipStream_t last_stream[16];
-        static bool have_last[16];
-        static hipEvent_t chain_ev[16];
         int dev = 0;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && hipStreamIsCapturing(st, &cs) == hipSuccess &&
             cs == hipStreamCaptureStatusNone) {
-            std::lock_guard<std::mutex> lk(mtx);
             if (have_last[dev] && last_stream[dev] != st) {
                 if (!chain_ev[dev]) (void)hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming);
                 if (chain_ev[dev] && hipEventRecord(chain_ev[dev], last_stream[dev]) == hipSuccess)
@@ -605,7 +619,8 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 #define FK_FUSED(DV, PV, NBX)                                                                                                    \
     hipLaunchKernelGGL((score_fused_kernel<DV, PV, NBX>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],      \
                        (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum,        \
-                       ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain)
+                       ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, \
+                       host_flag, spin_ticks)
 #define FK_FUSED_P(DV, NBX)                                                                                 \
     do {                                                                                                    \
         if (PERT == 1) FK_FUSED(DV, 1, NBX); else if (PERT == 2) FK_FUSED(DV, 2, NBX); else FK_FUSED(DV, 4, NBX);  \

@@ -582,6 +582,12 @@ __global__ void epoch_bump_kernel(uint32_t *epoch)
     *epoch = e ? e : 1u;
 }
 
+hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st)
+{
+    hipLaunchKernelGGL(epoch_bump_kernel, dim3(1), dim3(1), 0, st, epoch);
+    return hipGetLastError();
+}
+
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
                         char *ws, hipStream_t st, int64_t *all_idx, uint16_t *all_keys, int64_t all_key_stride,
@@ -627,7 +633,10 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
         ProfScope ps_(K_TSP_ROWSUM, st);
         hipLaunchKernelGGL(tsp_rowsum_kernel, dim3((L.n + 255) / 256, p.B), dim3(256), 0, st, c_out, c_row_stride, p.Hkv, L.n, t_out,
                            t_row_stride, hist + (size_t)p.B * p.Hkv * HIST12);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) {
+            if (fused) (void)launch_epoch_bump(reinterpret_cast<uint32_t *>(ws) + 2, st);     // the token of the fused launch is spent
+            return e;
+        }
     }
     if (fused) {
         uint32_t *epoch = reinterpret_cast<uint32_t *>(ws) + 2;

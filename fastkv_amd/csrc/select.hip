@@ -293,9 +293,15 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
                                                                    int append, int64_t *__restrict__ idx_out, int64_t idx_row_stride,
                                                                    uint16_t *__restrict__ key_out, int64_t key_row_stride,
                                                                    const uint32_t *__restrict__ hist12, uint32_t *__restrict__ arrive,
-                                                                   uint32_t *__restrict__ table)
+                                                                   uint32_t *__restrict__ table, uint32_t *__restrict__ ctrl,
+                                                                   uint32_t *__restrict__ host_flag, uint64_t spin_ticks)
 {
     __shared__ SplShared sh;
+    __shared__ uint32_t s_abort;
+    // bounded wait (fk_device.h SpinCtl): same token as the scoring launch of this operator call (the epoch advances in the
+    // compaction kernel, after this one)
+    const SpinCtl sp = make_spin(ctrl, host_flag, handoff_token(ctrl[2]), spin_ticks);
+    if (threadIdx.x == 0) s_abort = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chunk = blockIdx.x, nchunks = gridDim.x, rowi = blockIdx.y;
     const uint16_t *row = scores + (size_t)rowi * row_stride;
@@ -369,15 +375,15 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             __hip_atomic_fetch_add(&arrive[rowi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t spins = 0;
             while (__hip_atomic_load(&arrive[rowi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)nchunks) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 23)) __builtin_trap();          // seconds: the launch is broken, fail loudly instead of hanging
+                if (spin_failed(sp)) { s_abort = 1; break; }          // chunks of this row never arrived: give up, loudly (host flag)
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __syncthreads();
+    if (s_abort) return;
     // ---------------- phase 2: totals over the row and over the chunks before this one
     for (int i = tid; i < nchunks * 17; i += SPL_THREADS) {
         const int cc = i / 17, f = i - cc * 17;
@@ -433,7 +439,8 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
                 int pos = -1;
                 if (keys[e] > thr) { pos = (int)(gt_before + min(eq_before, quota)); gt_before++; }
                 else if (keys[e] == thr) { if (eq_before < quota) pos = (int)(gt_before + eq_before); eq_before++; }
-                if (pos >= 0) { out[pos] = (int64_t)(j0 + e); if (kout) kout[pos] = (uint16_t)keys[e]; }
+                // (pos < k always holds on a consistent histogram; an abandoned scoring launch leaves anything in it)
+                if (pos >= 0 && pos < k) { out[pos] = (int64_t)(j0 + e); if (kout) kout[pos] = (uint16_t)keys[e]; }
             }
         }
     }
@@ -456,15 +463,17 @@ __global__ void __launch_bounds__(256) rank_scatter_kernel(const int64_t *__rest
 
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
-                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st)
+                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl)
 {
     if (rows == 0) return hipSuccess;
+    uint32_t *host_flag = ctrl ? abort_flag_device() : nullptr;
     const int64_t nchunks = (n + SPL_CHUNK - 1) / SPL_CHUNK;
     const bool vec = ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && (row_stride % 8 == 0) && (row_stride >= ((n + 7) & ~(int64_t)7));
-    if (hist12 && arrive && table && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec) {
-        ProfScope ps_(K_SELECT, st);
+    if (hist12 && arrive && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec) {
+        ProfScope ps_(K_SELECT_SPLIT, st);
         hipLaunchKernelGGL(select_split_kernel, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
-                           (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12, arrive, table);
+                           (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12, arrive, table, ctrl,
+                           host_flag, spin_limit_ticks());
         return hipGetLastError();
     }
     const int64_t kal = (k + 7) & ~(int64_t)7;

@@ -11,14 +11,21 @@ That is possible because the arithmetic contract makes every globa
                                           final canonical top-k over the P*k candidates (a global winner is always a
                                           local winner of its shard, ties included)
 
-Collectives per layer (all tiny, latency bound on xGMI -- use direct all-gather / all-reduce, never rings of big
-buffers): (1) all-gather of the window queries + K halo rows (a few KiB), (2) MAX, (3) SUM, (4) the candidate
-all-gather named in the north star (k*8 bytes per score row per rank), and optionally (5) a SUM all-reduce that
-replicates the compacted K/V rows (each row has exactly one non-zero contributor, so the fp16 sum is exact).
+FOUR collectives per layer, all tiny and latency bound on xGMI (direct all-gather / all-reduce of a few KiB, never a ring
+of big buffers), every layer the same four (the TSP layer adds none, unknown shard lengths add none):
+    (1) all-gather   shard length + window queries (held by the last rank) + the K halo rows of every rank
+    (2) all-reduce   MAX of the row maxima with their NaN flags
+    (3) all-reduce   SUM of the fixed-point row sums
+    (4) all-gather   candidate records of the per-head rows AND of the TSP row (the index all-gather of the north star)
+Each needs the global result of the one before (queries -> max -> sum -> scores -> selection), and the exact sum
+sum_j fix(exp(x_j - max)) cannot be rebuilt from partial sums taken against local maxima, so (2) and (3) do not fold into one
+message the way a rescaling online softmax would (SURVEY.md 8(e) budgeted 3 under that assumption).
+No K/V bytes cross the fabric: every rank keeps the selected rows it owns (`replicate=False`, the layout a sequence-parallel
+decode consumes); `replicate=True` (tests, single-GPU consumers) adds (5), an exact all-reduce of the compacted rows.
 
 Rank r owns positions [pos0_r, pos0_r + S_r); the last rank owns the window (the prompt's last W positions).
 The local compute goes through a small `LocalOps` interface: `HipLocalOps` (the product: C-ABI `fastkv_sp_*` stages and
-the regular select / compact kernels) or, in the CPU tests, an oracle-backed stand-in injected by the test.
+the regular select kernels) or, in the CPU tests, an oracle-backed stand-in injected by the test.
 """
 from __future__ import annotations
 
@@ -29,6 +36,10 @@ import torch
 import torch.distributed as dist
 
 NEG_INF_F16_BITS = 0xFC00
+SP_PAD_RECORD = (NEG_INF_F16_BITS << 32) | 0xFFFFFFFF          # csrc/sp.hip: SP_PAD
+
+# collectives issued by this module since import (tests assert the per-layer count)
+COLLECTIVES = {"all_gather": 0, "all_reduce": 0}
 
 
 # ------------------------------------------------------------------------------------------------- local compute
@@ -92,42 +103,63 @@ class HipLocalOps:
         self.check(rc, "sp_scores")
         return c, t
 
-    def select(self, rows2d, k, order="index"):
-        return self.ops.select(rows2d.contiguous(), k, order)
+    def local_candidates(self, rows2d, k, pos0, records):
+        """records [rows, k] int64 (a view of the send buffer) <- the shard's canonical top-min(k, n_own) of every fp16 row as
+        {score bits << 32 | global position}, ascending position, padded with {-inf, no position}."""
+        rows, n_own = rows2d.shape
+        kl = min(k, n_own)
+        li = self.ops.select(rows2d, kl, "index") if kl > 0 else None
+        self.check(self.lib.fastkv_sp_pack_f16(rows2d.data_ptr() if kl else None, rows, rows2d.stride(0) if kl else 0,
+                                               li.data_ptr() if kl else None, kl, k, pos0, records.data_ptr(), self.ops._stream()),
+                   "sp_pack")
 
-    def compact(self, k, v, idx, window):
-        return self.ops.compact(k, v, idx, window)
+    def merge_candidates(self, allc, offset, rows, k, order, append=0, n_glob=0):
+        """allc [P, L] int64: every rank's records; this row set starts at `offset` of each block.  Final canonical top-k over
+        the P*k candidates of each row -> global positions [rows, k + append] (`append` window positions n_glob.. after them)."""
+        P = allc.shape[0]
+        dev = allc.device
+        sc = torch.empty(rows, P * k, dtype=torch.float16, device=dev)
+        self.check(self.lib.fastkv_sp_unpack_f16(allc.data_ptr(), allc.stride(0), offset, P, rows, k, sc.data_ptr(), sc.stride(0),
+                                                 self.ops._stream()), "sp_unpack")
+        sel = self.ops.select(sc, k, order)
+        out = torch.empty(rows, k + append, dtype=torch.int64, device=dev)
+        self.check(self.lib.fastkv_sp_pick(allc.data_ptr(), allc.stride(0), offset, rows, k, sel.data_ptr(), k, append, n_glob,
+                                           out.data_ptr(), self.ops._stream()), "sp_pick")
+        return out
+
+    def compact_owned(self, k, v, kv_idx, pos0, window, capacity, window_owner):
+        """[B,Hkv,capacity,D] x2: the rows of kv_idx (global positions) inside this shard (+ the window rows when
+        `window_owner`), zeros in the slots other ranks own."""
+        B, Hkv, S_r, D = k.shape
+        ko = torch.empty(B, Hkv, capacity, D, dtype=torch.float16, device=k.device)
+        vo = torch.empty_like(ko)
+        rc = self.lib.fastkv_sp_compact_f16(B, Hkv, S_r, D, window, capacity, k.data_ptr(), self.ops._strides(k), v.data_ptr(),
+                                            self.ops._strides(v), kv_idx.data_ptr(), pos0, 1 if window_owner else 0, ko.data_ptr(),
+                                            vo.data_ptr(), self.ops._stream())
+        self.check(rc, "sp_compact")
+        return ko, vo
 
 
 # ------------------------------------------------------------------------------------------------- helpers
-def _f16_bits(t: torch.Tensor) -> torch.Tensor:
-    return t.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
-
-
-def _pack(scores: torch.Tensor, gidx: torch.Tensor) -> torch.Tensor:
-    """(fp16 score, global position) -> one int64 per candidate: score bits << 32 | position."""
-    return (_f16_bits(scores) << 32) | (gidx & 0xFFFFFFFF)
-
-
-def _unpack(packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    bits = ((packed >> 32) & 0xFFFF).to(torch.int32)
-    scores = torch.where(bits >= 0x8000, bits - 0x10000, bits).to(torch.int16).view(torch.float16)
-    return scores, (packed & 0xFFFFFFFF)
-
-
 def _host_staged(t: torch.Tensor, group) -> bool:
-    """gloo has no device transport for ROCm tensors: stage through the host (used by the 2-process single-GPU test)."""
+    """gloo has no device transport for ROCm tensors: stage through the host (used by the shared-GPU tests)."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def _all_gather(t: torch.Tensor, group) -> List[torch.Tensor]:
-    src = t.contiguous().cpu() if _host_staged(t, group) else t.contiguous()
-    out = [torch.empty_like(src) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(out, src, group=group)
-    return [o.to(t.device) for o in out] if src is not t and src.device != t.device else out
+def _all_gather(t: torch.Tensor, group) -> torch.Tensor:
+    """[L] -> [P, L] (rank order), one collective."""
+    COLLECTIVES["all_gather"] += 1
+    P = dist.get_world_size(group)
+    src = t.contiguous()
+    if _host_staged(t, group):
+        src = src.cpu()
+    out = torch.empty(P * src.numel(), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.view(P, -1).to(t.device)
 
 
 def _all_reduce(t: torch.Tensor, op, group) -> None:
+    COLLECTIVES["all_reduce"] += 1
     if _host_staged(t, group):
         h = t.cpu()
         dist.all_reduce(h, op=op, group=group)
@@ -136,17 +168,28 @@ def _all_reduce(t: torch.Tensor, op, group) -> None:
         dist.all_reduce(t, op=op, group=group)
 
 
+def check_shards(shard_lengths: List[int], window: int, kernel_size: int) -> None:
+    """What the sharded operator needs from the split -- evaluated on the same list by every rank, so that all ranks fail
+    (or go on) together and nobody is left waiting in a collective."""
+    pad = kernel_size // 2
+    if min(shard_lengths) < max(pad, 1) or shard_lengths[-1] < window + pad:
+        raise ValueError(f"sp_update_kv: every shard needs >= kernel//2 = {pad} positions and the last one the whole window "
+                         f"plus the halo (>= {window + pad}); got {shard_lengths}")
+
+
 # ------------------------------------------------------------------------------------------------- the operator
 def sp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_states: torch.Tensor, *, window_size: int,
                  kernel_size: int, pooling: str, capacity: int, tsp_len: int = 0, order: str = "score", group=None,
-                 local_ops=None, shard_lengths: Optional[List[int]] = None, replicate: bool = True):
+                 local_ops=None, shard_lengths: Optional[List[int]] = None, replicate: bool = False):
     """Sequence-sharded compress branch of FastKVCluster.update_kv (/root/reference/baselines/fastkv/utils.py:93-132).
 
     key/value_states [B,Hkv,S_r,D], query_states [B,H,S_r,D]: this rank's slice of the prompt (ranks in sequence order).
     `capacity` / `tsp_len` are GLOBAL (utils.py:86-87, :123-126 applied to the global length by the caller).
-    Returns (k_out [B,Hkv,capacity,D], v_out, tsp_idx [B,tsp_len] int64 | None, kv_idx [B,Hkv,capacity-W] int64):
-    identical on every rank and bit-identical to the single-GPU operator when `replicate`; with `replicate=False`
-    k_out / v_out hold only the rows this rank owns (zeros elsewhere) and no K/V bytes cross the fabric.
+    Returns (k_out [B,Hkv,capacity,D], v_out, tsp_idx [B,tsp_len] int64 | None, kv_idx [B,Hkv,capacity-W] int64).
+    kv_idx / tsp_idx are identical on every rank and equal to the single-GPU operator's.  k_out / v_out hold the selected
+    rows THIS rank owns (zeros in the other slots; the ranks' tensors add up to the single-GPU result) -- no K/V bytes cross
+    the fabric; `replicate=True` adds one all-reduce that makes them identical on every rank.
+    Four collectives per call (module docstring), five with `replicate`.
     """
     lo = local_ops or HipLocalOps()
     P, r = dist.get_world_size(group), dist.get_rank(group)
@@ -156,28 +199,37 @@ def sp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_sta
     dev = key_states.device
     if pooling not in ("avgpool", "maxpool"):
         raise ValueError("Pooling method not supported")
+    if shard_lengths is not None:
+        check_shards(shard_lengths, W, kernel_size)                  # before the first collective, same verdict on every rank
+        assert shard_lengths[r] == S_r
+    common = dict(window=W, kernel_size=kernel_size, pooling=pooling)
+
+    # (1) shard length + window queries (owned by the last rank) + K halo rows of every rank: one small all-gather
+    nq, nk = B * H * W * D, B * Hkv * pad * D
+    HDR = 8                                                          # 16 bytes: the pieces behind it stay 16-B aligned
+    packet = torch.zeros(HDR + nq + 2 * nk, dtype=torch.float16, device=dev)
+    packet[:4].view(torch.int64).fill_(S_r)
+    o_q, o_l, o_r = HDR, HDR + nq, HDR + nq + nk                     # window queries | first `pad` K rows | last `pad` K rows
+    if S_r >= W:
+        packet[o_q:o_l].view(B, H, W, D).copy_(query_states[:, :, S_r - W:, :])
+    hl = min(pad, S_r)                                               # a shard shorter than the halo fails check_shards below
+    if hl:
+        packet[o_l:o_r].view(B, Hkv, pad, D)[:, :, :hl].copy_(key_states[:, :, :hl, :])
+        packet[o_r:].view(B, Hkv, pad, D)[:, :, pad - hl:].copy_(key_states[:, :, S_r - hl:, :])
+    packets = _all_gather(packet, group)
     if shard_lengths is None:
-        lens = _all_gather(torch.tensor([S_r], dtype=torch.int64, device=dev), group)
-        shard_lengths = [int(x.item()) for x in lens]
-    assert shard_lengths[r] == S_r and min(shard_lengths) >= max(pad, 1) and shard_lengths[-1] >= W + pad, \
-        "every shard needs >= kernel//2 positions and the last one the whole window"
+        shard_lengths = [int(x) for x in packets[:, :4].contiguous().view(torch.int64).view(-1).tolist()]
+        check_shards(shard_lengths, W, kernel_size)                  # every rank sees the same list
     pos0 = sum(shard_lengths[:r])
     S = sum(shard_lengths)
     n = S - W
     kk = capacity - W
     assert W < capacity <= S and (tsp_len == 0 or W < tsp_len < S)
-    common = dict(window=W, kernel_size=kernel_size, pooling=pooling)
+    q_win = packets[P - 1, o_q:o_l].view(B, H, W, D)
+    left = packets[r - 1, o_r:].view(B, Hkv, pad, D) if r > 0 and pad else None               # the previous rank's last rows
+    right = packets[r + 1, o_l:o_r].view(B, Hkv, pad, D) if r < P - 1 and pad else None       # the next rank's first rows
 
-    # (1) window queries (owned by the last rank) + K halo rows of every rank: one small all-gather
-    nq, nk = B * H * W * D, B * Hkv * pad * D
-    packet = torch.cat([query_states[:, :, S_r - W:, :].reshape(-1) if S_r >= W else torch.zeros(nq, dtype=torch.float16, device=dev),
-                        key_states[:, :, :pad, :].reshape(-1), key_states[:, :, S_r - pad:, :].reshape(-1)])
-    packets = _all_gather(packet, group)
-    q_win = packets[P - 1][:nq].view(B, H, W, D)
-    left = packets[r - 1][nq + nk:].view(B, Hkv, pad, D) if r > 0 and pad else None
-    right = packets[r + 1][nq:nq + nk].view(B, Hkv, pad, D) if r < P - 1 and pad else None
-
-    # (2) local logits with halo columns: column x <-> global position pos0 - pad + x
+    # local logits with halo columns: column x <-> global position pos0 - pad + x
     ncols = S_r + 2 * pad
     Sp = (ncols + 7) // 8 * 8
     logits = torch.zeros(B, H, W, Sp, dtype=torch.float16, device=dev)
@@ -188,48 +240,29 @@ def sp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_sta
         lo.logits(q_win, right, logits, pad + S_r, **common)
     win = (ncols, pos0 - pad, pad, pad + S_r, S, Sp)
 
-    # (3) + (4) global softmax statistics: MAX (with NaN flags), then the exact fixed-point SUM
+    # (2) + (3) global softmax statistics: MAX (with NaN flags), then the exact fixed-point SUM
     gmax = lo.rowmax(logits, win, Hkv, D, **common)
     _all_reduce(gmax, dist.ReduceOp.MAX, group)
     gsum = lo.rowsum(logits, win, gmax, Hkv, D, **common)
     _all_reduce(gsum, dist.ReduceOp.SUM, group)
 
-    # (5) scores of the owned candidate positions
+    # scores of the owned candidate positions
     n_own = max(0, min(S_r, n - pos0))
     c_loc, t_loc = lo.scores(logits, win, gmax, gsum, n_own, tsp_len > 0, Hkv, D, **common)
 
-    # (6) local canonical top-k -> the candidate all-gather -> final canonical top-k
-    def global_topk(rows2d: torch.Tensor, k: int, final_order: str) -> torch.Tensor:
-        nrows = rows2d.shape[0]
-        kl = min(k, n_own)
-        cand = torch.full((nrows, k), (NEG_INF_F16_BITS << 32) | 0xFFFFFFFF, dtype=torch.int64, device=dev)
-        if kl > 0:
-            li = lo.select(rows2d, kl, "index")
-            cand[:, :kl] = _pack(torch.gather(rows2d, 1, li), li + pos0)
-        allc = torch.cat(_all_gather(cand, group), dim=1)            # [rows, P*k], ascending global position per rank block
-        sc, gi = _unpack(allc)
-        sel = lo.select(sc, k, final_order)
-        return torch.gather(gi, 1, sel)
-
-    kv_idx = global_topk(c_loc.reshape(B * Hkv, n_own), kk, order).view(B, Hkv, kk)
-    tsp_idx = None
+    # (4) local canonical top-k of every row -> ONE all-gather of the candidate records -> final canonical top-k
+    kt = tsp_len - W if tsp_len else 0
+    n_kv = B * Hkv * kk
+    cand = torch.empty(n_kv + B * kt, dtype=torch.int64, device=dev)
+    lo.local_candidates(c_loc.view(B * Hkv, n_own), kk, pos0, cand[:n_kv].view(B * Hkv, kk))
     if tsp_len:
-        t_sel = global_topk(t_loc.reshape(B, n_own), tsp_len - W, "index")
-        tsp_idx = torch.cat([t_sel, torch.arange(n, S, device=dev, dtype=torch.int64).expand(B, -1)], dim=1)   # utils.py:128-130
+        lo.local_candidates(t_loc.view(B, n_own), kt, pos0, cand[n_kv:].view(B, kt))
+    allc = _all_gather(cand, group)                                  # [P, n_kv + B*kt]
+    kv_idx = lo.merge_candidates(allc, 0, B * Hkv, kk, order).view(B, Hkv, kk)
+    tsp_idx = lo.merge_candidates(allc, n_kv, B, kt, "index", append=W, n_glob=n) if tsp_len else None     # utils.py:127-130
 
-    # (7) compaction of the rows this rank owns (+ the window rows on the last rank), optional replication
-    own = (kv_idx >= pos0) & (kv_idx < pos0 + S_r)
-    li = torch.where(own, kv_idx - pos0, torch.zeros_like(kv_idx))
-    wl = min(W, S_r)
-    ko, vo = lo.compact(key_states, value_states, li.contiguous(), wl)     # [B,Hkv,kk+wl,D]: rows + this shard's last wl rows
-    k_out = torch.zeros(B, Hkv, capacity, D, dtype=torch.float16, device=dev)
-    v_out = torch.zeros_like(k_out)
-    m = own[..., None]
-    k_out[:, :, :kk] = torch.where(m, ko[:, :, :kk], torch.zeros((), dtype=torch.float16, device=dev))
-    v_out[:, :, :kk] = torch.where(m, vo[:, :, :kk], torch.zeros((), dtype=torch.float16, device=dev))
-    if r == P - 1:
-        k_out[:, :, kk:] = ko[:, :, kk + wl - W:]
-        v_out[:, :, kk:] = vo[:, :, kk + wl - W:]
+    # compaction of the rows this rank owns (+ the window rows on the last rank); (5) optional replication
+    k_out, v_out = lo.compact_owned(key_states, value_states, kv_idx, pos0, W, capacity, r == P - 1)
     if replicate:
         # exactly one non-zero contributor per element; summed as int32 words (two fp16 each) so that even -0.0 keeps its bits
         both = torch.stack([k_out, v_out])
@@ -276,8 +309,11 @@ def tp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_sta
     ko, vo, kv_idx, c = lo.update_kv_local(query_states, key_states, value_states, W, kernel_size, pooling, capacity, order)
     tsp = None
     if tsp_len:
-        parts = _all_gather(c.contiguous(), group)                       # [B,Hkv_l,n] per rank, rank order = head order
-        c_all = torch.cat(parts, dim=1).contiguous()                     # [B,Hkv,n]
+        P = dist.get_world_size(group)
+        n = c.shape[2]
+        parts = _all_gather(c.contiguous().view(-1), group).view(P, B, Hkv_l, n)   # rank order = head order
+        c_all = parts.permute(1, 0, 2, 3).reshape(B, P * Hkv_l, n)       # [B,Hkv,n] (a view when B == 1)
+        c_all = c_all.contiguous()
         t = lo.head_sum(c_all)
         tsp = lo.select_tsp(t, tsp_len - W, W)
     return ko, vo, tsp, kv_idx

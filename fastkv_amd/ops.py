@@ -163,8 +163,13 @@ def head_sum(c: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def compact(k: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, window: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """K/V gather + window append (utils.py:114-121) for given per-head indices [B,Hkv,cap-W] int64."""
+def compact(k: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, window: int, scores: Optional[torch.Tensor] = None,
+            return_sorted: bool = False):
+    """K/V gather + window append (utils.py:114-121) for given per-head indices [B,Hkv,cap-W] int64.
+
+    `scores` None: rows in the order of `idx`.  `scores` [B,Hkv,>=S-W] fp16 (the score rows `idx` was selected from, `idx`
+    ascending): rows in the reference's order -- score descending, ties by position (utils.py:113) -- ranked inside the copy
+    kernel; `return_sorted` adds the positions in that order."""
     _check_qkv(k, k, v)
     L = load()
     B, Hkv, S, D = k.shape
@@ -173,10 +178,21 @@ def compact(k: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, window: int) ->
     p = Problem(B=B, H=Hkv, Hkv=Hkv, S=S, D=D, window=window, kernel=1, pooling=0, capacity=cap, tsp_len=0, order=0, reserved=0)
     ko = torch.empty(B, Hkv, cap, D, dtype=torch.float16, device=k.device)
     vo = torch.empty_like(ko)
-    rc = L.fastkv_compact_f16(ctypes.byref(p), k.data_ptr(), _strides(k), v.data_ptr(), _strides(v), idx.data_ptr(),
-                              ko.data_ptr(), vo.data_ptr(), _stream())
-    check(rc, "compact")
-    return ko, vo
+    if scores is None:
+        rc = L.fastkv_compact_f16(ctypes.byref(p), k.data_ptr(), _strides(k), v.data_ptr(), _strides(v), idx.data_ptr(),
+                                  ko.data_ptr(), vo.data_ptr(), _stream())
+        check(rc, "compact")
+        return ko, vo
+    _require_cuda(scores)
+    assert scores.dtype == torch.float16 and scores.dim() == 3 and scores.shape[:2] == (B, Hkv) and scores.stride(2) == 1 \
+        and scores.stride(0) == Hkv * scores.stride(1)
+    srt = torch.empty_like(idx) if return_sorted else None
+    ws = _workspace(B * Hkv * ((cap - window + 7) // 8 * 8) * 2, k.device, "scratch")
+    rc = L.fastkv_compact_ranked_f16(ctypes.byref(p), k.data_ptr(), _strides(k), v.data_ptr(), _strides(v), idx.data_ptr(),
+                                     scores.data_ptr(), scores.stride(1), srt.data_ptr() if srt is not None else None,
+                                     ko.data_ptr(), vo.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "compact_ranked")
+    return (ko, vo, srt) if return_sorted else (ko, vo)
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -33,6 +33,7 @@ extern "C" {
 #define FASTKV_EWORKSPACE (-2) /* workspace too small */
 #define FASTKV_ELAUNCH (-3)    /* HIP launch error */
 #define FASTKV_EUNSUPPORTED (-4)
+#define FASTKV_EABORTED (-5)   /* an EARLIER fused launch gave up a bounded in-kernel wait; see fastkv_workspace_init */
 
 #define FASTKV_POOL_AVG 0 /* F.avg_pool1d(k, padding=k//2, stride=1)   utils.py:105-106 */
 #define FASTKV_POOL_MAX 1 /* F.max_pool1d(k, padding=k//2, stride=1)   utils.py:107-108 */
@@ -69,12 +70,27 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  * memset is needed and graph replays are safe.  The call is idempotent (a live control block keeps its epoch), so it may be
  * repeated or end up inside a captured graph.  A workspace that was never initialised makes the scoring kernel trap
  * (a loud HIP error at the next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
- * The fused scoring kernel also needs all its workgroups resident at once, so two of them must not overlap on one GPU:
- * calls on different streams of ONE process are chained by the library (an event dependency when the stream changes);
- * calls from different processes sharing a GPU, or graphs replayed concurrently on several streams, must set
- * FASTKV_FUSED=0 (the three-kernel path).
+ *
+ * Residency.  The fused scoring kernel and the split selection exchange partial results between workgroups INSIDE a launch,
+ * so a waiting workgroup needs its partners to be resident.  The library sizes those grids to what the device holds when
+ * it is otherwise idle (occupancy query), but HIP gives no residency guarantee next to other work (hipLaunchCooperativeKernel
+ * only checks the grid size at launch, and costs 15-20 us per launch on this chip).  What the library guarantees instead:
+ *   - another kernel holding compute units (another stream, RCCL, another process) only DELAYS the launch: its late
+ *     workgroups start when units free up and the waiting ones are served then;
+ *   - every in-kernel wait is bounded by wall-clock time (FASTKV_SPIN_LIMIT_MS, default 2000).  A workgroup that gives up
+ *     tells the rest of the launch (which exits at its next poll) and raises a flag in pinned host memory; nothing traps,
+ *     nothing hangs, the HIP context stays usable, indices are clamped so the following stages cannot fault.  The outputs
+ *     of that call are invalid, and the NEXT operator call in the process (or fastkv_last_status()) returns FASTKV_EABORTED
+ *     once -- the asynchronous-error convention of the HIP runtime itself;
+ *   - calls on different streams of ONE process are chained by the library (an event dependency when the stream changes,
+ *     taken under a lock that also covers the enqueue), so two such launches of one process never overlap;
+ *   - processes that share a GPU, or graphs replayed concurrently on several streams, should set FASTKV_FUSED=0 (the
+ *     three-kernel scoring path has no in-launch waits); if they do not, overlapping launches end in FASTKV_EABORTED.
  */
 int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+/* FASTKV_EABORTED if a launch of this process gave up a bounded wait since the last report (clears the report), else 0.
+ * Host-only (reads a word of pinned memory); call it after synchronising to learn about the calls just completed. */
+int fastkv_last_status(void);
 
 /*
  * The whole operator: replaces the compress branch of FastKVCluster.update_kv (utils.py:93-132).
@@ -134,6 +150,18 @@ int fastkv_compact_f16(const fastkv_problem *p, const void *k, const int64_t k_s
                        void *k_out, void *v_out, void *stream);
 
 /*
+ * Stage 3 alone in the reference's row order (FASTKV_ORDER_SCORE): idx_asc int64 [B,Hkv,capacity-window] are the winners
+ * in ASCENDING position (fastkv_select_f16 with FASTKV_ORDER_INDEX), scores fp16 [B*Hkv rows, >= S-window] their score rows;
+ * row i of a head lands in slot rank(i) (score descending, ties by ascending position: utils.py:113), found by comparison
+ * counting inside the copy kernel -- no sort.  idx_sorted_out (optional) receives the positions in that order.
+ * workspace: B*Hkv * round_up(capacity-window, 8) * 2 bytes, 16-B aligned.
+ */
+int fastkv_compact_ranked_f16(const fastkv_problem *p, const void *k, const int64_t k_strides[4],
+                              const void *v, const int64_t v_strides[4], const int64_t *idx_asc, const void *scores,
+                              int64_t score_row_stride, int64_t *idx_sorted_out, void *k_out, void *v_out, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
+/*
  * Generic row gather: dst[b, r, :] = src[b, idx[b, r], :]; rows of `row_bytes` (multiple of 16).
  * Serves the TSP propagation of hidden states and position ids (llama_model.py:254-257).
  */
@@ -185,11 +213,43 @@ int fastkv_sp_scores_f16(const fastkv_problem *p, void *logits, const fastkv_sp_
                          void *stream);
 
 /*
+ * Candidate exchange of the sequence-sharded selection (utils.py:113 / :127 across ranks): a global winner is always a
+ * canonical local winner of the shard that owns it, so every rank contributes its local top-k as fixed-size records
+ * {fp16 score bits << 32 | global position} (padded with {-inf, 0xffffffff}), ONE all-gather moves them (the records of
+ * the per-head rows and of the TSP row share the buffer), and the final canonical top-k over the P*k candidates of a
+ * row -- listed rank by rank, i.e. in ascending global position -- equals the single-device selection, ties included.
+ *   pack    records_out[row, i] for i < k from the rank's ascending local winners idx_local [rows, kl] (kl <= k) of the
+ *           fp16 rows `scores` (row stride in elements); pos0 = global position of the shard's first key
+ *   unpack  gathered records (rank r's block at records + r*rank_stride, this row set at `offset` inside a block)
+ *           -> fp16 rows scores_out [rows, P*k] for fastkv_select_f16
+ *   pick    idx_out[row, j] = position of candidate sel[row, j] (j < kout), followed by `append` window positions
+ *           n_glob, n_glob+1, ... (utils.py:128-129)
+ */
+int fastkv_sp_pack_f16(const void *scores, int64_t rows, int64_t row_stride, const int64_t *idx_local, int64_t kl, int64_t k,
+                       int64_t pos0, int64_t *records_out, void *stream);
+int fastkv_sp_unpack_f16(const int64_t *records, int64_t rank_stride, int64_t offset, int32_t P, int64_t rows, int64_t k,
+                         void *scores_out, int64_t out_stride, void *stream);
+int fastkv_sp_pick(const int64_t *records, int64_t rank_stride, int64_t offset, int64_t rows, int64_t k, const int64_t *sel,
+                   int64_t kout, int64_t append, int64_t n_glob, int64_t *idx_out, void *stream);
+/*
+ * K/V rows of the global winners kv_idx [B,Hkv,capacity-window] (global positions) that lie in this rank's shard
+ * [pos0, pos0 + S_r), written to their slots of k_out / v_out [B,Hkv,capacity,D] contiguous; slots owned by other ranks
+ * are written as zeros (the ranks' outputs add up to utils.py:114-121's result).  window_owner != 0 (the last rank): the
+ * shard's last `window` rows fill the last `window` slots.  k, v: the rank's [B,Hkv,S_r,D] slices, element strides.
+ */
+int fastkv_sp_compact_f16(int32_t B, int32_t Hkv, int32_t S_r, int32_t D, int32_t window, int32_t capacity, const void *k,
+                          const int64_t k_strides[4], const void *v, const int64_t v_strides[4], const int64_t *kv_idx, int64_t pos0,
+                          int32_t window_owner, void *k_out, void *v_out, void *stream);
+
+/*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
  * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b)) so tests can compare the GPU bit-for-bit with the CPU oracle.
  */
 int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream);
+/* Test hook: `wgs` 256-thread workgroups that each hold `lds_bytes` of LDS for `usec` microseconds -- "another kernel is
+ * holding compute units" for the residency tests of the in-launch hand-offs. */
+int fastkv_debug_occupy(int wgs, int lds_bytes, int64_t usec, void *stream);
 
 /*
  * Measurement hooks (bench.py): when enabled, every kernel launch is bracketed by HIP events on its stream.

@@ -9,6 +9,8 @@ import torch
 
 from oracle import fastkv_oracle as O
 
+SP_PAD_RECORD = (0xFC00 << 32) | 0xFFFFFFFF      # csrc/sp.hip: SP_PAD
+
 
 def _i64x4(t):
     return (ctypes.c_int64 * 4)(*t.stride())
@@ -60,12 +62,40 @@ class OracleLocalOps:
         return torch.stack([O.canonical_topk(rows2d[i], k, order) for i in range(rows2d.shape[0])]) if rows2d.shape[0] else \
             torch.empty(0, k, dtype=torch.int64)
 
-    def compact(self, k, v, idx, window):
-        B, Hkv, S, D = k.shape
-        sel = idx[..., None].expand(-1, -1, -1, D)
-        ko = torch.cat([torch.gather(k, 2, sel), k[:, :, S - window:]], dim=2)
-        vo = torch.cat([torch.gather(v, 2, sel), v[:, :, S - window:]], dim=2)
-        return ko.contiguous(), vo.contiguous()
+    # ---- twins of csrc/sp.hip (index arithmetic only; the semantics the HIP stages are tested against on the GPU)
+    def local_candidates(self, rows2d, k, pos0, records):
+        rows, n_own = rows2d.shape
+        kl = min(k, n_own)
+        records.fill_(SP_PAD_RECORD)
+        if kl > 0:
+            li = self.select(rows2d, kl, "index")
+            bits = torch.gather(rows2d, 1, li).contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+            records[:, :kl] = (bits << 32) | ((li + pos0) & 0xFFFFFFFF)
+
+    def merge_candidates(self, allc, offset, rows, k, order, append=0, n_glob=0):
+        P = allc.shape[0]
+        rec = allc[:, offset:offset + rows * k].view(P, rows, k).permute(1, 0, 2).reshape(rows, P * k)     # rank-major candidate list
+        bits = ((rec >> 32) & 0xFFFF).to(torch.int32)
+        sc = torch.where(bits >= 0x8000, bits - 0x10000, bits).to(torch.int16).view(torch.float16)
+        sel = self.select(sc, k, order)
+        pos = torch.gather(rec & 0xFFFFFFFF, 1, sel)
+        if append:
+            pos = torch.cat([pos, torch.arange(n_glob, n_glob + append, dtype=torch.int64).expand(rows, -1)], dim=1)
+        return pos
+
+    def compact_owned(self, k, v, kv_idx, pos0, window, capacity, window_owner):
+        B, Hkv, S_r, D = k.shape
+        kk = capacity - window
+        own = (kv_idx >= pos0) & (kv_idx < pos0 + S_r)
+        li = torch.where(own, kv_idx - pos0, torch.zeros_like(kv_idx))[..., None].expand(-1, -1, -1, D)
+        outs = []
+        for t in (k, v):
+            o = torch.zeros(B, Hkv, capacity, D, dtype=t.dtype)
+            o[:, :, :kk] = torch.where(own[..., None], torch.gather(t, 2, li), torch.zeros((), dtype=t.dtype))
+            if window_owner:
+                o[:, :, kk:] = t[:, :, S_r - window:]
+            outs.append(o)
+        return outs[0], outs[1]
 
 
 class OracleTPOps:

@@ -29,20 +29,35 @@ def _worker(rank, world, port, case, lens, q_out):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from fastkv_amd.dist import sp_update_kv
+        import fastkv_amd.dist as D
         from gen_inputs import make_qkv
         from oracle import fastkv_oracle as O
         from sp_oracle_ops import OracleLocalOps
         O.set_threads(2)
         q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], full_q=True)
         lo, hi = sum(lens[:rank]), sum(lens[:rank + 1])
-        out = sp_update_kv(k[:, :, lo:hi], q[:, :, lo:hi], v[:, :, lo:hi], window_size=case["W"], kernel_size=case["ks"],
-                           pooling=case["pooling"], capacity=case["cap"], tsp_len=case["tsp_len"], order=case["order"],
-                           local_ops=OracleLocalOps(), shard_lengths=None if case.get("discover") else lens)
+        replicate = case.get("replicate", False)
+        before = dict(D.COLLECTIVES)
+        try:
+            out = D.sp_update_kv(k[:, :, lo:hi], q[:, :, lo:hi], v[:, :, lo:hi], window_size=case["W"], kernel_size=case["ks"],
+                                 pooling=case["pooling"], capacity=case["cap"], tsp_len=case["tsp_len"], order=case["order"],
+                                 local_ops=OracleLocalOps(), shard_lengths=None if case.get("discover") else lens,
+                                 replicate=replicate)
+        except ValueError as e:
+            q_out.put((rank, "ValueError" if case.get("expect_error") else "EXC " + repr(e)))
+            return
+        ncoll = sum(D.COLLECTIVES.values()) - sum(before.values())
         want = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], case["order"])
-        ok = torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and torch.equal(out[3], want[2])
+        ko, vo = out[0], out[1]
+        if not replicate:
+            # every rank holds only the rows it owns: the ranks' tensors add up (as bit patterns) to the single-process result
+            both = torch.stack([ko, vo]).view(torch.int32)
+            dist.all_reduce(both, op=dist.ReduceOp.SUM)
+            ko, vo = both.view(torch.float16).view(2, *out[0].shape)
+        ok = torch.equal(ko, want[0]) and torch.equal(vo, want[1]) and torch.equal(out[3], want[2])
         ok = ok and ((out[2] is None and want[3] is None) or torch.equal(out[2], want[3]))
-        q_out.put((rank, bool(ok)))
+        ok = ok and ncoll == (5 if replicate else 4)                 # the link budget of fastkv_amd/dist.py, TSP layer or not
+        q_out.put((rank, bool(ok) if ok else f"mismatch (collectives {ncoll})"))
     except Exception as e:   # noqa: BLE001
         import traceback
         q_out.put((rank, "EXC " + repr(e) + traceback.format_exc()))
@@ -51,18 +66,20 @@ def _worker(rank, world, port, case, lens, q_out):
 
 
 CASES = [
-    # two even shards, avgpool, TSP on, reference row order
-    (dict(seed=41, B=1, H=8, Hkv=2, S=512, D=128, W=8, ks=7, pooling="avgpool", cap=96, tsp_len=160, order="score"), [256, 256]),
-    # three ragged shards, maxpool (plateaus straddle shard borders), B=2, index order, lengths discovered by all-gather
+    # two even shards, avgpool, TSP on, reference row order, replicated output
+    (dict(seed=41, B=1, H=8, Hkv=2, S=512, D=128, W=8, ks=7, pooling="avgpool", cap=96, tsp_len=160, order="score", replicate=True),
+     [256, 256]),
+    # three ragged shards, maxpool (plateaus straddle shard borders), B=2, index order, lengths discovered by the first all-gather
     (dict(seed=42, B=2, H=4, Hkv=2, S=700, D=64, W=8, ks=5, pooling="maxpool", cap=128, tsp_len=0, order="index", discover=True),
      [300, 150, 250]),
-    # budget larger than a shard: the last rank contributes fewer candidates than k
+    # budget larger than a shard: the last rank contributes fewer candidates than k; rows stay where they are owned
     (dict(seed=43, B=1, H=8, Hkv=1, S=400, D=128, W=8, ks=7, pooling="maxpool", cap=300, tsp_len=350, order="score"), [350, 50]),
+    # a middle shard shorter than the window (but not than the halo): no window rows there, nothing special
+    (dict(seed=44, B=1, H=8, Hkv=2, S=600, D=128, W=8, ks=7, pooling="avgpool", cap=64, tsp_len=100, order="score"), [290, 5, 305]),
 ]
 
 
-@pytest.mark.parametrize("case,lens", CASES)
-def test_sequence_sharded_matches_single_process_oracle(case, lens):
+def _run(case, lens, timeout=300):
     world = len(lens)
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue()
@@ -70,10 +87,29 @@ def test_sequence_sharded_matches_single_process_oracle(case, lens):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, lens, q_out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q_out.get(timeout=300) for _ in range(world)]
+    res = [q_out.get(timeout=timeout) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
+    return res
+
+
+@pytest.mark.parametrize("case,lens", CASES)
+def test_sequence_sharded_matches_single_process_oracle(case, lens):
+    res = _run(case, lens)
     assert all(r[1] is True for r in res), res
+
+
+@pytest.mark.parametrize("discover", [False, True])
+def test_unusable_split_fails_on_every_rank_together(discover):
+    """A shard shorter than the pooling halo (or a last shard without the whole window): every rank raises the same
+    ValueError -- before any collective when the lengths are given, right after the first one when they are discovered --
+    instead of one rank failing late and its peers waiting in a collective for ever."""
+    case = dict(seed=45, B=1, H=8, Hkv=2, S=400, D=128, W=8, ks=7, pooling="avgpool", cap=64, tsp_len=0, order="score",
+                discover=discover, expect_error=True)
+    res = _run(case, [200, 2, 198], timeout=120)
+    assert all(r[1] == "ValueError" for r in res), res
+    res = _run(case, [391, 9], timeout=120)
+    assert all(r[1] == "ValueError" for r in res), res
 
 
 def _tp_worker(rank, world, port, case, q_out):

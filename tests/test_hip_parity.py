@@ -99,6 +99,14 @@ def test_stage_apis_and_properties(dev):
     idx3 = ops.select(c[0], 200, "score")[None]
     ko, vo = ops.compact(kd, vd, idx3.contiguous(), 8)
     assert torch.equal(ko.cpu(), expected_kv(k, idx3.cpu(), 8)) and torch.equal(vo.cpu(), expected_kv(v, idx3.cpu(), 8))
+    # stage 3 in the reference's row order from the ASCENDING winners + their score rows (fastkv_compact_ranked_f16): equals the
+    # explicit score-ordered gather, ties by position included (maxpool plateaus)
+    for kk in (1, 200, 1000):
+        asc = ops.select(c[0], kk, "index")[None].contiguous()
+        srt = ops.select(c[0], kk, "score")[None].contiguous()
+        ko2, vo2, got = ops.compact(kd, vd, asc, 8, scores=c, return_sorted=True)
+        assert torch.equal(got.cpu(), srt.cpu()), kk
+        assert torch.equal(ko2.cpu(), expected_kv(k, srt.cpu(), 8)) and torch.equal(vo2.cpu(), expected_kv(v, srt.cpu(), 8))
 
 
 def test_degenerate_rows(dev):
@@ -536,3 +544,64 @@ def test_keep_all_layers_bit_exact(shape, dev):
     want = O.update_kv(q, k, v, 8, s["ks"], s["pooling"], s["S"], 0, "score")
     assert torch.equal(kslab[:, :, :s["S"]].cpu(), want[0]) and torch.equal(vslab[:, :, :s["S"]].cpu(), want[1])
     assert not kslab[:, :, s["S"]:].any()
+
+
+# ------------------------------------------------------------------------------------------------ residency of the in-launch hand-offs
+_RESIDENCY_CHILD = """
+import ctypes, sys, time, torch
+sys.path.insert(0, 'tests')
+from gen_inputs import make_qkv
+from fastkv_amd import ops
+from fastkv_amd._lib import load, FastKVNativeError
+from oracle import fastkv_oracle as O
+L = load(); dev = torch.device('cuda:0')
+q, k, v = make_qkv(77, 1, 32, 8, 32768, 128, 8)
+qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
+want = O.update_kv(q, k, v, 8, 7, 'maxpool', 2048, 2048, 'score')
+def run():
+    out = ops.update_kv(qd, kd, vd, 8, 7, 'maxpool', 2048, 2048, 'score', return_indices=True)
+    torch.cuda.synchronize()
+    return out
+def same(out):
+    return torch.equal(out[0].cpu(), want[0]) and torch.equal(out[1].cpu(), want[1]) and torch.equal(out[3].cpu(), want[2]) \\
+        and torch.equal(out[2].cpu(), want[3])
+assert same(run()) and L.fastkv_last_status() == 0                      # idle GPU
+side = torch.cuda.Stream()
+# "another kernel holds compute units": 128 workgroups with 128 KiB of LDS each sit on half of the chip for HOLD_MS
+assert L.fastkv_debug_occupy(128, 128 * 1024, HOLD_MS * 1000, side.cuda_stream) == 0
+time.sleep(0.02)
+t0 = time.perf_counter()
+out = run()
+dt = (time.perf_counter() - t0) * 1e3
+print('held call took %.1f ms' % dt)
+"""
+
+
+def test_operator_next_to_a_kernel_that_holds_half_the_chip(dev):
+    """A long-running kernel on another stream holds half of the compute units while the operator runs (32k shape: the fused
+    scoring kernel's 512 workgroups and the split selection wait for partners that cannot become resident until the other
+    kernel ends).  The launch is delayed, not broken: same bits as the oracle, no report."""
+    r = _child("HOLD_MS = 300\n" + _RESIDENCY_CHILD +
+               "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nprint('child ok')\n", {})
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_abandoned_launch_is_reported_not_trapped(dev):
+    """The same with a wait limit (FASTKV_SPIN_LIMIT_MS=40) shorter than the other kernel's hold: the waiting workgroups give
+    up, the launch ends (no trap, no hang, no fault in the stages behind it), the process learns about it through
+    FASTKV_EABORTED at the next call -- and the context is alive: the call after that is bit-exact again."""
+    code = "HOLD_MS = 600\n" + _RESIDENCY_CHILD + """
+assert dt < 550, dt                                                         # it did not wait for the other kernel
+try:
+    run()                                                                   # the NEXT call reports the abandoned one
+    raise SystemExit('no report')
+except FastKVNativeError as e:
+    assert 'gave up' in str(e), str(e)
+torch.cuda.synchronize()                                                    # the holding kernel has ended by now or soon
+time.sleep(0.7)
+assert L.fastkv_last_status() == 0
+assert same(run()) and L.fastkv_last_status() == 0
+print('child ok')
+"""
+    r = _child(code, {"FASTKV_SPIN_LIMIT_MS": "40"})
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
