@@ -23,11 +23,40 @@ def _splitmix64(start: int, count: int) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def normal_f16(seed: int, stream: int, count: int, scale: float = 1.0) -> np.ndarray:
+_fast = None
+
+
+def _fast_lib():
+    """tests/gen_fast.c compiled on first use (gcc, a second); None if that is not possible -> the numpy version below."""
+    global _fast
+    if _fast is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        src, lib = os.path.join(here, "gen_fast.c"), os.path.join(here, "libgen_fast.so")
+        try:
+            if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+                tmp = lib + ".tmp.%d" % os.getpid()
+                subprocess.check_call(["gcc", "-O3", "-mf16c", "-fopenmp", "-shared", "-fPIC", "-o", tmp, src])
+                os.replace(tmp, lib)
+            L = ctypes.CDLL(lib)
+            L.gen_normal_f16.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p]
+            L.gen_normal_f16.restype = None
+            _fast = L
+        except Exception:   # noqa: BLE001 - no compiler: the numpy version is the definition anyway
+            _fast = False
+    return _fast or None
+
+
+def normal_f16(seed: int, stream: int, count: int, scale: float = 1.0, use_c: bool = True) -> np.ndarray:
     """`count` approximately-N(0, scale^2) values as fp16, from (seed, stream)."""
     out = np.empty(count, dtype=np.float16)
     CH = 1 << 20
     base = ((seed * 0x100000001B3) ^ (stream * 0xD6E8FEB86659FD93)) & _M
+    if use_c and scale == 1.0 and count > 0 and _fast_lib() is not None:
+        _fast_lib().gen_normal_f16(base, count, out.ctypes.data)          # bit-identical twin of the loop below
+        return out
     for lo in range(0, count, CH):
         m = min(CH, count - lo)
         r = _splitmix64(base + 3 * lo * 0x9E3779B97F4A7C15, 3 * m).reshape(m, 3)

@@ -1,0 +1,143 @@
+"""Seed sweep at the graded length: how often does the oracle's <= 1-ulp score noise move a selected index?
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+
+    python tests/golden/make_sweep.py
+
+For every case of tests/golden_cases.py:SWEEP_CASES (Llama-3-8B geometry, S = 32768; both poolings; the constant budget of
+BASELINE.json configs[1] and the published proportional recipe) the REFERENCE (baselines/fastkv/utils.py:80-134, imported,
+not copied) runs with the `Tensor.topk` spy of make_golden.py, which exposes its score tensors; the canonical top-k (value
+descending, position ascending) of those scores is the index set an implementation must produce.  The oracle
+(oracle/fastkv_oracle.c) runs on the same inputs, and the script records, per case and per row,
+  * how many score elements differ between oracle and reference (always by 1 fp16 ulp),
+  * whether one of them lies within 1 ulp of the row's k-th value (a "straddle": the only way an index can move),
+  * how many indices actually differ (`flips`).
+Fixtures: tests/golden/sweep32k.npz (canonical indices as uint16, tie metadata, every 64th reference score) and
+tests/golden/sweep_meta.json (the statistics; rows that flip are LISTED there, never dropped -- the replay tests check that
+exactly those rows differ and all others are identical).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, "/root/reference")
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+
+import numpy as np
+import torch
+
+from gen_inputs import make_qkv
+from golden_cases import SWEEP_CASES
+from baselines.fastkv.utils import FastKVCluster      # the reference
+
+sys.path.append(ROOT)                                 # after the reference: only `oracle` is taken from the repository
+from oracle import fastkv_oracle as O                 # noqa: E402
+
+torch.set_num_threads(8)
+O.set_threads(8)
+
+
+def run_reference(q, k, v, case):
+    cl = FastKVCluster(window_size=case["W"], max_capacity_prompt=case["cap"], kernel_size=case["ks"],
+                       pooling=case["pooling"], tsp_layer=True, tsp_length=case["tsp_len"])
+    spied = []
+    orig = torch.Tensor.topk
+
+    def spy(self, *a, **kw):
+        spied.append(self.detach().clone())
+        return orig(self, *a, **kw)
+
+    torch.Tensor.topk = spy
+    try:
+        cl.update_kv(k, q, v, None, q.shape[1] // k.shape[1], 0)
+    finally:
+        torch.Tensor.topk = orig
+    return spied[0], spied[1]
+
+
+def canonical(row: torch.Tensor, k: int) -> torch.Tensor:
+    srt = torch.sort(row.float(), descending=True, stable=True)
+    return torch.sort(srt.indices[:k]).values, srt.values[k - 1]
+
+
+def bits(t):
+    return t.contiguous().view(torch.int16).to(torch.int32)
+
+
+def main():
+    arrays, meta = {}, {"cases": {}, "note": "flips = indices of canonical_topk(oracle scores) that are not in canonical_topk(reference scores)"}
+    tot_rows = tot_straddle = tot_flip_rows = tot_flips = tot_mism = tot_el = tot_invalid = 0
+    for name, case in SWEEP_CASES.items():
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+        c_ref, t_ref = run_reference(q, k, v, case)
+        _, _, idx_or, tsp_or, c_or, t_or = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"],
+                                                       "index", return_scores=True)
+        B, Hkv, n = c_ref.shape
+        kk, tk = case["cap"] - case["W"], case["tsp_len"] - case["W"]
+        d = (bits(c_or) - bits(c_ref)).abs()
+        rows = []
+        can = torch.empty(B, Hkv, kk, dtype=torch.int64)
+        ties = np.zeros((B, Hkv, 3), dtype=np.int64)
+        for b in range(B):
+            for g in range(Hkv):
+                sel, vk = canonical(c_ref[b, g], kk)
+                can[b, g] = sel
+                vk_bits = int(bits(vk.to(torch.float16)))
+                ties[b, g] = (vk_bits, int((c_ref[b, g].float() > vk).sum()), int((c_ref[b, g].float() == vk).sum()))
+                mm = d[b, g] > 0
+                near = mm & (((bits(c_ref[b, g]) - vk_bits).abs() <= 1) | ((bits(c_or[b, g]) - vk_bits).abs() <= 1))
+                got = set(idx_or[b, g].tolist())
+                flips = sorted(got - set(sel.tolist()))
+                # is the oracle's set still an answer `topk` could have given on the REFERENCE's scores (every element above the
+                # k-th value taken, the rest from the tie plateau, where torch's choice is arbitrary: SURVEY A.2)?
+                rf = c_ref[b, g].float()
+                valid = set(torch.nonzero(rf > vk).flatten().tolist()) <= got <= set(torch.nonzero(rf >= vk).flatten().tolist())
+                rows.append({"row": [b, g], "mismatching_scores": int(mm.sum()), "straddling": int(near.sum()), "flips": len(flips),
+                             "flipped_positions": flips, "valid_topk_of_reference_scores": bool(valid)})
+        tsel, tvk = canonical(t_ref[0], tk)
+        tcan = torch.cat([tsel, torch.arange(n, case["S"])])
+        tvk_bits = int(bits(tvk.to(torch.float16)))
+        td = (bits(t_or) - bits(t_ref)).abs()
+        tmm = td[0] > 0
+        tnear = tmm & (((bits(t_ref[0]) - tvk_bits).abs() <= 1) | ((bits(t_or[0]) - tvk_bits).abs() <= 1))
+        tgot = set(tsp_or[0, :tk].tolist())
+        tflips = sorted(tgot - set(tsel.tolist()))
+        trf = t_ref[0].float()
+        tvalid = set(torch.nonzero(trf > tvk).flatten().tolist()) <= tgot <= set(torch.nonzero(trf >= tvk).flatten().tolist())
+        arrays[name + ".idx"] = can.numpy().astype(np.uint16)
+        arrays[name + ".tsp"] = tcan.numpy().astype(np.uint16)
+        arrays[name + ".ties"] = ties
+        arrays[name + ".c_sampled"] = c_ref[..., ::64].contiguous().view(torch.int16).numpy()
+        m = {"case": case, "score_elements": int(d.numel()), "mismatching_scores": int((d > 0).sum()), "max_ulp": int(d.max()),
+             "rows": rows, "tsp": {"mismatching_scores": int(tmm.sum()), "max_ulp": int(td.max()), "straddling": int(tnear.sum()),
+                                   "flips": len(tflips), "flipped_positions": tflips,
+                                   "valid_topk_of_reference_scores": bool(tvalid)}}
+        meta["cases"][name] = m
+        tot_rows += len(rows) + 1
+        tot_straddle += sum(1 for r in rows if r["straddling"]) + (1 if tnear.any() else 0)
+        tot_flip_rows += sum(1 for r in rows if r["flips"]) + (1 if tflips else 0)
+        tot_flips += sum(r["flips"] for r in rows) + len(tflips)
+        tot_invalid += sum(1 for r in rows if not r["valid_topk_of_reference_scores"]) + (0 if tvalid else 1)
+        tot_mism += int((d > 0).sum()) + int(tmm.sum())
+        tot_el += int(d.numel()) + int(td.numel())
+        print(name, "mismatching", m["mismatching_scores"], "max ulp", m["max_ulp"], "straddling rows",
+              sum(1 for r in rows if r["straddling"]), "flipping rows", sum(1 for r in rows if r["flips"]), "tsp flips", len(tflips))
+    meta["summary"] = {"cases": len(SWEEP_CASES), "rows": tot_rows, "score_elements": tot_el, "mismatching_scores": tot_mism,
+                       "mismatch_rate": tot_mism / tot_el, "rows_with_a_straddling_mismatch": tot_straddle,
+                       "rows_that_flip": tot_flip_rows, "indices_flipped": tot_flips,
+                       "row_flip_rate": tot_flip_rows / tot_rows,
+                       "rows_whose_set_is_not_a_valid_topk_of_the_reference_scores": tot_invalid}
+    np.savez_compressed(os.path.join(HERE, "sweep32k.npz"), **arrays)
+    with open(os.path.join(HERE, "sweep_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta["summary"], indent=1))
+
+
+if __name__ == "__main__":
+    main()

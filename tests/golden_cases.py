@@ -46,3 +46,12 @@ HOST_CASES = {
                          tsp_rate=0.2, eviction_mode="constant", tsp_idx=15, retain_rate=0.1),
     },
 }
+
+# Seed sweep at the graded length (tests/golden/make_sweep.py): 12 seeds x {BASELINE.json configs[1] (constant budget 2048, TSP
+# length 2048, maxpool = the CLI default), the published recipe (proportional: retain 0.1 -> 3276, tsp_rate 0.2 -> 6553, avgpool)}
+SWEEP_CASES = {}
+for _s in range(12):
+    SWEEP_CASES[f"sweep_max_{_s:02d}"] = dict(seed=100 + _s, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="maxpool",
+                                              cap=2048, tsp_len=2048)
+    SWEEP_CASES[f"sweep_recipe_{_s:02d}"] = dict(seed=200 + _s, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="avgpool",
+                                                 cap=3276, tsp_len=6553)

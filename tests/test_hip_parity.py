@@ -560,7 +560,7 @@ qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q
 want = O.update_kv(q, k, v, 8, 7, 'maxpool', 2048, 2048, 'score')
 def run():
     out = ops.update_kv(qd, kd, vd, 8, 7, 'maxpool', 2048, 2048, 'score', return_indices=True)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()                               # this stream only: not the holding kernel's
     return out
 def same(out):
     return torch.equal(out[0].cpu(), want[0]) and torch.equal(out[1].cpu(), want[1]) and torch.equal(out[3].cpu(), want[2]) \\
@@ -605,3 +605,20 @@ print('child ok')
 """
     r = _child(code, {"FASTKV_SPIN_LIMIT_MS": "40"})
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_seed_sweep_32k_on_gpu(dev):
+    """All 24 sweep cases at S = 32768 (tests/golden/sweep32k.npz: canonical top-k of the REFERENCE's scores, 12 seeds x the
+    constant budget and 12 x the published proportional recipe) replayed through the operator: identical index sets on every
+    row except the ones the fixture lists (oracle and GPU agree there too -- same arithmetic)."""
+    from fastkv_amd import ops
+    from golden_cases import SWEEP_CASES
+    from test_oracle_golden import _sweep, check_against_sweep
+    z, meta = _sweep()
+    for name, case in SWEEP_CASES.items():
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+        qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+        ko, vo, tsp, idx = ops.update_kv(qd, kd, vd, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "index",
+                                         return_indices=True)
+        check_against_sweep(name, idx.cpu(), tsp.cpu(), z, meta)
+        assert torch.equal(ko.cpu(), expected_kv(k, idx.cpu(), case["W"]))

@@ -136,3 +136,57 @@ def test_oracle_gather_rows():
     src = torch.arange(50 * 24, dtype=torch.float16).view(50, 24)
     idx = torch.tensor([3, 0, 49, 7, 7], dtype=torch.int64)
     assert torch.equal(O.gather_rows(src, idx), src[idx])
+
+
+# ------------------------------------------------------------------------------------------------ seed sweep at S = 32768
+def _sweep():
+    import json
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "sweep32k.npz"))
+    with open(os.path.join(GOLDEN, "sweep_meta.json")) as f:
+        return z, json.load(f)
+
+
+def check_against_sweep(name, kv_idx, tsp_idx, z, meta):
+    """kv_idx [1,Hkv,k] / tsp_idx [1,tsp_len] (ascending) of an implementation vs canonical_topk(REFERENCE scores) of sweep case
+    `name`: identical on every row, except the rows tests/golden/sweep_meta.json lists as flipping (a 1-ulp score difference
+    at the k-th value), where exactly the listed positions differ."""
+    m = meta["cases"][name]
+    want = torch.from_numpy(z[name + ".idx"].astype(np.int64))
+    for r in m["rows"]:
+        b, g = r["row"]
+        got, ref = set(kv_idx[b, g].tolist()), set(want[b, g].tolist())
+        assert sorted(got - ref) == r["flipped_positions"] and len(ref - got) == r["flips"], (name, r["row"])
+        if not r["flips"]:
+            assert torch.equal(kv_idx[b, g], want[b, g])
+    tw = torch.from_numpy(z[name + ".tsp"].astype(np.int64))
+    got, ref = set(tsp_idx[0].tolist()), set(tw.tolist())
+    assert sorted(got - ref) == m["tsp"]["flipped_positions"] and len(ref - got) == m["tsp"]["flips"], name
+    if not m["tsp"]["flips"]:
+        assert torch.equal(tsp_idx[0], tw)
+
+
+def test_generator_c_twin_is_bit_identical():
+    """tests/gen_fast.c (used when gcc is there) == the numpy definition of tests/gen_inputs.py, bit for bit."""
+    import gen_inputs as G
+    for seed, stream, n in ((0, 1, 300007), (5, 2, (1 << 20) + 17), (123456789123, 3, 777)):
+        a, b = G.normal_f16(seed, stream, n, use_c=False), G.normal_f16(seed, stream, n)
+        assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+
+
+def test_seed_sweep_32k_flip_statistics():
+    """24 seeds at the graded length (12 x BASELINE configs[1], 12 x the published proportional recipe): the oracle's indices
+    equal canonical_topk(reference scores) on every row but the ones the fixture lists -- and the committed statistics say how
+    rare those are (tests/golden/make_sweep.py: 216 rows, 6 with one or two moved indices, 1 of them outside the reference's
+    own tie plateau)."""
+    from golden_cases import SWEEP_CASES
+    z, meta = _sweep()
+    s = meta["summary"]
+    assert s["cases"] == len(SWEEP_CASES) >= 20 and s["rows"] == 216
+    assert s["mismatch_rate"] < 1e-3 and s["rows_that_flip"] <= 6 and s["indices_flipped"] <= 7
+    assert s["rows_whose_set_is_not_a_valid_topk_of_the_reference_scores"] <= 1
+    for name, case in SWEEP_CASES.items():
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+        _, _, idx, tsp = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "index")
+        check_against_sweep(name, idx, tsp, z, meta)
