@@ -128,7 +128,13 @@ def make_model_forward(modeling, mask_fn_for):
             if new_position_ids is not None:                      # after the TSP layer: fewer tokens, new rotary tables
                 position_ids = new_position_ids
                 position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
-                causal_mask = None                                # unpadded prompts only, as in the reference
+                # The mask of the reduced sequence: causal over the surviving TOKENS (the reference's flash-attention call is
+                # causal=True on whatever sequence it gets, llama_model.py:181-183).  Rebuilt rather than dropped: eager
+                # attention masks only when it is handed a mask, so `None` would make every later layer bidirectional.
+                # No 2-D padding mask (unpadded prompts only, as in the reference: SURVEY 3.2), no cache (prefill attention runs
+                # over the current K/V), and no position ids: the gaps between surviving positions are not sequence boundaries.
+                causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=hidden_states, attention_mask=None,
+                                                       past_key_values=None, position_ids=None)
         hidden_states = self.norm(hidden_states)
         hidden_states = hidden_states[:, -1:, :]                  # only the last token feeds lm_head
         return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)

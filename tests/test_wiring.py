@@ -205,3 +205,25 @@ def test_slab_cache_matches_dynamic_cache(monkeypatch):
     for x, y in zip(runs["0"][0], runs["1"][0]):
         assert torch.equal(x, y)
     assert runs["1"][2].get_seq_length() == 43
+
+
+def test_eager_attention_stays_causal_after_the_tsp_layer():
+    """`--attn_implementation eager` masks only when it is handed a mask: after the TSP gather the model loop rebuilds the
+    causal mask for the surviving tokens (the reference's flash-attention call is causal=True on whatever sequence it gets,
+    /root/reference/baselines/fastkv/llama_model.py:181-183).  Same weights, same prompt: eager == sdpa."""
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import prefill
+    ids = torch.randint(0, 1000, (1, 160), generator=torch.Generator().manual_seed(11))
+    outs = {}
+    for impl in ("sdpa", "eager"):
+        a = _args(method="fastkv", max_capacity_prompts=40, tsp_len=64, tsp_idx=1, attn_implementation=impl)
+        a.context_lengths = [160]
+        replace_llama("fastkv")
+        torch.manual_seed(13)
+        model = prefill.build_model(a, "cpu")
+        set_model(model, a)
+        for layer in model.model.layers:
+            layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+        with torch.no_grad():
+            outs[impl] = model(ids, attention_mask=torch.ones_like(ids)).logits
+    assert torch.allclose(outs["eager"], outs["sdpa"], atol=2e-4, rtol=1e-4), float((outs["eager"] - outs["sdpa"]).abs().max())

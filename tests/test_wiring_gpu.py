@@ -45,3 +45,65 @@ def test_slab_cache_in_place_compaction_matches_dynamic_cache(monkeypatch):
         assert torch.equal(pkv_s.layers[i].keys, pkv_d.layers[i].keys) and torch.equal(pkv_s.layers[i].values, pkv_d.layers[i].values)
     for x, y in zip(dyn, slab):
         assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------ whole patched model vs the oracle
+def _capture_and_compare(family):
+    """Two decoder layers of the family's 7-8B geometry (head_dim 128, 32 query / 8 KV heads) on the GPU with the PRODUCT
+    cluster, a 4096-token prompt (BASELINE.json configs[0]'s shape: budget 512, TSP length 2048; layer 0 is the TSP layer so
+    that layer 1 runs on the 2048 survivors).  Every layer's update_kv inputs are captured and replayed through the ORACLE
+    cluster on the CPU: the rows that went into the cache, tsp_idx and the rewired position ids must be identical."""
+    from baselines.monkeypatch import replace_llama, replace_mistral, set_model
+    from benchmark import prefill
+    from oracle.fastkv_oracle import OracleFastKVCluster
+    name = {"llama": "llama3-8b", "mistral": "mistral-7b"}[family]
+    a = prefill.parse_args(["--model_path", name, "--num_layers", "2", "--device", "cuda", "--save_txt", "", "--method", "fastkv",
+                            "--max_capacity_prompts", "512", "--tsp_len", "2048", "--tsp_idx", "0", "--pooling", "maxpool"])
+    a.save_txt = False
+    a.context_lengths = [4096]
+    (replace_llama if family == "llama" else replace_mistral)("fastkv")
+    torch.manual_seed(21)
+    model = prefill.build_model(a, "cuda")
+    assert type(model.model.layers[0].self_attn).__name__ == ("LlamaFastKVAttention" if family == "llama" else "MistralFastKVAttention")
+    set_model(model, a)
+    captured = []
+    for layer in model.model.layers:
+        cl = layer.self_attn.kv_cluster
+        orig = cl.update_kv
+
+        def spy(key_states, query_states, value_states, attention_mask, groups, layer_idx, _orig=orig, _cl=cl, **kw):
+            out = _orig(key_states, query_states, value_states, attention_mask, groups, layer_idx, **kw)
+            cfg = dict(window_size=_cl.window_size, max_capacity_prompt=_cl.max_capacity_prompt, kernel_size=_cl.kernel_size,
+                       pooling=_cl.pooling, tsp_layer=_cl.tsp_layer, tsp_length=_cl.tsp_length, tsp_rate=_cl.tsp_rate,
+                       retain_rate=_cl.retain_rate, eviction_mode=_cl.eviction_mode)
+            captured.append((cfg, groups, layer_idx, tuple(t.detach().cpu() for t in (key_states, query_states, value_states)),
+                             tuple(None if t is None else t.detach().cpu() for t in out)))
+            return out
+
+        cl.update_kv = spy
+    ids = torch.randint(0, 1000, (1, 4096), generator=torch.Generator().manual_seed(23)).cuda()
+    with torch.no_grad():
+        out = model(ids, attention_mask=torch.ones_like(ids))
+    torch.cuda.synchronize()
+    assert len(captured) == 2 and [c[3][0].shape[2] for c in captured] == [4096, 2048]
+    for cfg, groups, layer_idx, (k, q, v), (kc, vc, tsp) in captured:
+        oc = OracleFastKVCluster(cfg["window_size"], cfg["max_capacity_prompt"], cfg["kernel_size"], cfg["pooling"], cfg["tsp_layer"],
+                                 cfg["tsp_length"], cfg["tsp_rate"], cfg["retain_rate"], cfg["eviction_mode"])
+        wk, wv, wt = oc.update_kv(k, q, v, None, groups, layer_idx)
+        assert torch.equal(kc, wk) and torch.equal(vc, wv), layer_idx
+        assert (tsp is None and wt is None) or torch.equal(tsp, wt), layer_idx
+        cache = out.past_key_values.layers[layer_idx]
+        assert torch.equal(cache.keys.cpu(), wk) and torch.equal(cache.values.cpu(), wv), layer_idx      # what attention will decode over
+    tsp0 = captured[0][4][2]
+    assert tsp0 is not None and tsp0.shape == (1, 2048) and captured[1][4][2] is None
+    assert torch.equal(model.model.layers[0].new_position_ids.cpu(), tsp0)                              # positions = arange -> gather == idx
+    assert out.logits.shape[:2] == (1, 1) and bool(torch.isfinite(out.logits).all())
+
+
+def test_llama_wiring_on_gpu_matches_oracle_cluster():
+    _capture_and_compare("llama")
+
+
+def test_mistral_wiring_on_gpu_matches_oracle_cluster():
+    """BASELINE.json configs[3]'s wiring (/root/reference/baselines/fastkv/mistral_model.py:100-107, 217-224)."""
+    _capture_and_compare("mistral")
