@@ -13,7 +13,7 @@ constexpr size_t CTRL_BYTES = 8192;  // control block at the start of every oper
                                      // u64 magic, u32 epoch (the rest is reserved)
                                      // u64 magic, u32 epoch, u32 abort word (token of a launch that gave up waiting)
 constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
-constexpr int FUSED_MAX_WGS = 512;   // workgroups of one fused score launch (2 per CU): sizes its hand-off records
+constexpr int FUSED_MAX_WGS = 1024;  // (unit, span) pairs of one fused score launch -- 512 workgroups (2 per CU) x up to 2 streams: sizes its hand-off records
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -67,7 +67,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
     L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum / halo granules
     // fused score with more than 4 query heads per KV head: per-position head-sum granules between virtual heads
-    L.off_fchain = o; o += (p.H / p.Hkv > 4) ? align_up((size_t)FUSED_MAX_WGS * 1024 * 8, 256) : 0;
+    L.off_fchain = o; o += (p.H / p.Hkv > 4) ? align_up((size_t)512 * 1024 * 8, 256) : 0;          // [unit span][positions]: 512 Ki granules at most
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {

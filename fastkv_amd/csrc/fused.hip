@@ -27,12 +27,13 @@
 #include "mfma_tile.h"
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace fk {
 
 #ifdef FK_STAMP
-__device__ unsigned long long g_fstamps[4096 * 8];
-#define FKF_STAMP(slot) do { if (lane == 0) g_fstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 8 + (slot)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_fstamps[4096 * 16];
+#define FKF_STAMP(slot) do { if (lane == 0) g_fstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define FKF_STAMP(slot) do { } while (0)
 #endif
@@ -60,7 +61,17 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
     return true;
 }
 
-template <int D, int PER, int NB>
+// NS = streams of a workgroup: 1 (the product), or 2 (an experiment kept for reproduction, FASTKV_FUSED_STREAMS=2, head dim
+// 128 only) -- the workgroup then works for TWO units (batch row, kv head, virtual head) at once, PER / NS tiles per wave
+// each, and runs their phases interleaved: while the hand-off of one stream is in flight the workgroup computes for the
+// other.  Schedule for NS = 2:  A0 pub | A1 pub | max0 B0 pub | max1 B1 pub | sum0 C0 pub | sum1 C1 pub | halo0 D0 | halo1 D1.
+// Measured on MI355X (per-wave stamps, tools/stamp_fused.py; profiles/r02_fused_streams.md), 32k shape / 2k shape:
+//   NS = 1  end 45.1 / 15.8 us;  NS = 2  end 56.3 / 29.0 us.  Bit-exact either way, and slower: the hand-offs are not what
+// the waves wait for -- a hand-off completes 0.3-1.2 us behind the LAST arriving wave; what looks like waiting in a median
+// wave is the other wave of its SIMD using the issue slots (vector-ALU work and fp32 MFMAs of a SIMD add up, in one wave or
+// across two: tools/probes/probe_overlap.hip).  The kernel is issue bound (per SIMD: A 27, B 9, C 5, D 4 us), and two streams
+// pay every hand-off's record sweep twice, with twice the producers per head.
+template <int D, int PER, int NB, int NS>
 __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -73,46 +84,66 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
-    // rows of one column instead of two columns of one row).  NW = packed words per tile.
-    constexpr int W = 8, G = 4, NPH = D / DH, TK = 32 * NB, NW = 8 * NB;
-    __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
-    __shared__ float As[(D / 2) * 64];
-    __shared__ float s_f[FUSED_PARTS][32];
-    __shared__ uint64_t s_u[FUSED_PARTS][32];
-    __shared__ uint32_t s_bad[FUSED_PARTS][32];
-    __shared__ float s_row[32];
+    // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
+    static_assert(PER % NS == 0, "tiles split evenly over the streams");
+    constexpr int W = 8, G = 4, NPH = D / DH, TK = 32 * NB, NW = 8 * NB, PS = PER / NS;
+    constexpr int SLAB_BYTES = 4 * 64 * ROWB, AS_FLOATS = (D / 2) * 64;
+    // one block of LDS, carved twice: phase A = the waves' K slabs + the fp32 query operand of every stream; phases C/D (all
+    // of phase A is over by then, on every stream) = the window-row-sum tiles and the key histograms of the streams
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SLAB_BYTES + NS * AS_FLOATS * 4];
+    __shared__ float s_pf[NS][4][32];                          // per-wave row maxima of a stream (phase A -> publish)
+    __shared__ uint64_t s_pu[NS][4][32];                       // per-wave fixed-point row sums (phase B -> publish)
+    __shared__ uint32_t s_pb[NS][4][32];
+    __shared__ float s_rf[FUSED_PARTS][32];                    // record reductions (one hand-off at a time)
+    __shared__ uint64_t s_ru[FUSED_PARTS][32];
+    __shared__ uint32_t s_rb[FUSED_PARTS][32];
+    __shared__ float s_gm[NS][32], s_ri[NS][32];               // row maxima / reciprocal row sums of the streams' heads
     __shared__ uint32_t s_abort;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
-    const int hv = blockIdx.x % (Hkv * VH), g = hv / VH, vh = hv - g * VH;
-    const int blk = blockIdx.x / (Hkv * VH), nblk = gridDim.x / (Hkv * VH), b = blockIdx.y;
-    const int bg = b * Hkv + g, BG = gridDim.y * Hkv;
-    const int bgv = bg * VH + vh;                            // hand-off records are per virtual head
+    // Unit = (kv head, virtual head) of this batch row; stream s of the workgroup works for unit hvp + s * UH / NS.
+    const int UH = Hkv * VH, UP = UH / NS;
+    const int hvp = blockIdx.x % UP, blk = blockIdx.x / UP, nblk = gridDim.x / UP, b = blockIdx.y;
+    const int BG = gridDim.y * Hkv;
+    int g_s[NS], vh_s[NS], bg_s[NS], bgv_s[NS];
+    const uint16_t *kb_s[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int hv = hvp + s * UP;
+        g_s[s] = hv / VH;
+        vh_s[s] = hv - g_s[s] * VH;
+        bg_s[s] = b * Hkv + g_s[s];
+        bgv_s[s] = bg_s[s] * VH + vh_s[s];                    // hand-off records are per virtual head
+        kb_s[s] = k + b * ks_b + (int64_t)g_s[s] * ks_h;
+    }
     const int n = S - W;
     const int nwt = (S + TK - 1) / TK;
     const int wave_id = blk * 4 + w;
-    const uint16_t *kb = k + b * ks_b + (int64_t)g * ks_h;
-    unsigned char *my = slab[w];
+    unsigned char *my = smem + w * (64 * ROWB);
+    float *As = reinterpret_cast<float *>(smem + SLAB_BYTES);  // [NS][AS_FLOATS]
     const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
 
     // control block (fastkv_workspace_init): a missing initialisation must not turn into a silent wrong answer.  The token
-    // of this launch is the epoch left by the previous one + 1 (score_finalize bumps it): never a launch argument, which a
-    // graph replay would freeze; the granules in memory still carry earlier tokens (or whatever the allocation held).
+    // of this launch is the epoch left by the previous one + 1 (the compaction kernel bumps it): never a launch argument,
+    // which a graph replay would freeze; the granules in memory still carry earlier tokens (or whatever the allocation held).
     if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
     const uint32_t token = handoff_token(ctrl[2]);
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (threadIdx.x == 0) s_abort = 0;
     FKF_STAMP(0);
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
-    // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record is published, so
-    // passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of the selection
-    // are touched by later kernels only.
-    uint32_t *hist_row = zero_area + (size_t)bg * HIST12;
-    if (vh == VH - 1)                                        // the group that fills the histogram in phase D
-        for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
-            __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
+    // is published, so passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of
+    // the selection are touched by later kernels only.
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (vh_s[s] == VH - 1) {                               // the group that fills the histogram in phase D
+            uint32_t *hist_row = zero_area + (size_t)bg_s[s] * HIST12;
+            for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
+                __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     {
         const int first = BG * HIST12, rest = zero_words - first;
         const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -121,134 +152,152 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         for (int i = lo + (int)threadIdx.x; i < hi2; i += 256) zero_area[first + i] = 0;
     }
 
-    // ---------------------------------------------------------------- A operand (see score_logits_mfma_kernel)
+    // tile t of the wave (0 .. PER-1): stream t / PS, tile wt(t) of that stream's row of tiles (contiguous keys per workgroup)
+    auto tile_wt = [&](int t) { return wave_id * PS + (t % PS); };
+    auto tile_valid = [&](int t) { return t < PER && tile_wt(t) < nwt; };
+    auto tile_key0 = [&](int t) { const int wt = tile_wt(t); return (wt < nwt ? wt : 0) * TK; };
+
+    // ---------------------------------------------------------------- A operands (see score_logits_mfma_kernel)
     constexpr int QV = 32 * (D / 8) / 256;
-    uint4 qv[QV];
+    uint4 qv[NS][QV];
 #pragma unroll
-    for (int u = 0; u < QV; ++u) {
-        const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
-        const int i = rowl / W, r = rowl - i * W;
-        qv[u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)((g * VH + vh) * G + i) * qs_h + (int64_t)(n + r) * qs_s + ch * 8);
-    }
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int u = 0; u < QV; ++u) {
+            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const int i = rowl / W, r = rowl - i * W;
+            qv[s][u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)((g_s[s] * VH + vh_s[s]) * G + i) * qs_h +
+                                                       (int64_t)(n + r) * qs_s + ch * 8);
+        }
     KStage sA, sB;
-    const int wt0 = wave_id * PER;                       // this wave's tiles: wt0 .. wt0 + PER - 1 (contiguous keys per workgroup)
-    k_fetch<NB>(sA, kb, ks_s, (wt0 < nwt ? wt0 : 0) * TK, S, 0, lane);
+    k_fetch<NB>(sA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < QV; ++u) {
-        const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
-        const uint32_t wds[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            As[(ch * 4 + e) * 64 + rowl] = h2f((uint16_t)(wds[e] & 0xffffu));
-            As[(ch * 4 + e) * 64 + 32 + rowl] = h2f((uint16_t)(wds[e] >> 16));
+        for (int u = 0; u < QV; ++u) {
+            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const uint32_t wds[4] = {qv[s][u].x, qv[s][u].y, qv[s][u].z, qv[s][u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                As[s * AS_FLOATS + (ch * 4 + e) * 64 + rowl] = h2f((uint16_t)(wds[e] & 0xffffu));
+                As[s * AS_FLOATS + (ch * 4 + e) * 64 + 32 + rowl] = h2f((uint16_t)(wds[e] >> 16));
+            }
         }
-    }
     __syncthreads();
-    {
-        const int first = (wt0 < nwt ? wt0 : 0) * TK;
-        if (NPH >= 2) k_fetch<NB>(sB, kb, ks_s, first, S, 1, lane);
-        else if (PER > 1 && wt0 + 1 < nwt) k_fetch<NB>(sB, kb, ks_s, (wt0 + 1) * TK, S, 0, lane);
-    }
+    if (NPH >= 2) k_fetch<NB>(sB, kb_s[0], ks_s, tile_key0(0), S, 1, lane);
+    else if (tile_valid(1)) k_fetch<NB>(sB, kb_s[(1 / PS) % NS], ks_s, tile_key0(1), S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---------------------------------------------------------------- phase A: logits of this wave's tiles, row maxima
     // lg[t][i]: a packed pair of scaled + masked fp16 logits.  NB == 2: query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns
     // key0 + n31 (low half) and key0 + 32 + n31 (high half).  NB == 1: rows m(i) (low) and m(i + 8) (high) at column
-    // key0 + n31.  mx[r] = running maximum of row m(r) over this lane's columns
+    // key0 + n31.
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][NW];
-    float mx[16];
-    uint32_t mx16[NW];                                           // the same for full tiles, as packed fp16 pairs
+    float ev[PER][2][NW];
+
+    // ================================================================ phase A of stream s: logits of its tiles, row maxima,
+    // publication of the workgroup's 32 partial maxima as {token, value} granules
+    auto phaseA = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        float mx[16];                                            // mx[r] = running maximum of row m(r) over this lane's columns
+        uint32_t mx16[NW];                                       // the same for full tiles, as packed fp16 pairs
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx[i] = -INFINITY;
+        for (int i = 0; i < 16; ++i) mx[i] = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) mx16[i] = 0xFC00FC00u;
+        for (int i = 0; i < NW; ++i) mx16[i] = 0xFC00FC00u;
 #pragma unroll
-    for (int t = 0; t < PER; ++t) {
+        for (int lt = 0; lt < PS; ++lt) {
+            constexpr int t0 = s * PS;
+            const int t = t0 + lt;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) lg[t][i] = 0;
-        const int wt = wt0 + t;
-        if (wt < nwt) {
-            const int key0 = wt * TK;
-            f32x16 acc0, acc1;
+            for (int i = 0; i < NW; ++i) lg[t][i] = 0;
+            const int wt = tile_wt(t);
+            if (wt < nwt) {
+                const int key0 = wt * TK;
+                f32x16 acc0, acc1;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+                for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 #pragma unroll
-            for (int ph = 0; ph < NPH; ++ph) {
-                const bool useA = NPH >= 2 ? ((ph & 1) == 0) : ((t & 1) == 0);
-                int nkey, nph;
-                if (NPH == 1) { nkey = (wt + 2) * TK; nph = 0; }
-                else if (ph + 2 < NPH) { nkey = key0; nph = ph + 2; }
-                else { nkey = (wt + 1) * TK; nph = ph + 2 - NPH; }
-                const bool more = nkey < nwt * TK && (NPH == 1 ? t + 2 < PER : (ph + 2 < NPH || t + 1 < PER));
-                if (useA) { k_commit<NB>(sA, lane, my); if (more) k_fetch<NB>(sA, kb, ks_s, nkey, S, nph, lane); }
-                else { k_commit<NB>(sB, lane, my); if (more) k_fetch<NB>(sB, kb, ks_s, nkey, S, nph, lane); }
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_phase_mx<NB>(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            redo_tile_if_nan<NPH, NB>(acc0, acc1, kb, ks_s, key0, S, lane, my, As + lane, n31, sh);
-            const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
-            if (key0 + TK <= n) {
-                // tile entirely among the candidates: no window mask, every column counts; the running maxima stay packed
-                // fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf) -- vector instructions of this phase are
-                // not hidden behind the MFMAs of the SIMD's other wave, every one of them counts
-#pragma unroll
-                for (int i = 0; i < NW; ++i) {
-                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[(i + 8) & 15]))}, sqrtD, rsqrtD);   // utils.py:94
-                    const uint32_t wd = (uint32_t)f2h(sc.x) | ((uint32_t)f2h(sc.y) << 16);
-                    mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
-                                                                                      __builtin_bit_cast(h16x2, wd)));
-                    lg[t][i] = wd;
+                for (int ph = 0; ph < NPH; ++ph) {
+                    const bool useA = NPH >= 2 ? ((ph & 1) == 0) : ((t & 1) == 0);
+                    // what to request next into the stage that is committed now: two phases ahead (the next phase pair of
+                    // this tile, or of the wave's next tile -- possibly the first tile of the next stream), or two tiles
+                    // ahead when a tile is a single phase
+                    int nt, nph;
+                    if (NPH == 1) { nt = t + 2; nph = 0; }
+                    else if (ph + 2 < NPH) { nt = t; nph = ph + 2; }
+                    else { nt = t + 1; nph = ph + 2 - NPH; }
+                    const bool more = nt < PER && tile_wt(nt) < nwt;
+                    const uint16_t *nkb = kb_s[(nt / PS) % NS];
+                    const int nkey = tile_key0(nt);
+                    if (useA) { k_commit<NB>(sA, lane, my); if (more) k_fetch<NB>(sA, nkb, ks_s, nkey, S, nph, lane); }
+                    else { k_commit<NB>(sB, lane, my); if (more) k_fetch<NB>(sB, nkb, ks_s, nkey, S, nph, lane); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_phase_mx<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {
+                redo_tile_if_nan<NPH, NB>(acc0, acc1, kb_s[s], ks_s, key0, S, lane, my, As + s * AS_FLOATS + lane, n31, sh);
+                const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
+                if (key0 + TK <= n) {
+                    // tile entirely among the candidates: no window mask, every column counts; the running maxima stay
+                    // packed fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf)
 #pragma unroll
-                for (int i = 0; i < NW; ++i) {
-                    const int rw = (i & 3) + 4 * hi;                                     // window row of both rows of the word: m % W
-                    const int rB = NB == 2 ? i : (i + 8) & 15;
-                    // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both halves of the pair in one packed sequence)
-                    const f32x2 sc = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[rB]))}, sqrtD, rsqrtD);
-                    uint16_t s0 = f2h(sc.x), s1 = f2h(sc.y);
-                    if (jA >= n && (jA - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));       // utils.py:95-101
-                    if (jB >= n && (jB - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
-                    if (jA < S) mx[i] = fmaxf(mx[i], h2f(s0));
-                    if (jB < S) mx[rB] = fmaxf(mx[rB], h2f(s1));
-                    lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
+                    for (int i = 0; i < NW; ++i) {
+                        const f32x2 scv = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[(i + 8) & 15]))}, sqrtD, rsqrtD);   // utils.py:94
+                        const uint32_t wd = (uint32_t)f2h(scv.x) | ((uint32_t)f2h(scv.y) << 16);
+                        mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
+                                                                                          __builtin_bit_cast(h16x2, wd)));
+                        lg[t][i] = wd;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        const int rw = (i & 3) + 4 * hi;                                     // window row of both rows of the word: m % W
+                        const int rB = NB == 2 ? i : (i + 8) & 15;
+                        // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both halves of the pair in one packed sequence)
+                        const f32x2 scv = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[rB]))}, sqrtD, rsqrtD);
+                        uint16_t s0 = f2h(scv.x), s1 = f2h(scv.y);
+                        if (jA >= n && (jA - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));       // utils.py:95-101
+                        if (jB >= n && (jB - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
+                        if (jA < S) mx[i] = fmaxf(mx[i], h2f(s0));
+                        if (jB < S) mx[rB] = fmaxf(mx[rB], h2f(s1));
+                        lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
+                    }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int rB = NB == 2 ? i : (i + 8) & 15;
-        mx[i] = fmaxf(mx[i], h2f((uint16_t)(mx16[i] & 0xffffu)));
-        mx[rB] = fmaxf(mx[rB], h2f((uint16_t)(mx16[i] >> 16)));
-    }
-    FKF_STAMP(1);
-    // row maxima: across the 32 lanes of a half wave, then across the 4 waves, then published
-    {
-        const float r = halfwave_reduce16(mx, lane, [](float a, float b) { return fmaxf(a, b); });
-        const int i = halfwave_red_index(lane);
-        if ((lane & 1) == 0) s_f[w][(i & 3) + 8 * (i >> 2) + 4 * hi] = r;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's histogram zeros have reached memory
-    __syncthreads();
-    uint64_t *pm = pmax + (size_t)bgv * nblk * 32;                   // [nblk][32] granules: row maxima
-    uint64_t *psu = psum + (size_t)bgv * nblk * 64;                  // [nblk][32][2] granules: row sums, low / high word
-    if (w == 0) {
-        if (lane < 32)
-            __hip_atomic_store(pm + blk * 32 + lane,
-                               granule(token, f32_bits(fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane])))),
+        for (int i = 0; i < NW; ++i) {
+            const int rB = NB == 2 ? i : (i + 8) & 15;
+            mx[i] = fmaxf(mx[i], h2f((uint16_t)(mx16[i] & 0xffffu)));
+            mx[rB] = fmaxf(mx[rB], h2f((uint16_t)(mx16[i] >> 16)));
+        }
+        // row maxima: across the 32 lanes of a half wave, then across the 4 waves, then published
+        {
+            const float r = halfwave_reduce16(mx, lane, [](float a, float b2) { return fmaxf(a, b2); });
+            const int i = halfwave_red_index(lane);
+            if ((lane & 1) == 0) s_pf[s][w][(i & 3) + 8 * (i >> 2) + 4 * hi] = r;
+        }
+        if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's histogram zeros have reached memory
+        __syncthreads();
+        if (w == 0 && lane < 32)
+            __hip_atomic_store(pmax + ((size_t)bgv_s[s] * nblk + blk) * 32 + lane,
+                               granule(token, f32_bits(fmaxf(fmaxf(s_pf[s][0][lane], s_pf[s][1][lane]), fmaxf(s_pf[s][2][lane], s_pf[s][3][lane])))),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!wait_first_granules(pm, 32, nblk, token, lane, sp)) s_abort = 1;
-    }
-    __syncthreads();
-    if (s_abort) return;
-    {
+    };
+
+    // ================================================================ hand-off 1 of stream s: row maxima of the head -> s_gm[s]
+    // (returns false when the launch is abandoned: every thread of the workgroup leaves)
+    auto read_max = [&](auto sc) -> bool {
+        constexpr int s = decltype(sc)::value;
+        const uint64_t *pm = pmax + (size_t)bgv_s[s] * nblk * 32;     // [nblk][32] granules: row maxima
+        if (w == 0 && !wait_first_granules(pm, 32, nblk, token, lane, sp)) s_abort = 1;
+        __syncthreads();
+        if (s_abort) return false;
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
             float v = -INFINITY;
@@ -266,106 +315,114 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     v = fmaxf(v, bits_f32((uint32_t)rec[u]));
                 }
             }
-            s_f[part][row] = v;
+            s_rf[part][row] = v;
             if (__syncthreads_and(ok)) break;
             if (threadIdx.x == 0 && spin_failed(sp)) s_abort = 1;      // a record behind a current granule 0 is still old: rare
             __syncthreads();
-            if (s_abort) return;
+            if (s_abort) return false;
         }
-    }
-    if (threadIdx.x < 32) {
-        float v = s_f[0][threadIdx.x];
+        if (threadIdx.x < 32) {
+            float v = s_rf[0][threadIdx.x];
 #pragma unroll
-        for (int u = 1; u < FUSED_PARTS; ++u) v = fmaxf(v, s_f[u][threadIdx.x]);
-        s_row[threadIdx.x] = v;
-    }
-    __syncthreads();
+            for (int u = 1; u < FUSED_PARTS; ++u) v = fmaxf(v, s_rf[u][threadIdx.x]);
+            s_gm[s][threadIdx.x] = v;
+        }
+        __syncthreads();
+        return true;
+    };
 
-    FKF_STAMP(2);
-    // ---------------------------------------------------------------- phase B: e = exp(x - max), fixed-point row sums
-    float gm[16];
+    // ================================================================ phase B of stream s: e = exp(x - max), fixed-point row
+    // sums, publication of the workgroup's 32 partial sums (two granules each)
+    auto phaseB = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        float gm[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gm[i] = s_row[(i & 3) + 8 * (i >> 2) + 4 * hi];
-    float ev[PER][2][NW];
-    uint32_t ahi[16], alo[16], nanbits = 0;
+        for (int i = 0; i < 16; ++i) gm[i] = s_gm[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
+        uint32_t ahi[16], alo[16], nanbits = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; }
+        for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; }
 #pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int key0 = (wt0 + t) * TK;                        // >= S when the wave has no tile t: nothing is counted
-        if (key0 + TK <= S) {
-            // full tile: every column counts and x <= max, so no column masks and no clamp; a NaN poisons the row anyway,
-            // whatever its conversion adds to the sums
+        for (int lt = 0; lt < PS; ++lt) {
+            constexpr int t0 = s * PS;
+            const int t = t0 + lt;
+            const int key0 = tile_wt(t) * TK;                        // >= S when the wave has no tile t: nothing is counted
+            if (key0 + TK <= S) {
+                // full tile: every column counts and x <= max, so no column masks and no clamp; a NaN poisons the row anyway,
+                // whatever its conversion adds to the sums
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const int rB = NB == 2 ? i : (i + 8) & 15;
-                const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-                const f32x2 e = det_expf2<true>(x - (f32x2){gm[i], gm[rB]});
-                ev[t][0][i] = e.x;
-                ev[t][1][i] = e.y;
-                uint32_t h0, l0, h1, l1;
-                exp_to_fix2(e, h0, l0, h1, l1);
-                if (NB == 2) {
-                    if (__builtin_isunordered(e.x, e.y)) nanbits |= 1u << i;
-                    ahi[i] += h0 + h1;
-                    alo[i] += l0 + l1;
-                } else {
-                    if (e.x != e.x) nanbits |= 1u << i;
-                    if (e.y != e.y) nanbits |= 1u << rB;
-                    ahi[i] += h0; alo[i] += l0;
-                    ahi[rB] += h1; alo[rB] += l1;
+                for (int i = 0; i < NW; ++i) {
+                    const int rB = NB == 2 ? i : (i + 8) & 15;
+                    const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
+                    const f32x2 e = det_expf2<true>(x - (f32x2){gm[i], gm[rB]});
+                    ev[t][0][i] = e.x;
+                    ev[t][1][i] = e.y;
+                    uint32_t h0, l0, h1, l1;
+                    exp_to_fix2(e, h0, l0, h1, l1);
+                    if (NB == 2) {
+                        if (__builtin_isunordered(e.x, e.y)) nanbits |= 1u << i;
+                        ahi[i] += h0 + h1;
+                        alo[i] += l0 + l1;
+                    } else {
+                        if (e.x != e.x) nanbits |= 1u << i;
+                        if (e.y != e.y) nanbits |= 1u << rB;
+                        ahi[i] += h0; alo[i] += l0;
+                        ahi[rB] += h1; alo[rB] += l1;
+                    }
+                }
+            } else {
+                const bool inA = key0 + n31 < S, inB = NB == 2 ? key0 + 32 + n31 < S : inA;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const int rB = NB == 2 ? i : (i + 8) & 15;
+                    const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
+                    const f32x2 e = det_expf2(x - (f32x2){gm[i], gm[rB]});
+                    ev[t][0][i] = e.x;
+                    ev[t][1][i] = e.y;
+                    uint32_t h0, l0, h1, l1;
+                    exp_to_fix2(e, h0, l0, h1, l1);
+                    const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
+                    if (inA && nan0) nanbits |= 1u << i;
+                    if (inB && nan1) nanbits |= 1u << rB;
+                    ahi[i] += inA && !nan0 ? h0 : 0u;
+                    alo[i] += inA && !nan0 ? l0 : 0u;
+                    ahi[rB] += inB && !nan1 ? h1 : 0u;
+                    alo[rB] += inB && !nan1 ? l1 : 0u;
                 }
             }
-        } else {
-            const bool inA = key0 + n31 < S, inB = NB == 2 ? key0 + 32 + n31 < S : inA;
+        }
+        // per lane at most 2*PS <= 8 elements per row (hi <= 2^16, lo <= 2^24 each): the 32-bit lane sums are exact; they
+        // are combined to the 2^-40 fixed-point value before the half-wave reduction
+        {
+            uint64_t tot[16];
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const int rB = NB == 2 ? i : (i + 8) & 15;
-                const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-                const f32x2 e = det_expf2(x - (f32x2){gm[i], gm[rB]});
-                ev[t][0][i] = e.x;
-                ev[t][1][i] = e.y;
-                uint32_t h0, l0, h1, l1;
-                exp_to_fix2(e, h0, l0, h1, l1);
-                const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
-                if (inA && nan0) nanbits |= 1u << i;
-                if (inB && nan1) nanbits |= 1u << rB;
-                ahi[i] += inA && !nan0 ? h0 : 0u;
-                alo[i] += inA && !nan0 ? l0 : 0u;
-                ahi[rB] += inB && !nan1 ? h1 : 0u;
-                alo[rB] += inB && !nan1 ? l1 : 0u;
+            for (int i = 0; i < 16; ++i) tot[i] = ((uint64_t)ahi[i] << 24) + alo[i];
+            const uint64_t r = halfwave_reduce16(tot, lane, [](uint64_t a, uint64_t b2) { return a + b2; });
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) nanbits |= (uint32_t)__shfl_xor((int)nanbits, o, 64);
+            const int i = halfwave_red_index(lane);
+            if ((lane & 1) == 0) {
+                const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                s_pu[s][w][m] = r;
+                s_pb[s][w][m] = (nanbits >> i) & 1u;
             }
         }
-    }
-    FKF_STAMP(3);
-    // per lane at most 2*PER <= 8 elements per row (hi <= 2^16, lo <= 2^24 each): the 32-bit lane sums are exact; they
-    // are combined to the 2^-40 fixed-point value before the half-wave reduction
-    {
-        uint64_t tot[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tot[i] = ((uint64_t)ahi[i] << 24) + alo[i];
-        const uint64_t r = halfwave_reduce16(tot, lane, [](uint64_t a, uint64_t b) { return a + b; });
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) nanbits |= (uint32_t)__shfl_xor((int)nanbits, o, 64);
-        const int i = halfwave_red_index(lane);
-        if ((lane & 1) == 0) {
-            const int m = (i & 3) + 8 * (i >> 2) + 4 * hi;
-            s_u[w][m] = r;
-            s_bad[w][m] = (nanbits >> i) & 1u;
+        __syncthreads();
+        if (w == 0) {
+            const int row = lane >> 1;
+            const uint32_t bad = s_pb[s][0][row] | s_pb[s][1][row] | s_pb[s][2][row] | s_pb[s][3][row];
+            const uint64_t tot = bad ? FK_SUM_POISON : s_pu[s][0][row] + s_pu[s][1][row] + s_pu[s][2][row] + s_pu[s][3][row];
+            __hip_atomic_store(psum + ((size_t)bgv_s[s] * nblk + blk) * 64 + lane, granule(token, (uint32_t)((lane & 1) ? tot >> 32 : tot)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }
-    __syncthreads();
-    if (w == 0) {
-        const int row = lane >> 1;
-        const uint32_t bad = s_bad[0][row] | s_bad[1][row] | s_bad[2][row] | s_bad[3][row];
-        const uint64_t tot = bad ? FK_SUM_POISON : s_u[0][row] + s_u[1][row] + s_u[2][row] + s_u[3][row];
-        __hip_atomic_store(psu + blk * 64 + lane, granule(token, (uint32_t)((lane & 1) ? tot >> 32 : tot)), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        if (!wait_first_granules(psu, 64, nblk, token, lane, sp)) s_abort = 1;
-    }
-    __syncthreads();
-    if (s_abort) return;
-    {
+    };
+
+    // ================================================================ hand-off 2 of stream s: row sums of the head -> s_ri[s]
+    auto read_sum = [&](auto sc) -> bool {
+        constexpr int s = decltype(sc)::value;
+        const uint64_t *psu = psum + (size_t)bgv_s[s] * nblk * 64;    // [nblk][32][2] granules: row sums, low / high word
+        if (w == 0 && !wait_first_granules(psu, 64, nblk, token, lane, sp)) s_abort = 1;
+        __syncthreads();
+        if (s_abort) return false;
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
             uint64_t s2 = 0;
@@ -387,92 +444,103 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     if (base + part + u * FUSED_PARTS < nblk) { if (v == FK_SUM_POISON) bad = 1; else s2 += v; }
                 }
             }
-            s_u[part][row] = s2;
-            s_bad[part][row] = bad;
+            s_ru[part][row] = s2;
+            s_rb[part][row] = bad;
             if (__syncthreads_and(ok)) break;
             if (threadIdx.x == 0 && spin_failed(sp)) s_abort = 1;
             __syncthreads();
-            if (s_abort) return;
+            if (s_abort) return false;
         }
-    }
-    if (threadIdx.x < 32) {
-        uint64_t s = 0;
-        uint32_t bad = 0;
+        if (threadIdx.x < 32) {
+            uint64_t sm = 0;
+            uint32_t bad = 0;
 #pragma unroll
-        for (int u = 0; u < FUSED_PARTS; ++u) { s += s_u[u][threadIdx.x]; bad |= s_bad[u][threadIdx.x]; }
-        s_row[threadIdx.x] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(s);          // utils.py:103
-    }
-    __syncthreads();
+            for (int u = 0; u < FUSED_PARTS; ++u) { sm += s_ru[u][threadIdx.x]; bad |= s_rb[u][threadIdx.x]; }
+            s_ri[s][threadIdx.x] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(sm);          // utils.py:103
+        }
+        __syncthreads();
+        return true;
+    };
 
-    FKF_STAMP(4);
-    // ---------------------------------------------------------------- phase C: probabilities, sum over the window rows
+    // ================================================================ phases C / D
     // Head i4 = i >> 2 of the group owns rows 8*i4 .. 8*i4+7; the lower half wave holds window rows 0-3 of every head,
     // the upper half rows 4-7.  The reference adds the 8 fp16 probabilities in ascending row order (fp32 accumulator,
     // utils.py:104): the lower half's partial sum crosses to the upper half, which finishes it and owns the result.
-    // The workgroup owns the contiguous positions [lo, lo + TWG): the window-row sums hs go to an LDS tile (the K slabs
-    // are free now), column pad + local position; candidates past n hold the pooling pad value (utils.py:106,108).
-    constexpr int TWG = 4 * PER * TK, PADMAX = 31, TW = TWG + 2 * PADMAX;
-    static_assert(G * TW * sizeof(float) + HIST12 * sizeof(uint32_t) <= sizeof(slab), "phase C/D do not fit the K slabs");
-    float(*tile)[TW] = reinterpret_cast<float(*)[TW]>(&slab[0][0]);
-    uint32_t *s_hist = reinterpret_cast<uint32_t *>(&slab[0][0] + G * TW * sizeof(float));
+    // The workgroup owns the contiguous positions [lo, lo + TWG) of each stream's head: the window-row sums hs go to the
+    // stream's LDS tile, column pad + local position; candidates past n hold the pooling pad value (utils.py:106,108).
+    constexpr int TWG = 4 * PS * TK, PADMAX = 31, TW = TWG + 2 * PADMAX;
+    static_assert(NS * (G * TW * sizeof(float) + HIST12 * sizeof(uint32_t)) <= sizeof(smem), "phases C/D do not fit the phase-A LDS");
     const int pad = ksize / 2, lo = blk * TWG;
     const bool avg = pooling == FASTKV_POOL_AVG;
     const float padv = avg ? 0.0f : -INFINITY;
     const bool want_hist = all_idx == nullptr;
-    float ri[16];
+    auto tile_of = [&](int s) { return reinterpret_cast<float(*)[TW]>(smem + (size_t)s * G * TW * sizeof(float)); };
+    auto hist_of = [&](int s) { return reinterpret_cast<uint32_t *>(smem + NS * G * TW * sizeof(float) + (size_t)s * HIST12 * sizeof(uint32_t)); };
+
+    auto phaseC = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        float(*tile)[TW] = tile_of(s);
+        uint32_t *s_hist = hist_of(s);
+        float ri[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ri[i] = s_row[(i & 3) + 8 * (i >> 2) + 4 * hi];
-    if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
+        for (int i = 0; i < 16; ++i) ri[i] = s_ri[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
+        if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int lp = (w * PER + t) * TK + n31;                    // local position of the word's column (NB == 2: block 0; block 1 is 32 further)
+        for (int lt = 0; lt < PS; ++lt) {
+            constexpr int t0 = s * PS;
+            const int t = t0 + lt;
+            const int lp = (w * PS + lt) * TK + n31;                    // local position of the word's column (NB == 2: block 0; block 1 is 32 further)
 #pragma unroll
-        for (int i4 = 0; i4 < 2 * NB; ++i4) {
-            // one packed pair per step: every operation below is per component what the scalar chain does.  NB == 2: the two
-            // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
-            f32x2 p[4];
+            for (int i4 = 0; i4 < 2 * NB; ++i4) {
+                // one packed pair per step: every operation below is per component what the scalar chain does.  NB == 2: the two
+                // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
+                f32x2 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
-                const f32x2 pr = (f32x2){ev[t][0][wd], ev[t][1][wd]} * (f32x2){ri[wd], ri[rB]};
-                p[u] = (f32x2){h2f(f2h(pr.x)), h2f(f2h(pr.y))};
-            }
-            f32x2 a = splat2(0.0f);
-            a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
-            f32x2 c = {__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
-            c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
-            if (hi) {
-                if (NB == 2) {
-                    tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
-                    tile[i4][PADMAX + lp + 32] = lo + lp + 32 < n ? h2f(f2h(c.y)) : padv;
-                } else {
-                    tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
-                    tile[(i4 + 2) & 3][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.y)) : padv;
+                for (int u = 0; u < 4; ++u) {
+                    const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
+                    const f32x2 pr = (f32x2){ev[t][0][wd], ev[t][1][wd]} * (f32x2){ri[wd], ri[rB]};
+                    p[u] = (f32x2){h2f(f2h(pr.x)), h2f(f2h(pr.y))};
+                }
+                f32x2 a = splat2(0.0f);
+                a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
+                f32x2 c = {__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
+                c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
+                if (hi) {
+                    if (NB == 2) {
+                        tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
+                        tile[i4][PADMAX + lp + 32] = lo + lp + 32 < n ? h2f(f2h(c.y)) : padv;
+                    } else {
+                        tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
+                        tile[(i4 + 2) & 3][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.y)) : padv;
+                    }
                 }
             }
         }
-    }
-    FKF_STAMP(5);
-    __syncthreads();
-
-    // ---------------------------------------------------------------- halo: `pad` positions from each neighbour
-    // Pooling reaches pad positions into the neighbouring workgroups of the head.  Every workgroup publishes its first
-    // and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the
-    // flag) and reads the neighbours' granules until their tag is this launch's token.  No neighbour = pooling padding.
-    {
-        uint64_t *eg = edges + ((size_t)bgv * nblk + blk) * (2 * G * PADMAX);
-        const int t = threadIdx.x, per_side = G * pad;
-        if (t < 2 * per_side) {
-            const int side = t >= per_side, q2 = t - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
+        __syncthreads();
+        // halo: pooling reaches `pad` positions into the neighbouring workgroups of the head.  Every workgroup publishes its
+        // first and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the flag)
+        uint64_t *eg = edges + ((size_t)bgv_s[s] * nblk + blk) * (2 * G * PADMAX);
+        const int tt = threadIdx.x, per_side = G * pad;
+        if (tt < 2 * per_side) {
+            const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
             const float v = tile[i4][PADMAX + (side ? TWG - pad + e : e)];
             __hip_atomic_store(eg + (side * G + i4) * PADMAX + e, ((uint64_t)token << 32) | f32_bits(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            // side 0 of this thread = the LEFT halo of this workgroup = the right edge (side 1) of workgroup blk - 1, and
-            // vice versa
+        }
+    };
+
+    // the neighbours' halo granules of stream s into the pad columns of its tile; no neighbour = pooling padding
+    auto read_halo = [&](auto sc) -> bool {
+        constexpr int s = decltype(sc)::value;
+        float(*tile)[TW] = tile_of(s);
+        const int tt = threadIdx.x, per_side = G * pad;
+        if (tt < 2 * per_side) {
+            const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
+            // side 0 of this thread = the LEFT halo of this workgroup = the right edge (side 1) of workgroup blk - 1, and vice versa
             const int nb = side ? blk + 1 : blk - 1;
             float hv = padv;
             if (nb >= 0 && nb < nblk) {
-                const uint64_t *src = edges + ((size_t)bgv * nblk + nb) * (2 * G * PADMAX) + ((side ? 0 : 1) * G + i4) * PADMAX + e;
+                const uint64_t *src = edges + ((size_t)bgv_s[s] * nblk + nb) * (2 * G * PADMAX) + ((side ? 0 : 1) * G + i4) * PADMAX + e;
                 uint64_t x;
                 while (((x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
                     __builtin_amdgcn_s_sleep(4);
@@ -482,57 +550,87 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             }
             tile[i4][side ? PADMAX + TWG + e : PADMAX - pad + e] = hv;
         }
-    }
-    __syncthreads();
-    if (s_abort) return;
-    FKF_STAMP(6);
-
-    // ---------------------------------------------------------------- phase D: pool, sum over the heads, scores + histogram
-    // (score_finalize of the three-kernel path, utils.py:105-112), PER positions per thread
-    uint64_t *chain_in = chain + ((size_t)(bgv - 1) * nblk + blk) * TWG;      // written by virtual head vh - 1 (vh > 0 only)
-    uint64_t *chain_out = chain + ((size_t)bgv * nblk + blk) * TWG;
-    const bool last_vh = vh == VH - 1;
-#pragma unroll
-    for (int u = 0; u * 256 < TWG; ++u) {
-        const int lp = u * 256 + threadIdx.x, j = lo + lp;
-        const bool is_out = lp < TWG && j < n;
-        float gsum = 0.0f;
-        if (is_out && vh > 0) {                              // the head sum so far: {token, fp32 bits} granule of this position
-            uint64_t x;
-            while ((uint32_t)((x = __hip_atomic_load(chain_in + lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
-                __builtin_amdgcn_s_sleep(4);
-                if (spin_failed(sp)) break;                  // abandoned launch: the value is never used (the host reports the call)
-            }
-            gsum = bits_f32((uint32_t)x);
-        }
-        if (is_out) {
-            float pv[G];
-#pragma unroll
-            for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], PADMAX + lp, pad, ksize, avg);
-#pragma unroll
-            for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
-            if (!last_vh) __hip_atomic_store(chain_out + lp, granule(token, f32_bits(gsum)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const uint16_t c16 = f2h(gsum);
-        if (is_out && last_vh) {
-            c_out[(size_t)bg * c_row_stride + j] = c16;
-            if (all_idx) {                                   // capacity == S: identity selection + keys (see score_finalize)
-                all_idx[(size_t)bg * n + j] = (int64_t)j;
-                if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
-            }
-        }
-        if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
-    }
-    if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
-    if (want_hist && last_vh) {
         __syncthreads();
-        for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
-    }
+        return !s_abort;
+    };
+
+    // phase D of stream s: pool, sum over the heads, scores + histogram (score_finalize of the three-kernel path,
+    // utils.py:105-112)
+    auto phaseD = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        float(*tile)[TW] = tile_of(s);
+        uint32_t *s_hist = hist_of(s);
+        const int bg = bg_s[s], bgv = bgv_s[s], vh = vh_s[s];
+        uint32_t *hist_row = zero_area + (size_t)bg * HIST12;
+        uint64_t *chain_in = chain + ((size_t)(bgv - 1) * nblk + blk) * TWG;      // written by virtual head vh - 1 (vh > 0 only)
+        uint64_t *chain_out = chain + ((size_t)bgv * nblk + blk) * TWG;
+        const bool last_vh = vh == VH - 1;
+#pragma unroll
+        for (int u = 0; u * 256 < TWG; ++u) {
+            const int lp = u * 256 + threadIdx.x, j = lo + lp;
+            const bool is_out = lp < TWG && j < n;
+            float gsum = 0.0f;
+            if (is_out && vh > 0) {                              // the head sum so far: {token, fp32 bits} granule of this position
+                uint64_t x;
+                while ((uint32_t)((x = __hip_atomic_load(chain_in + lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (spin_failed(sp)) break;                  // abandoned launch: the value is never used (the host reports the call)
+                }
+                gsum = bits_f32((uint32_t)x);
+            }
+            if (is_out) {
+                float pv[G];
+#pragma unroll
+                for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], PADMAX + lp, pad, ksize, avg);
+#pragma unroll
+                for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
+                if (!last_vh) __hip_atomic_store(chain_out + lp, granule(token, f32_bits(gsum)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const uint16_t c16 = f2h(gsum);
+            if (is_out && last_vh) {
+                c_out[(size_t)bg * c_row_stride + j] = c16;
+                if (all_idx) {                                   // capacity == S: identity selection + keys (see score_finalize)
+                    all_idx[(size_t)bg * n + j] = (int64_t)j;
+                    if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
+                }
+            }
+            if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
+        }
+        if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
+        if (want_hist && last_vh) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
+        }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NS - 1>;            // (== S0 when NS == 1: the second calls below are compiled out)
+    phaseA(S0{});
+    FKF_STAMP(1);
+    if (NS == 2) phaseA(S1{});
+    FKF_STAMP(2);
+    if (!read_max(S0{})) return;
+    FKF_STAMP(3);
+    phaseB(S0{});
+    FKF_STAMP(4);
+    if (NS == 2) { if (!read_max(S1{})) return; FKF_STAMP(5); phaseB(S1{}); }
+    FKF_STAMP(6);
+    if (!read_sum(S0{})) return;
     FKF_STAMP(7);
+    phaseC(S0{});
+    FKF_STAMP(8);
+    if (NS == 2) { if (!read_sum(S1{})) return; FKF_STAMP(9); phaseC(S1{}); }
+    FKF_STAMP(10);
+    if (!read_halo(S0{})) return;
+    FKF_STAMP(11);
+    phaseD(S0{});
+    FKF_STAMP(12);
+    if (NS == 2) { if (!read_halo(S1{})) return; FKF_STAMP(13); phaseD(S1{}); }
+    FKF_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <int D, int PER, int NB> static bool fused_resident(int grid_wgs)
+template <int D, int PER, int NB, int NS> static bool fused_resident(int grid_wgs)
 {
     struct Info { int wgs_per_cu, cus; };
     static const Info info = []() {                            // initialised once, thread-safe (C++11 static)
@@ -540,7 +638,7 @@ template <int D, int PER, int NB> static bool fused_resident(int grid_wgs)
         int dev = 0, nb = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB>), 256, 0) ==
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB, NS>), 256, 0) ==
                 hipSuccess) {
             r.wgs_per_cu = nb;
             r.cus = prop.multiProcessorCount;
@@ -550,6 +648,29 @@ template <int D, int PER, int NB> static bool fused_resident(int grid_wgs)
     return info.wgs_per_cu >= 1 && grid_wgs <= (info.wgs_per_cu < 2 ? info.wgs_per_cu : 2) * info.cus;
 }
 
+// One instantiation: residency check + launch.
+template <int D, int PER, int NB, int NS> struct FusedLaunch {
+    static bool resident(int wgs) { return fused_resident<D, PER, NB, NS>(wgs); }
+    template <typename... Args> static void launch(dim3 grid, hipStream_t st, Args... args)
+    {
+        hipLaunchKernelGGL((score_fused_kernel<D, PER, NB, NS>), grid, dim3(256), 0, st, args...);
+    }
+};
+
+// Calls f(FusedLaunch<D, PER, NB, NS>{}) for the runtime shape; false if that combination is not instantiated.
+template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, F &&f)
+{
+#define FK_CASE(DV, PV, NBV, NSV) if (D == DV && per == PV && nb == NBV && ns == NSV) { f(FusedLaunch<DV, PV, NBV, NSV>{}); return true; }
+#define FK_CASES_D(DV)                                                                                          \
+    FK_CASE(DV, 1, 1, 1) FK_CASE(DV, 2, 1, 1) FK_CASE(DV, 4, 1, 1) FK_CASE(DV, 1, 2, 1) FK_CASE(DV, 2, 2, 1) FK_CASE(DV, 4, 2, 1)
+    FK_CASES_D(64) FK_CASES_D(128) FK_CASES_D(256)
+    // two streams (experiment): head dim 128, one tile per stream and wave
+    FK_CASE(128, 2, 1, 2) FK_CASE(128, 2, 2, 2)
+#undef FK_CASES_D
+#undef FK_CASE
+    return false;
+}
+
 // Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
 // covered and the caller must take the three-kernel path.
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
@@ -557,38 +678,51 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err)
 {
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    // FASTKV_FUSED_STREAMS=2: the two-heads-per-workgroup experiment (measured slower, see the kernel's comment); default 1
+    static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
     const int G = p.H / p.Hkv, VH = G / 4;                     // virtual heads of 4 query heads per KV head
     if (disabled || L.engine != ENGINE_MFMA || p.window != 8 || G % 4 != 0 || VH > 8 || p.kernel > 63) return false;
+    uint32_t *host_flag = abort_flag_device();
+    if (!host_flag) return false;                                // no way to report an abandoned launch: staged path
+    const int UH = p.Hkv * VH;                                   // units (kv head, virtual head) per batch row
     // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
-    const int NBV = (int64_t)p.B * p.Hkv * VH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
-    const int nwt = (p.S + 32 * NBV - 1) / (32 * NBV);
-    int nblk = (2 * 256) / (p.Hkv * p.B * VH);
-    if (nblk < 1) return false;
-    if (nblk > (nwt + 3) / 4) nblk = (nwt + 3) / 4;
-    const int per = (nwt + nblk * 4 - 1) / (nblk * 4);
-    if (per > 4) return false;
-    const int PERT = per <= 1 ? 1 : per <= 2 ? 2 : 4;          // tiles per wave the kernel is instantiated for
-    nblk = (nwt + PERT * 4 - 1) / (PERT * 4);                   // a workgroup owns 4*PERT consecutive tiles
-    if ((size_t)p.B * p.Hkv * VH * nblk > FUSED_MAX_WGS) return false;
+    const int NBV = (int64_t)p.B * UH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
+    const int TKV = 32 * NBV;
+    const int nwt = (p.S + TKV - 1) / TKV;
+    // one stream per workgroup: a workgroup owns 4 * PER consecutive tiles of ONE unit, at most 512 workgroups (2 per CU)
+    int nblk1 = (2 * 256) / (p.B * UH);
+    if (nblk1 < 1) return false;
+    if (nblk1 > (nwt + 3) / 4) nblk1 = (nwt + 3) / 4;
+    const int per1 = (nwt + nblk1 * 4 - 1) / (nblk1 * 4);
+    if (per1 > 4) return false;
+    int PERT = per1 <= 1 ? 1 : per1 <= 2 ? 2 : 4;              // tiles per wave the kernel is instantiated for
+    int NS = 1;
+    // Two streams: the workgroup owns 4 * PER / 2 consecutive tiles of TWO units (hvp and hvp + UH/2).  Needs an even number
+    // of units per batch row, rows that split into whole workgroup spans (no ragged or missing tiles: the prefetch chain runs
+    // straight from the last tile of stream 0 into the first tile of stream 1) and both query operands in LDS.
+    if (ns_pref == 2 && UH % 2 == 0 && p.D == 128) {
+        const int per2 = 2;                                     // one tile per stream and wave (the instantiated case)
+        if (PERT > 2) goto one_stream;
+        const int span = 4 * (per2 / 2) * TKV;                  // positions of a workgroup per stream
+        if (p.S % span == 0) { NS = 2; PERT = per2; }
+    }
+one_stream:
+    const int PS = PERT / NS;
+    const int nblk = (nwt + PS * 4 - 1) / (PS * 4);            // workgroups (spans) per unit
+    const size_t vwgs = (size_t)p.B * UH * nblk;                // hand-off records are per unit and span
+    if (vwgs > FUSED_MAX_WGS) return false;
+    const int wgs = (int)(vwgs / NS);
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(ws);
-    uint32_t *host_flag = abort_flag_device();
-    if (!host_flag) return false;                                // no way to report an abandoned launch: staged path
     const uint64_t spin_ticks = spin_limit_ticks();
-    uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [wg][2][4][31] halo granules
+    uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [unit span][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
-    dim3 grid(nblk * p.Hkv * VH, p.B);
-    const int wgs = nblk * p.Hkv * VH * p.B;
-    uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [wg][positions of a workgroup] head-sum granules (VH > 1)
+    dim3 grid(nblk * UH / NS, p.B);
+    uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
     bool resident = false;
-#define FK_RES2(DV, NBX) (PERT == 1 ? fused_resident<DV, 1, NBX>(wgs) : PERT == 2 ? fused_resident<DV, 2, NBX>(wgs) : fused_resident<DV, 4, NBX>(wgs))
-#define FK_RES(DV) (NBV == 1 ? FK_RES2(DV, 1) : FK_RES2(DV, 2))
-    resident = p.D == 64 ? FK_RES(64) : p.D == 128 ? FK_RES(128) : FK_RES(256);
-#undef FK_RES
-#undef FK_RES2
-    if (!resident) return false;
+    if (!fused_dispatch(p.D, PERT, NBV, NS, [&](auto fl) { resident = decltype(fl)::resident(wgs); }) || !resident) return false;
     // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
     // for each other until the spin limit and be reported as FASTKV_EABORTED).  Within this process the library sees to it:
     // when a launch comes on another stream than the previous one, an event recorded on the previous stream (now: behind
@@ -616,25 +750,11 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         }
     }
     ProfScope ps_(K_FUSED, st);
-#define FK_FUSED(DV, PV, NBX)                                                                                                    \
-    hipLaunchKernelGGL((score_fused_kernel<DV, PV, NBX>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],      \
-                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum,        \
-                       ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, \
-                       host_flag, spin_ticks)
-#define FK_FUSED_P(DV, NBX)                                                                                 \
-    do {                                                                                                    \
-        if (PERT == 1) FK_FUSED(DV, 1, NBX); else if (PERT == 2) FK_FUSED(DV, 2, NBX); else FK_FUSED(DV, 4, NBX);  \
-    } while (0)
-#define FK_FUSED_D(DV)                                                   \
-    do {                                                                 \
-        if (NBV == 1) FK_FUSED_P(DV, 1); else FK_FUSED_P(DV, 2);         \
-    } while (0)
-    if (p.D == 64) FK_FUSED_D(64);
-    else if (p.D == 128) FK_FUSED_D(128);
-    else FK_FUSED_D(256);
-#undef FK_FUSED_D
-#undef FK_FUSED_P
-#undef FK_FUSED
+    fused_dispatch(p.D, PERT, NBV, NS, [&](auto fl) {
+        decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
+                             p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
+                             c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks);
+    });
     *err = hipGetLastError();
     return true;
 }
