@@ -61,9 +61,18 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                         k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
                                                                            self.num_key_value_groups, self.layer_idx)
                     past_key_values.update(k_c, v_c, self.layer_idx)
-                else:                                             # decode: plain append
-                    key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
+                else:                                             # decode: plain append (llama_model.py:143-145)
                     self.tsp_idx = None
+                    layers = getattr(past_key_values, "layers", None)
+                    slab = layers[self.layer_idx] if layers is not None and self.layer_idx < len(layers) else None
+                    if isinstance(slab, SlabLayer) and slab.static_decode and key_states.is_cuda and q_len == 1:
+                        # static decode over the slab: append + GQA attention through the HIP decode kernels, the length is a
+                        # device-side counter -> no shape changes, the step is graph-capturable (fastkv_amd/cache.py)
+                        ops.decode_append(slab.kslab, slab.vslab, key_states, value_states, slab.len_dev)
+                        attn_output = ops.decode_attention(query_states, slab.kslab, slab.vslab, slab.len_dev, self.scaling)
+                        slab.host_step()
+                        return self.o_proj(attn_output.view(*input_shape, -1)), None
+                    key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
 
             attention_interface = modeling.ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation,
                                                                                 modeling.eager_attention_forward)
@@ -113,11 +122,17 @@ def make_model_forward(modeling, mask_fn_for):
         if use_cache and past_key_values is None:
             past_key_values = make_cache(self.config)
         if position_ids is None:
+            if getattr(past_key_values, "static_decode", False):
+                raise ValueError("static decode (graph-capturable) needs position_ids as a device tensor: a host-side position "
+                                 "would be frozen into the captured graph")
             past_seen = past_key_values.get_seq_length() if past_key_values is not None else 0
             position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + past_seen).unsqueeze(0)
             position_ids = position_ids.expand(inputs_embeds.shape[0], -1)
-        causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
-                                               past_key_values=past_key_values, position_ids=position_ids)
+        if getattr(past_key_values, "static_decode", False) and inputs_embeds.shape[1] == 1:
+            causal_mask = None                                    # one new token attends to the whole cache: nothing to mask
+        else:
+            causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                                                   past_key_values=past_key_values, position_ids=position_ids)
         hidden_states = inputs_embeds
         position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:

@@ -1,10 +1,15 @@
 """End-to-end latency harness: counterpart of /root/reference/benchmark/e2e.py (`:53-176`): one prefill followed by
 `genlen-1` greedy decode steps over the (compressed) cache, every forward bracketed by device events (`:72-93`),
 throughput = (genlen-1) / total time.  Same flags as benchmark/prefill.py (+ `--genlen`); models are random-initialised
-geometries (no checkpoints on the GPU box), decode attention runs through PyTorch-ROCm SDPA -- the decode kernel itself
-is outside this repository's hot path, what this harness exercises is that the compressed, per-layer cache produced by
-the prefill path is consumed correctly step after step (positions restart at the compressed length when no
-`position_ids` are passed, exactly as in the reference, `:82-90`)."""
+geometries (no checkpoints on the GPU box).  Positions restart at the compressed length when no `position_ids` are passed,
+exactly as in the reference (`:82-90`).
+
+Two decode paths:
+  * eager (any device, any cache): `model(input_ids=tok, past_key_values=pkv)` per token, attention through PyTorch SDPA;
+  * `--decode_graph` (default on the GPU with the slab cache, FASTKV_SLAB_CACHE=1): the cache goes into static-decode mode
+    (fastkv_amd/cache.py: lengths in device memory), the attention module appends and attends through the HIP decode
+    kernels (csrc/decode.hip), and the whole step -- model forward, argmax, token and position update -- is captured once
+    in a HIP graph and replayed for the remaining tokens: no host work per layer, no shape changes, no reallocation."""
 from __future__ import annotations
 
 import os
@@ -19,6 +24,40 @@ import numpy as np
 import torch
 
 from benchmark import prefill as P
+
+
+def graph_decode(model, pkv, tok, steps, timed):
+    """`steps` greedy decode steps over a slab cache in static-decode mode: the first one eagerly (it warms every library up on
+    this stream and is a real, counted step), then ONE capture of the step and `steps - 1` replays.  Returns (ms, tokens)."""
+    dev = tok.device
+    pkv.enable_static_decode(steps + 8)
+    tok_buf = tok.clone()
+    # positions restart at the compressed length (reference e2e.py:82-90 passes no position_ids); kept on the device
+    pos_buf = torch.full((tok.shape[0], 1), pkv.get_seq_length(), dtype=torch.int64, device=dev)
+    out_tok = torch.zeros(steps, dtype=torch.int64, device=dev)
+    step_no = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        out = model(input_ids=tok_buf, past_key_values=pkv, position_ids=pos_buf)
+        nxt = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
+        tok_buf.copy_(nxt)
+        pos_buf.add_(1)
+        out_tok.index_copy_(0, step_no, nxt[0])
+        step_no.add_(1)
+
+    total, _ = timed(step)                                        # eager: step 1
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):                    # records step 2 (nothing runs during the capture)
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(steps - 1):
+        dt, _ = timed(g.replay)
+        total += dt
+    pkv.finish_static_decode()                                    # host mirrors <- device lengths
+    return total, [int(x) for x in out_tok.tolist()]
 
 
 def main(model, args):
@@ -48,6 +87,7 @@ def main(model, args):
         return (time.perf_counter() - t0) * 1e3, out
 
     results = []
+    graph_mode = False
     for it in range(args.num_warmups + args.num_runs):
         with torch.no_grad():
             t_prefill, out = timed(lambda: model(input_id, attention_mask=attn_mask))
@@ -55,12 +95,18 @@ def main(model, args):
             tok = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
             generated = [int(tok[0, 0])]
             t_decode = 0.0
-            for _ in range(args.genlen - 1):
-                dt, out = timed(lambda: model(input_ids=tok, past_key_values=pkv))
-                t_decode += dt
-                pkv = out.past_key_values
-                tok = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
-                generated.append(int(tok[0, 0]))
+            graph_mode = bool(getattr(args, "decode_graph", True)) and use_events and hasattr(pkv, "enable_static_decode") \
+                and args.genlen > 2
+            if graph_mode:
+                t_decode, toks = graph_decode(model, pkv, tok, args.genlen - 1, timed)
+                generated += toks
+            else:
+                for _ in range(args.genlen - 1):
+                    dt, out = timed(lambda: model(input_ids=tok, past_key_values=pkv))
+                    t_decode += dt
+                    pkv = out.past_key_values
+                    tok = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
+                    generated.append(int(tok[0, 0]))
         if it >= args.num_warmups:
             results.append((t_prefill, t_decode, len(generated)))
         cache_len = int(pkv.layers[0].keys.shape[-2])
@@ -70,7 +116,8 @@ def main(model, args):
     tot = pre + dec
     res = {"method": args.method, "context_length": args.context_length, "genlen": args.genlen, "prefill_ms": float(pre.mean()),
            "decode_ms_per_token": float(dec.mean() / max(1, args.genlen - 1)),
-           "throughput_tok_s": float((args.genlen - 1) / (tot.mean() / 1e3)), "final_cache_len_layer0": cache_len}
+           "throughput_tok_s": float((args.genlen - 1) / (tot.mean() / 1e3)), "final_cache_len_layer0": cache_len,
+           "decode_path": "hip graph replay over the slab cache (HIP decode attention)" if graph_mode else "eager (SDPA)"}
     print(f"[e2e] {args.method} ctx={args.context_length} gen={args.genlen}: prefill {res['prefill_ms']:.1f} ms, "
           f"decode {res['decode_ms_per_token']:.2f} ms/token, e2e throughput {res['throughput_tok_s']:.1f} tok/s, cache {cache_len}")
     return res

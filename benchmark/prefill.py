@@ -144,6 +144,8 @@ def parse_args(argv=None):
     p.add_argument("--attn_implementation", type=str, default="sdpa", choices=["flash_attention_2", "sdpa", "eager"])
     # Benchmark settings
     p.add_argument("--genlen", type=int, default=128)
+    p.add_argument("--decode_graph", type=int, default=1, help="e2e.py on the GPU with FASTKV_SLAB_CACHE=1: capture the decode "
+                                                             "step in a HIP graph (HIP decode attention over the slab cache)")
     p.add_argument("--num_warmups", type=int, default=1)
     p.add_argument("--num_runs", type=int, default=1)
     p.add_argument("--eval_batch_size", type=int, default=1)

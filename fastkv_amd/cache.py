@@ -6,6 +6,11 @@ copy of the WHOLE layer cache at every decode step.  `SlabLayer` owns one `[B,Hk
 the HIP compaction writes its rows straight into it (`FastKVCluster.update_kv(..., out_factory=layer.prefill_views)` ->
 `fastkv_update_kv_strided_f16`), decode steps append one row in place, and attention reads the `[:, :, :len]` view.
 Drop-in for `DynamicCache` in greedy decoding (`update`, `get_seq_length`, `get_mask_sizes`); pure torch, device-agnostic.
+
+Static decode: `enable_static_decode(extra_rows)` makes room for the tokens to come and puts every layer's
+length into device memory (`len_dev`).  From then on the attention module appends and attends through the HIP decode
+kernels (`fastkv_decode_append_f16` / `fastkv_decode_attention_f16`), which read and advance that device-side length: no shape
+changes from step to step, so the whole decode step can be captured once in a HIP graph and replayed (benchmark/e2e.py).
 """
 from __future__ import annotations
 
@@ -19,6 +24,8 @@ class SlabLayer(DynamicLayer):
         self.reserve = reserve
         self.kslab = self.vslab = None
         self.len = 0
+        self.static_decode = False
+        self.len_dev = None
 
     def _alloc(self, B, H, rows, D, dtype, device):
         self.kslab = torch.empty(B, H, rows, D, dtype=dtype, device=device)
@@ -73,9 +80,40 @@ class SlabLayer(DynamicLayer):
     def get_seq_length(self) -> int:
         return self.len
 
+    # ---- static decode: the length lives on the device, the kernels advance it
+    def enable_static_decode(self, extra_rows: int):
+        assert self.kslab is not None and self.kslab.is_cuda, "static decode needs a prefilled slab on the GPU"
+        if self.len + extra_rows > self.kslab.shape[2]:
+            self._grow(self.len + extra_rows)
+        self.len_dev = torch.tensor([self.len], dtype=torch.int32, device=self.kslab.device)
+        self.static_decode = True
+
+    def host_step(self):
+        """Host mirror of one decode step (the device-side length is advanced by the attention kernel)."""
+        self.len += 1
+
+    def finish_static_decode(self, true_len=None):
+        """Leave static mode: the host mirror takes the device's length (one small copy + sync) unless it is given."""
+        if self.static_decode:
+            self.len = int(self.len_dev.item()) if true_len is None else int(true_len)
+            self.static_decode = False
+            self._views()
+
 
 class FastKVSlabCache(Cache):
     """`DynamicCache` stand-in made of `SlabLayer`s (one per decoder layer)."""
 
     def __init__(self, num_layers: int, reserve: int = 256):
         super().__init__(layers=[SlabLayer(reserve) for _ in range(num_layers)])
+
+    @property
+    def static_decode(self) -> bool:
+        return bool(self.layers) and all(getattr(l, "static_decode", False) for l in self.layers)
+
+    def enable_static_decode(self, extra_rows: int):
+        for l in self.layers:
+            l.enable_static_decode(extra_rows)
+
+    def finish_static_decode(self):
+        for l in self.layers:
+            l.finish_static_decode()

@@ -1,0 +1,264 @@
+// Decode step over the compressed per-layer cache (/root/reference/baselines/fastkv/llama_model.py:143-145
+// appends the new K/V row with `past_key_value.update` -- a torch.cat of the whole layer -- and attends with flash-attn,
+// /root/reference/benchmark/e2e.py:72-93 times it).  Here the cache is a pre-sized slab [B,Hkv,rows,D] per layer
+// (fastkv_amd/cache.py) whose current length lives in DEVICE memory, so the whole decode step has static shapes and can be
+// replayed from a HIP graph:
+//   decode_append    the step's K/V row -> slab row `len`                        (one 16-B piece per thread)
+//   decode_partial   GQA attention of the G query heads of a KV head over a slice of the len+1 rows: scores with one cache
+//                    row per lane (the row's 2*D bytes in 16-B loads), online softmax per wave, P.V with the lanes across
+//                    head_dim (coalesced 4-B loads of V rows, probabilities from LDS) -> {max, sum, o[D]} per slice
+//   decode_combine   merges the slices, writes fp16 [B,1,H*D], advances `len`
+// HBM bound by construction (every cache byte is read once: 2*Hkv*(len+1)*D*2 bytes per layer, 9.4 MB at budget 2048 + 256
+// decoded tokens), in practice latency bound at these sizes: the slices spread a layer over 8*nsplit workgroups.
+// fp32 softmax; the result is compared with PyTorch SDPA to fp16 tolerance (tests/test_decode_gpu.py), not bit for bit.
+#include "fk_device.h"
+#include "fk_host.h"
+#include "prof.h"
+
+namespace fk {
+
+constexpr int DEC_THREADS = 256;
+
+template <int LPR>
+__global__ void __launch_bounds__(64) decode_append_kernel(const uint16_t *__restrict__ k_new, int64_t kn_b, int64_t kn_h,
+                                                          const uint16_t *__restrict__ v_new, int64_t vn_b, int64_t vn_h,
+                                                          uint16_t *__restrict__ kslab, uint16_t *__restrict__ vslab, int64_t s_b,
+                                                          int64_t s_h, int64_t s_r, int rows, const int32_t *__restrict__ len_dev)
+{
+    const int h = blockIdx.x, b = blockIdx.y, sub = threadIdx.x;
+    int len = *len_dev;
+    if (sub >= LPR) return;
+    if (len >= rows) len = rows - 1;                             // a full slab overwrites its last row instead of its neighbour (the host sizes it)
+    const uint4 kv = *reinterpret_cast<const uint4 *>(k_new + b * kn_b + h * kn_h + sub * 8);
+    const uint4 vv = *reinterpret_cast<const uint4 *>(v_new + b * vn_b + h * vn_h + sub * 8);
+    *reinterpret_cast<uint4 *>(kslab + b * s_b + h * s_h + (int64_t)len * s_r + sub * 8) = kv;
+    *reinterpret_cast<uint4 *>(vslab + b * s_b + h * s_h + (int64_t)len * s_r + sub * 8) = vv;
+}
+
+// part[b][h][c] = {m, l, o[D]} (fp32).  grid (nsplit, Hkv, B), 256 threads.
+template <int D, int G>
+__global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint16_t *__restrict__ q, int64_t q_b, int64_t q_h,
+                                                                   const uint16_t *__restrict__ kslab,
+                                                                   const uint16_t *__restrict__ vslab, int64_t s_b, int64_t s_h,
+                                                                   int64_t s_r, int rows, const int32_t *__restrict__ len_dev,
+                                                                   float scaling, float *__restrict__ part, int nsplit)
+{
+    constexpr int DPL = D / 64;                                  // head-dim elements per lane in the P.V product
+    __shared__ float s_q[G][D];
+    __shared__ float s_p[4][G][64];
+    __shared__ float s_m[4][G], s_l[4][G];
+    __shared__ float s_o[4][G][D];
+    const int c = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int len = *len_dev + 1;                                      // the step's own row was appended at index *len_dev
+    if (len > rows) len = rows;
+    const int chunk = ((len + nsplit - 1) / nsplit + 63) / 64 * 64;
+    const int lo = c * chunk, hi = min(len, lo + chunk);
+    for (int i = threadIdx.x; i < G * D; i += DEC_THREADS) {
+        const int g = i / D, d = i - g * D;
+        s_q[g][d] = h2f(q[b * q_b + (int64_t)(hk * G + g) * q_h + d]) * scaling;
+    }
+    __syncthreads();
+    const uint16_t *kb = kslab + b * s_b + hk * s_h, *vb = vslab + b * s_b + hk * s_h;
+    float m[G], l[G], o[G][DPL];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[g][e] = 0.0f;
+    }
+    for (int t0 = lo + w * 64; t0 < hi; t0 += 4 * 64) {
+        // ---- scores: lane = cache row t0 + lane
+        const int j = t0 + lane;
+        const bool valid = j < hi;
+        const uint16_t *kr = kb + (int64_t)(valid ? j : hi - 1) * s_r;
+        float sc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) sc[g] = 0.0f;
+#pragma unroll
+        for (int half = 0; half < D / 64; ++half) {
+            uint4 kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + half * 64 + u * 8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t wds[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float k0 = h2f((uint16_t)(wds[e] & 0xffffu)), k1 = h2f((uint16_t)(wds[e] >> 16));
+                    const int d = half * 64 + u * 8 + e * 2;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sc[g] = __builtin_fmaf(s_q[g][d + 1], k1, __builtin_fmaf(s_q[g][d], k0, sc[g]));
+                }
+            }
+        }
+        // ---- online softmax of the tile (wave-wide), probabilities to LDS
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float s = valid ? sc[g] : -INFINITY;
+            const float tm = wave_max(s);
+            const float mn = fmaxf(m[g], tm);
+            const float p = valid ? __expf(s - mn) : 0.0f;
+            float ps = p;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+            const float corr = __expf(m[g] - mn);                // m = -inf on the first tile: exp(-inf) = 0
+            l[g] = l[g] * corr + ps;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) o[g][e] *= corr;
+            m[g] = mn;
+            s_p[w][g][lane] = p;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- P.V: lane = head-dim elements lane*DPL .. ; rows of the tile one after the other (coalesced row loads)
+        const int nrow = min(64, hi - t0);
+        for (int r0 = 0; r0 < nrow; r0 += 8) {
+            uint32_t vv[8][(DPL + 1) / 2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jr = min(t0 + r0 + u, hi - 1);
+                const uint16_t *vr = vb + (int64_t)jr * s_r + lane * DPL;
+                if (DPL == 1) vv[u][0] = *vr;
+                else if (DPL == 2) vv[u][0] = *reinterpret_cast<const uint32_t *>(vr);
+                else { const uint2 x = *reinterpret_cast<const uint2 *>(vr); vv[u][0] = x.x; vv[u][1] = x.y; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (r0 + u < nrow) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float p = s_p[w][g][r0 + u];
+#pragma unroll
+                        for (int e = 0; e < DPL; ++e) {
+                            const uint32_t wd = vv[u][e / 2];
+                            o[g][e] = __builtin_fmaf(p, h2f((uint16_t)((e & 1) ? wd >> 16 : wd & 0xffffu)), o[g][e]);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the four waves' partials -> one record of the slice
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (lane == 0) { s_m[w][g] = m[g]; s_l[w][g] = l[g]; }
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) s_o[w][g][lane * DPL + e] = o[g][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G * D; i += DEC_THREADS) {
+        const int g = i / D, d = i - g * D;
+        const float M = fmaxf(fmaxf(s_m[0][g], s_m[1][g]), fmaxf(s_m[2][g], s_m[3][g]));
+        float L = 0.0f, O = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float f = s_m[ww][g] == -INFINITY ? 0.0f : __expf(s_m[ww][g] - M);
+            L += s_l[ww][g] * f;
+            O += s_o[ww][g][d] * f;
+        }
+        float *rec = part + (((size_t)b * gridDim.y * G + hk * G + g) * nsplit + c) * (D + 2);
+        rec[2 + d] = O;
+        if (d == 0) { rec[0] = M; rec[1] = L; }
+    }
+}
+
+// grid (H, B), D threads; advances *len_dev (block 0, thread 0) -- every reader of the old length has finished by now
+template <int D>
+__global__ void __launch_bounds__(D) decode_combine_kernel(const float *__restrict__ part, int nsplit, uint16_t *__restrict__ out, int H,
+                                                           int32_t *__restrict__ len_dev, int rows)
+{
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float *rec = part + ((size_t)b * H + h) * nsplit * (D + 2);
+    float M = -INFINITY;
+    for (int c = 0; c < nsplit; ++c) M = fmaxf(M, rec[c * (D + 2)]);
+    float L = 0.0f, O = 0.0f;
+    for (int c = 0; c < nsplit; ++c) {
+        const float mc = rec[c * (D + 2)];
+        const float f = mc == -INFINITY ? 0.0f : __expf(mc - M);
+        L += rec[c * (D + 2) + 1] * f;
+        O += rec[c * (D + 2) + 2 + d] * f;
+    }
+    out[((size_t)b * H + h) * D + d] = f2h(O / L);
+    if (h == 0 && b == 0 && d == 0 && len_dev) { const int n = *len_dev + 1; *len_dev = n < rows ? n : rows; }
+}
+
+}  // namespace fk
+
+using namespace fk;
+
+extern "C" {
+
+size_t fastkv_decode_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t nsplit)
+{
+    if (B < 1 || H < 1 || nsplit < 1) return 0;
+    return align_up((size_t)B * H * nsplit * (D + 2) * sizeof(float), 256);
+}
+
+int fastkv_decode_append_f16(int32_t B, int32_t Hkv, int32_t D, const void *k_new, const int64_t kn_strides[2], const void *v_new,
+                             const int64_t vn_strides[2], void *kslab, void *vslab, const int64_t slab_strides[3], int32_t rows,
+                             const int32_t *len_dev, void *stream)
+{
+    if (B < 1 || Hkv < 1 || rows < 1 || !k_new || !v_new || !kslab || !vslab || !len_dev || !kn_strides || !vn_strides || !slab_strides)
+        return FASTKV_EINVAL;
+    if (D != 64 && D != 128 && D != 256) return FASTKV_EUNSUPPORTED;
+    if (((uintptr_t)k_new | (uintptr_t)v_new | (uintptr_t)kslab | (uintptr_t)vslab) & 15) return FASTKV_EINVAL;
+    for (int i = 0; i < 2; ++i) if ((kn_strides[i] & 7) || (vn_strides[i] & 7)) return FASTKV_EINVAL;
+    for (int i = 0; i < 3; ++i) if (slab_strides[i] & 7) return FASTKV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps_(K_DECODE, st);
+    dim3 grid(Hkv, B);
+#define FK_APP(LPRV)                                                                                                                \
+    hipLaunchKernelGGL((decode_append_kernel<LPRV>), grid, dim3(64), 0, st, (const uint16_t *)k_new, kn_strides[0], kn_strides[1],  \
+                       (const uint16_t *)v_new, vn_strides[0], vn_strides[1], (uint16_t *)kslab, (uint16_t *)vslab, slab_strides[0], \
+                       slab_strides[1], slab_strides[2], rows, len_dev)
+    if (D == 64) FK_APP(8);
+    else if (D == 128) FK_APP(16);
+    else FK_APP(32);
+#undef FK_APP
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, const void *q, const int64_t q_strides[2],
+                                const void *kslab, const void *vslab, const int64_t slab_strides[3], int32_t rows, int32_t *len_dev,
+                                float scaling, int32_t nsplit, void *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B < 1 || Hkv < 1 || H < Hkv || (H % Hkv) || rows < 1 || nsplit < 1 || nsplit > 256) return FASTKV_EINVAL;
+    if (!q || !kslab || !vslab || !len_dev || !out || !workspace || !q_strides || !slab_strides) return FASTKV_EINVAL;
+    if (D != 64 && D != 128 && D != 256) return FASTKV_EUNSUPPORTED;
+    const int G = H / Hkv;
+    if (G != 1 && G != 2 && G != 4 && G != 8) return FASTKV_EUNSUPPORTED;
+    if (((uintptr_t)kslab | (uintptr_t)vslab) & 15) return FASTKV_EINVAL;
+    for (int i = 0; i < 3; ++i) if (slab_strides[i] & 7) return FASTKV_EINVAL;
+    if (workspace_bytes < fastkv_decode_workspace_bytes(B, H, D, nsplit)) return FASTKV_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    dim3 grid(nsplit, Hkv, B);
+    {
+        ProfScope ps_(K_DECODE, st);
+#define FK_PART(DV, GV)                                                                                                              \
+    hipLaunchKernelGGL((decode_partial_kernel<DV, GV>), grid, dim3(DEC_THREADS), 0, st, (const uint16_t *)q, q_strides[0], q_strides[1], \
+                       (const uint16_t *)kslab, (const uint16_t *)vslab, slab_strides[0], slab_strides[1], slab_strides[2], rows,     \
+                       (const int32_t *)len_dev, scaling, part, nsplit)
+#define FK_PART_G(DV)                                                                                      \
+    do {                                                                                                   \
+        if (G == 1) FK_PART(DV, 1); else if (G == 2) FK_PART(DV, 2); else if (G == 4) FK_PART(DV, 4); else FK_PART(DV, 8); \
+    } while (0)
+        if (D == 64) FK_PART_G(64);
+        else if (D == 128) FK_PART_G(128);
+        else FK_PART_G(256);
+#undef FK_PART_G
+#undef FK_PART
+    }
+    if (hipGetLastError() != hipSuccess) return FASTKV_ELAUNCH;
+    ProfScope ps2_(K_DECODE, st);
+    if (D == 64) hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(H, B), dim3(64), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
+    else if (D == 128) hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(H, B), dim3(128), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
+    else hipLaunchKernelGGL((decode_combine_kernel<256>), dim3(H, B), dim3(256), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+}  // extern "C"

@@ -7,7 +7,7 @@
 
 namespace fk {
 
-enum KernelId { K_PREP_Q = 0, K_LOGITS, K_ROWSTATS, K_FINALIZE, K_TSP_ROWSUM, K_SELECT, K_RANK, K_COMPACT, K_GATHER, K_FUSED, K_SELECT_SPLIT, K_SP_AUX, K_COUNT };
+enum KernelId { K_PREP_Q = 0, K_LOGITS, K_ROWSTATS, K_FINALIZE, K_TSP_ROWSUM, K_SELECT, K_RANK, K_COMPACT, K_GATHER, K_FUSED, K_SELECT_SPLIT, K_SP_AUX, K_DECODE, K_COUNT };
 
 struct ProfScope {
     int slot;

@@ -10,7 +10,7 @@ static std::vector<Rec> g_recs;     // recorded since the last read
 static std::vector<Rec> g_pool;     // reusable events
 
 static const char *const g_names[K_COUNT] = {"prep_q", "score_logits", "row_stats", "score_finalize", "tsp_rowsum",
-                                             "select_topk", "rank_scatter", "compact_kv", "gather_rows", "score_fused", "select_split", "sp_aux"};
+                                             "select_topk", "rank_scatter", "compact_kv", "gather_rows", "score_fused", "select_split", "sp_aux", "decode"};
 
 ProfScope::ProfScope(int kid, hipStream_t s) : slot(-1), st(s)
 {

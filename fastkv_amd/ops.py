@@ -213,3 +213,40 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
                               idx.data_ptr(), idx.stride(0), B, idx.shape[1], S, row_bytes, out.data_ptr(), _stream())
     check(rc, "gather_rows")
     return out
+
+
+# ------------------------------------------------------------------------------------------------- decode over the slab cache
+DECODE_NSPLIT = int(os.environ.get("FASTKV_DECODE_NSPLIT", "16"))
+
+
+def decode_append(kslab: torch.Tensor, vslab: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, len_dev: torch.Tensor) -> None:
+    """Slab row `len_dev[0]` <- the step's K/V row ([B,Hkv,1,D]); the length itself is advanced by decode_attention."""
+    _require_cuda(kslab, vslab, k_new, v_new, len_dev)
+    B, Hkv, rows, D = kslab.shape
+    assert k_new.shape == (B, Hkv, 1, D) and v_new.shape == k_new.shape and k_new.stride(3) == 1 and v_new.stride(3) == 1
+    assert kslab.stride() == vslab.stride() and kslab.stride(3) == 1 and len_dev.dtype == torch.int32
+    I2, I3 = ctypes.c_int64 * 2, ctypes.c_int64 * 3
+    rc = load().fastkv_decode_append_f16(B, Hkv, D, k_new.data_ptr(), I2(k_new.stride(0), k_new.stride(1)), v_new.data_ptr(),
+                                         I2(v_new.stride(0), v_new.stride(1)), kslab.data_ptr(), vslab.data_ptr(),
+                                         I3(*kslab.stride()[:3]), rows, len_dev.data_ptr(), _stream())
+    check(rc, "decode_append")
+
+
+def decode_attention(q: torch.Tensor, kslab: torch.Tensor, vslab: torch.Tensor, len_dev: torch.Tensor, scaling: float,
+                     nsplit: int = 0) -> torch.Tensor:
+    """GQA attention of q [B,H,1,D] over slab rows 0 .. len_dev[0] (inclusive: the row decode_append just wrote) -> fp16
+    [B,1,H*D]; advances len_dev on the device.  Static shapes: capturable in a HIP graph."""
+    _require_cuda(q, kslab, vslab, len_dev)
+    B, H, one, D = q.shape
+    Hkv, rows = kslab.shape[1], kslab.shape[2]
+    assert one == 1 and q.stride(3) == 1 and q.dtype == torch.float16 and kslab.dtype == torch.float16
+    nsplit = nsplit or DECODE_NSPLIT
+    L = load()
+    out = torch.empty(B, 1, H * D, dtype=torch.float16, device=q.device)
+    ws = _workspace(L.fastkv_decode_workspace_bytes(B, H, D, nsplit), q.device, "decode")
+    I2, I3 = ctypes.c_int64 * 2, ctypes.c_int64 * 3
+    rc = L.fastkv_decode_attention_f16(B, H, Hkv, D, q.data_ptr(), I2(q.stride(0), q.stride(1)), kslab.data_ptr(), vslab.data_ptr(),
+                                       I3(*kslab.stride()[:3]), rows, len_dev.data_ptr(), ctypes.c_float(scaling), nsplit,
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "decode_attention")
+    return out

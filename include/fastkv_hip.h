@@ -242,6 +242,27 @@ int fastkv_sp_compact_f16(int32_t B, int32_t Hkv, int32_t S_r, int32_t D, int32_
                           int32_t window_owner, void *k_out, void *v_out, void *stream);
 
 /*
+ * ---- Decode over the compressed cache (the reference appends with `past_key_value.update` -- a torch.cat
+ * of the whole layer -- and attends with flash-attn: baselines/fastkv/llama_model.py:143-145, benchmark/e2e.py:72-93) ----
+ * The layer's cache is a pre-sized slab [B,Hkv,rows,D] (element strides slab_strides = {batch, head, row}, the compaction
+ * wrote its first `capacity` rows: fastkv_update_kv_strided_f16) whose current length is an int32 in DEVICE memory: shapes
+ * are static, so a whole decode step can be captured in a HIP graph and replayed.
+ *   fastkv_decode_append_f16     k_new / v_new [B,Hkv,1,D] (element strides {batch, head}) -> slab row *len_dev
+ *   fastkv_decode_attention_f16  q [B,H,1,D] (strides {batch, head}) attends over rows 0 .. *len_dev (the appended row
+ *                                included), G = H/Hkv in {1,2,4,8} query heads share a KV head; fp32 softmax; out fp16
+ *                                [B,1,H*D] contiguous; then *len_dev += 1.  nsplit = slices per KV head (8-32: the layer is
+ *                                spread over Hkv*nsplit workgroups); workspace: fastkv_decode_workspace_bytes.
+ * Compared with PyTorch SDPA to fp16 tolerance, not bit for bit (a different summation order of the softmax).
+ */
+size_t fastkv_decode_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t nsplit);
+int fastkv_decode_append_f16(int32_t B, int32_t Hkv, int32_t D, const void *k_new, const int64_t kn_strides[2], const void *v_new,
+                             const int64_t vn_strides[2], void *kslab, void *vslab, const int64_t slab_strides[3], int32_t rows,
+                             const int32_t *len_dev, void *stream);
+int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, const void *q, const int64_t q_strides[2],
+                                const void *kslab, const void *vslab, const int64_t slab_strides[3], int32_t rows, int32_t *len_dev,
+                                float scaling, int32_t nsplit, void *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
  * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b)) so tests can compare the GPU bit-for-bit with the CPU oracle.

@@ -1,0 +1,129 @@
+"""Decode over the compressed slab cache on the MI355X: the HIP append / GQA decode-attention kernels
+against a plain PyTorch fp32 reference of the same step, and the graph-replayed greedy decode of benchmark/e2e.py against
+the eager DynamicCache path of the same model (/root/reference/benchmark/e2e.py:72-93 is the loop being reproduced).
+
+Tolerance, not bit equality: the kernel sums the softmax in another order than SDPA (slices per KV head, online softmax per
+wave); outputs are fp16, so |diff| <= 2e-3 * max|ref| + 1e-3 is a few fp16 ulps."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_step(q, kslab, vslab, L, scaling):
+    """fp32 attention of q [B,H,1,D] over rows 0..L-1 of the slabs, GQA by head repetition."""
+    B, H, _, D = q.shape
+    Hkv = kslab.shape[1]
+    k = kslab[:, :, :L].float().repeat_interleave(H // Hkv, dim=1)
+    v = vslab[:, :, :L].float().repeat_interleave(H // Hkv, dim=1)
+    s = torch.einsum("bhqd,bhkd->bhqk", q.float(), k) * scaling
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhqk,bhkd->bhqd", p, v)                      # [B,H,1,D]
+    return o.transpose(1, 2).reshape(B, 1, H * D)
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,L0,rows", [
+    (1, 32, 8, 128, 2048, 2304),       # Llama-3-8B layer after a budget-2048 prefill
+    (1, 32, 8, 128, 1, 64),            # a cache of one row
+    (2, 8, 8, 64, 63, 200),            # MHA, head_dim 64, batch 2, ragged slice ends
+    (1, 8, 1, 128, 3276, 3500),        # Llama-3-70B TP rank (G = 8), the proportional recipe's capacity
+    (1, 16, 8, 256, 130, 256),         # G = 2, head_dim 256
+])
+def test_decode_kernels_match_fp32_reference(B, H, Hkv, D, L0, rows):
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + L0)
+    kslab = torch.randn(B, Hkv, rows, D, generator=g, device=dev, dtype=torch.float16)
+    vslab = torch.randn(B, Hkv, rows, D, generator=g, device=dev, dtype=torch.float16)
+    untouched_k = kslab.clone()
+    len_dev = torch.tensor([L0], dtype=torch.int32, device=dev)
+    scaling = D ** -0.5
+    for step in range(3):
+        # q / k_new / v_new exactly as the attention module hands them over: [B,1,h,D] storage viewed as [B,h,1,D]
+        q = torch.randn(B, 1, H, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+        kn = torch.randn(B, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+        vn = torch.randn(B, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+        for nsplit in (0, 5):
+            if nsplit:                                              # second pass over the same step: rewind the length
+                len_dev.fill_(L0 + step)
+            ops.decode_append(kslab, vslab, kn, vn, len_dev)
+            out = ops.decode_attention(q, kslab, vslab, len_dev, scaling, nsplit=nsplit)
+            torch.cuda.synchronize()
+            L = L0 + step + 1
+            assert int(len_dev.item()) == L
+            assert torch.equal(kslab[:, :, L - 1], kn[:, :, 0]) and torch.equal(vslab[:, :, L - 1], vn[:, :, 0])
+            ref = _ref_step(q, kslab, vslab, L, scaling)
+            tol = 2e-3 * float(ref.abs().max()) + 1e-3
+            assert float((out.float() - ref).abs().max()) <= tol, (step, nsplit, float((out.float() - ref).abs().max()), tol)
+    assert torch.equal(kslab[:, :, :L0], untouched_k[:, :, :L0]) and torch.equal(kslab[:, :, L0 + 3:], untouched_k[:, :, L0 + 3:])
+
+
+def test_graph_replayed_decode_matches_eager_dynamic_cache(monkeypatch):
+    """Two layers of the Llama-3-8B geometry, 700-token prompt compressed to 128 rows per layer, then 6 greedy decode steps:
+    (a) eager over DynamicCache with SDPA (the reference's loop), (b) benchmark.e2e.graph_decode over the slab cache (HIP
+    decode kernels, ONE captured step replayed).  Same tokens are fed to both (teacher forcing with (a)'s tokens would hide
+    nothing here: the check is on the logits of every step), logits agree to fp16 tolerance, the caches hold the same rows."""
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import e2e, prefill
+
+    def build(slab):
+        monkeypatch.setenv("FASTKV_SLAB_CACHE", slab)
+        a = prefill.parse_args(["--model_path", "llama3-8b", "--num_layers", "2", "--device", "cuda", "--save_txt", "", "--method",
+                                "fastkv", "--max_capacity_prompts", "128", "--tsp_len", "256", "--tsp_idx", "0"])
+        a.save_txt = False
+        a.context_lengths = [700]
+        replace_llama("fastkv")
+        torch.manual_seed(3)
+        model = prefill.build_model(a, "cuda")
+        set_model(model, a)
+        return model
+
+    ids = torch.randint(0, 1000, (1, 700), generator=torch.Generator().manual_seed(5)).cuda()
+    steps = 6
+    # (a) eager, DynamicCache
+    model = build("0")
+    logits_a, toks_a = [], []
+    with torch.no_grad():
+        out = model(ids, attention_mask=torch.ones_like(ids))
+        pkv = out.past_key_values
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        first = tok.clone()
+        for _ in range(steps):
+            out = model(input_ids=tok, past_key_values=pkv)          # positions restart at the compressed length (e2e.py:82-90)
+            logits_a.append(out.logits[:, -1].float().cpu())
+            tok = out.logits[:, -1].argmax(-1, keepdim=True)
+            toks_a.append(int(tok[0, 0]))
+    keys_a = [pkv.layers[i].keys.clone() for i in range(2)]
+    del model, pkv
+    # (b) slab cache + graph replay; capture the logits of every step through a hook on lm_head
+    model = build("1")
+    logits_b = []
+    hook = model.lm_head.register_forward_hook(lambda m, i, o: logits_b.append(o[:, -1].float().clone()))
+    with torch.no_grad():
+        out = model(ids, attention_mask=torch.ones_like(ids))
+        pkv = out.past_key_values
+        assert torch.equal(out.logits[:, -1].argmax(-1, keepdim=True), first)
+        logits_b.clear()
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            return 0.0, None
+
+        _, toks_b = e2e.graph_decode(model, pkv, first, steps, timed)
+    hook.remove()
+    # the hook fired once for the eager step, once during the capture (garbage: nothing runs then) and the graph's output
+    # buffer holds the LAST replayed step afterwards; the tokens are recorded on the device for every step
+    assert len(toks_b) == steps
+    scale = max(float(l.abs().max()) for l in logits_a)
+    assert float((logits_b[0].cpu() - logits_a[0]).abs().max()) <= 2e-2 * scale + 2e-3          # step 1 (eager, HIP kernels)
+    assert float((logits_b[-1].cpu() - logits_a[-1]).abs().max()) <= 3e-2 * scale + 2e-3         # last replayed step
+    # greedy tokens: identical unless two logits of a random-initialised model are within the tolerance of each other
+    agree = sum(int(x == y) for x, y in zip(toks_a, toks_b))
+    assert toks_b[0] == toks_a[0] and agree >= steps - 2, (toks_a, toks_b)
+    for i in range(2):
+        kb = pkv.layers[i].keys
+        assert kb.shape == keys_a[i].shape == (1, 8, 128 + steps, 128)
+        assert torch.equal(kb[:, :, :128], keys_a[i][:, :, :128])                                # the compacted prefill rows
+        if agree == steps:
+            assert float((kb[:, :, 128:].float() - keys_a[i][:, :, 128:].float()).abs().max()) <= 5e-2
