@@ -75,3 +75,30 @@ def set_model(model, args):
             setattr(args, name, [val] * layers)
     from baselines.fastkv.utils import compress_fastkv
     compress_fastkv(model, args)
+
+
+# ---- generation-input preparation (/root/reference/baselines/monkeypatch.py:249-389) ---------------------------------
+# The reference overrides `prepare_inputs_for_generation` of transformers 4.45 so that, after a COMPRESSED prefill, decode
+# steps get their true positions (attention-mask cumsum, `:280-288`) instead of positions derived from the shorter cache.
+# The installed transformers (5.x) already derives `position_ids` from the attention mask inside `generate()`; these two
+# functions keep the reference's names importable and enforce exactly that rule on top of the stock implementation, so a
+# caller that installs them (as the reference's `replace_llama` / `replace_mistral` do) gets the same behaviour on both.
+def _prepare_inputs_true_positions(stock):
+    def prepare(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, position_ids=None, **kwargs):
+        model_inputs = stock(self, input_ids, past_key_values=past_key_values, attention_mask=attention_mask,
+                             inputs_embeds=inputs_embeds, position_ids=position_ids, **kwargs)
+        if attention_mask is not None and position_ids is None:
+            pos = attention_mask.long().cumsum(-1) - 1                 # monkeypatch.py:280-283
+            pos.masked_fill_(attention_mask == 0, 1)
+            ids = model_inputs.get("input_ids")
+            n_new = ids.shape[1] if ids is not None else model_inputs["inputs_embeds"].shape[1]
+            model_inputs["position_ids"] = pos[:, -n_new:].clone(memory_format=torch.contiguous_format)
+        return model_inputs
+    return prepare
+
+
+import torch  # noqa: E402  (only the two functions below need it)
+from transformers import LlamaForCausalLM, MistralForCausalLM  # noqa: E402
+
+prepare_inputs_for_generation_llama = _prepare_inputs_true_positions(LlamaForCausalLM.prepare_inputs_for_generation)
+prepare_inputs_for_generation_mistral = _prepare_inputs_true_positions(MistralForCausalLM.prepare_inputs_for_generation)

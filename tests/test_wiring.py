@@ -227,3 +227,43 @@ def test_eager_attention_stays_causal_after_the_tsp_layer():
         with torch.no_grad():
             outs[impl] = model(ids, attention_mask=torch.ones_like(ids)).logits
     assert torch.allclose(outs["eager"], outs["sdpa"], atol=2e-4, rtol=1e-4), float((outs["eager"] - outs["sdpa"]).abs().max())
+
+
+@pytest.mark.parametrize("install_override", [False, True])
+def test_generate_decodes_at_true_positions_after_a_compressed_prefill(install_override):
+    """`model.generate()` on top of a compressed prefill: decode steps must run at the prompt's TRUE positions (200, 201, ...),
+    not at positions derived from the 40-row cache -- what the reference's prepare_inputs_for_generation override provides on
+    transformers 4.45 (/root/reference/baselines/monkeypatch.py:280-288).  The installed transformers does it by itself;
+    with the reference-named override installed the result is the same."""
+    from transformers import LlamaForCausalLM
+    from baselines import monkeypatch as MP
+    from benchmark import prefill
+    a = _args(method="fastkv", max_capacity_prompts=40, tsp_len=80, tsp_idx=0)
+    a.context_lengths = [200]
+    MP.replace_llama("fastkv")
+    stock = LlamaForCausalLM.prepare_inputs_for_generation
+    if install_override:
+        LlamaForCausalLM.prepare_inputs_for_generation = MP.prepare_inputs_for_generation_llama      # as monkeypatch.py:55-56
+    try:
+        torch.manual_seed(17)
+        model = prefill.build_model(a, "cpu")
+        MP.set_model(model, a)
+        for layer in model.model.layers:
+            layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+        seen = []
+        inner = type(model.model).forward
+
+        def spy(self, *args, **kw):
+            seen.append((kw["position_ids"][0, -1].item(), kw["past_key_values"].get_seq_length()))
+            return inner(self, *args, **kw)
+
+        type(model.model).forward = spy
+        try:
+            ids = torch.randint(0, 1000, (1, 200), generator=torch.Generator().manual_seed(19))
+            out = model.generate(ids, attention_mask=torch.ones_like(ids), max_new_tokens=4, do_sample=False)
+        finally:
+            type(model.model).forward = inner
+        assert out.shape == (1, 204)
+        assert seen == [(199, 0), (200, 40), (201, 41), (202, 42)]
+    finally:
+        LlamaForCausalLM.prepare_inputs_for_generation = stock
