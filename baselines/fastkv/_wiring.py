@@ -21,6 +21,26 @@ from fastkv_amd.cache import FastKVSlabCache, SlabLayer
 from fastkv_amd.cluster import init_fastkv
 
 
+def _static_step(past_key_values, hidden_states) -> bool:
+    """One-token step over a slab cache in static-decode mode on the GPU: the small operators of the step take their
+    single-launch HIP versions (csrc/decode.hip; the stock modules issue 7 / 8 / 2 elementwise launches for them)."""
+    return getattr(past_key_values, "static_decode", False) and hidden_states.is_cuda and hidden_states.shape[1] == 1 \
+        and hidden_states.dtype == torch.float16
+
+
+def _norm(module, hidden_states, static):
+    if static and hasattr(module, "variance_epsilon") and module.weight.dtype == torch.float16:
+        return ops.decode_rmsnorm(hidden_states, module.weight, module.variance_epsilon)
+    return module(hidden_states)
+
+
+def _mlp(module, hidden_states, static):
+    if static and getattr(getattr(module, "config", None), "hidden_act", None) == "silu" and hasattr(module, "gate_proj") \
+            and getattr(module.gate_proj, "bias", None) is None:
+        return module.down_proj(ops.decode_silu_mul(module.gate_proj(hidden_states), module.up_proj(hidden_states)))
+    return module(hidden_states)
+
+
 def make_cache(config):
     """DynamicCache as in the reference, or (FASTKV_SLAB_CACHE=1) pre-sized per-layer slabs that the compaction writes
     into directly and decode steps append to in place (fastkv_amd/cache.py)."""
@@ -46,7 +66,10 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
             key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
             value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
             cos, sin = position_embeddings
-            query_states, key_states = modeling.apply_rotary_pos_emb(query_states, key_states, cos, sin)
+            if _static_step(past_key_values, hidden_states) and cos.dtype == torch.float16:
+                ops.decode_rope_(query_states, key_states, cos, sin)      # in place on the fresh projections, one launch
+            else:
+                query_states, key_states = modeling.apply_rotary_pos_emb(query_states, key_states, cos, sin)
 
             if past_key_values is not None:
                 if q_len > 1:                                     # prefill: compress what goes into the cache
@@ -88,15 +111,16 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
 
 def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None,
                                 use_cache=False, position_embeddings=None, **kwargs):
+    static = _static_step(past_key_values, hidden_states)
     residual = hidden_states
-    hidden_states = self.input_layernorm(hidden_states)
+    hidden_states = _norm(self.input_layernorm, hidden_states, static)
     hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                       past_key_values=past_key_values, use_cache=use_cache,
                                       position_embeddings=position_embeddings, **kwargs)
     hidden_states = residual + hidden_states
     residual = hidden_states
-    hidden_states = self.post_attention_layernorm(hidden_states)
-    hidden_states = self.mlp(hidden_states)
+    hidden_states = _norm(self.post_attention_layernorm, hidden_states, static)
+    hidden_states = _mlp(self.mlp, hidden_states, static)
     hidden_states = residual + hidden_states
     # [FastKV] token-selective propagation: keep only the selected tokens from this layer on
     tsp_idx = getattr(self.self_attn, "tsp_idx", None)
@@ -150,7 +174,7 @@ def make_model_forward(modeling, mask_fn_for):
                 # over the current K/V), and no position ids: the gaps between surviving positions are not sequence boundaries.
                 causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=hidden_states, attention_mask=None,
                                                        past_key_values=None, position_ids=None)
-        hidden_states = self.norm(hidden_states)
+        hidden_states = _norm(self.norm, hidden_states, _static_step(past_key_values, hidden_states))
         hidden_states = hidden_states[:, -1:, :]                  # only the last token feeds lm_head
         return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
 

@@ -76,18 +76,17 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
         float sc[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) sc[g] = 0.0f;
+        {
+            uint4 kv[D / 8];                                     // the whole row in flight: one round trip per tile
 #pragma unroll
-        for (int half = 0; half < D / 64; ++half) {
-            uint4 kv[8];
+            for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + half * 64 + u * 8);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < D / 8; ++u) {
                 const uint32_t wds[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float k0 = h2f((uint16_t)(wds[e] & 0xffffu)), k1 = h2f((uint16_t)(wds[e] >> 16));
-                    const int d = half * 64 + u * 8 + e * 2;
+                    const int d = u * 8 + e * 2;
 #pragma unroll
                     for (int g = 0; g < G; ++g) sc[g] = __builtin_fmaf(s_q[g][d + 1], k1, __builtin_fmaf(s_q[g][d], k0, sc[g]));
                 }
@@ -114,10 +113,11 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
         __builtin_amdgcn_wave_barrier();
         // ---- P.V: lane = head-dim elements lane*DPL .. ; rows of the tile one after the other (coalesced row loads)
         const int nrow = min(64, hi - t0);
-        for (int r0 = 0; r0 < nrow; r0 += 8) {
-            uint32_t vv[8][(DPL + 1) / 2];
+        constexpr int RB = 32;                                   // V rows in flight per batch: the tile costs two round trips
+        for (int r0 = 0; r0 < nrow; r0 += RB) {
+            uint32_t vv[RB][(DPL + 1) / 2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 const int jr = min(t0 + r0 + u, hi - 1);
                 const uint16_t *vr = vb + (int64_t)jr * s_r + lane * DPL;
                 if (DPL == 1) vv[u][0] = *vr;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
                 else { const uint2 x = *reinterpret_cast<const uint2 *>(vr); vv[u][0] = x.x; vv[u][1] = x.y; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 if (r0 + u < nrow) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
@@ -184,6 +184,84 @@ __global__ void __launch_bounds__(D) decode_combine_kernel(const float *__restri
     }
     out[((size_t)b * H + h) * D + d] = f2h(O / L);
     if (h == 0 && b == 0 && d == 0 && len_dev) { const int n = *len_dev + 1; *len_dev = n < rows ? n : rows; }
+}
+
+// ---- the step's small operators, one launch each (the stock modules run 7 / 8 / 2 elementwise launches for them) ----
+// RMSNorm as transformers' LlamaRMSNorm / MistralRMSNorm compute it: fp32 mean of squares, x * rsqrt(var + eps) -> fp16,
+// times the fp16 weight -> fp16.  One 256-thread workgroup per row.
+__global__ void __launch_bounds__(256) decode_rmsnorm_kernel(const uint16_t *__restrict__ x, int64_t x_row, const uint16_t *__restrict__ wgt,
+                                                            uint16_t *__restrict__ out, int hidden, float eps)
+{
+    __shared__ float s_part[4];
+    const uint16_t *xr = x + (int64_t)blockIdx.x * x_row;
+    float ss = 0.0f;
+    for (int i = threadIdx.x * 8; i < hidden; i += 256 * 8) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(xr + i);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = h2f((uint16_t)(wds[e] & 0xffffu)), b = h2f((uint16_t)(wds[e] >> 16));
+            ss = __builtin_fmaf(a, a, ss);
+            ss = __builtin_fmaf(b, b, ss);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float var = (s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)hidden;
+    const float r = 1.0f / __builtin_sqrtf(var + eps);
+    for (int i = threadIdx.x * 8; i < hidden; i += 256 * 8) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(xr + i), g = *reinterpret_cast<const uint4 *>(wgt + i);
+        const uint32_t wx[4] = {v.x, v.y, v.z, v.w}, wg[4] = {g.x, g.y, g.z, g.w};
+        uint32_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t n0 = f2h(h2f((uint16_t)(wx[e] & 0xffffu)) * r), n1 = f2h(h2f((uint16_t)(wx[e] >> 16)) * r);
+            const uint16_t y0 = f2h(h2f((uint16_t)(wg[e] & 0xffffu)) * h2f(n0)), y1 = f2h(h2f((uint16_t)(wg[e] >> 16)) * h2f(n1));
+            o4[e] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+        }
+        *reinterpret_cast<uint4 *>(out + (int64_t)blockIdx.x * hidden + i) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+}
+
+// apply_rotary_pos_emb on the step's q [B,H,1,D] and k [B,Hkv,1,D] (both rewritten in place), cos / sin [B,1,D]:
+// x*cos -> fp16, rotate_half(x)*sin -> fp16, sum -> fp16 -- the stock fp16 sequence, rounding for rounding.
+__global__ void __launch_bounds__(128) decode_rope_kernel(uint16_t *__restrict__ q, int64_t q_b, int64_t q_h, int H,
+                                                         uint16_t *__restrict__ k, int64_t k_b, int64_t k_h, int Hkv,
+                                                         const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
+                                                         int64_t cs_b, int D)
+{
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    if (d >= D / 2) return;
+    uint16_t *x = h < H ? q + b * q_b + (int64_t)h * q_h : k + b * k_b + (int64_t)(h - H) * k_h;
+    const float x1 = h2f(x[d]), x2 = h2f(x[d + D / 2]);
+    const float c1 = h2f(cosv[b * cs_b + d]), c2 = h2f(cosv[b * cs_b + d + D / 2]);
+    const float s1 = h2f(sinv[b * cs_b + d]), s2 = h2f(sinv[b * cs_b + d + D / 2]);
+    // rotate_half(x) = cat(-x2, x1)
+    const uint16_t o1 = f2h(h2f(f2h(x1 * c1)) + h2f(f2h(-x2 * s1)));
+    const uint16_t o2 = f2h(h2f(f2h(x2 * c2)) + h2f(f2h(x1 * s2)));
+    x[d] = o1;
+    x[d + D / 2] = o2;
+}
+
+// act_fn(gate) * up of the MLP (SiLU): silu in fp32 -> fp16, times up -> fp16
+__global__ void __launch_bounds__(256) decode_silu_mul_kernel(const uint16_t *__restrict__ gate, const uint16_t *__restrict__ up,
+                                                             uint16_t *__restrict__ out, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint4 g = *reinterpret_cast<const uint4 *>(gate + i), u = *reinterpret_cast<const uint4 *>(up + i);
+    const uint32_t wg[4] = {g.x, g.y, g.z, g.w}, wu[4] = {u.x, u.y, u.z, u.w};
+    uint32_t o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float g0 = h2f((uint16_t)(wg[e] & 0xffffu)), g1 = h2f((uint16_t)(wg[e] >> 16));
+        const uint16_t a0 = f2h(g0 / (1.0f + __expf(-g0))), a1 = f2h(g1 / (1.0f + __expf(-g1)));
+        const uint16_t y0 = f2h(h2f(a0) * h2f((uint16_t)(wu[e] & 0xffffu))), y1 = f2h(h2f(a1) * h2f((uint16_t)(wu[e] >> 16)));
+        o4[e] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+    }
+    *reinterpret_cast<uint4 *>(out + i) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
 }
 
 }  // namespace fk
@@ -258,6 +336,38 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
     if (D == 64) hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(H, B), dim3(64), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
     else if (D == 128) hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(H, B), dim3(128), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
     else hipLaunchKernelGGL((decode_combine_kernel<256>), dim3(H, B), dim3(256), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_decode_rmsnorm_f16(const void *x, int64_t rows, int64_t x_row_stride, int32_t hidden, const void *weight, float eps, void *out,
+                              void *stream)
+{
+    if (!x || !weight || !out || rows < 0 || hidden < 8 || (hidden & 7) || (x_row_stride & 7) || x_row_stride < hidden) return FASTKV_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) & 15) return FASTKV_EINVAL;
+    if (rows == 0) return FASTKV_OK;
+    ProfScope ps_(K_DECODE, (hipStream_t)stream);
+    hipLaunchKernelGGL(decode_rmsnorm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, x_row_stride,
+                       (const uint16_t *)weight, (uint16_t *)out, hidden, eps);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q, const int64_t q_strides[2], void *k,
+                           const int64_t k_strides[2], const void *cosv, const void *sinv, int64_t cs_batch_stride, void *stream)
+{
+    if (B < 1 || H < 1 || Hkv < 1 || D < 2 || (D & 1) || D > 256 || !q || !k || !cosv || !sinv || !q_strides || !k_strides) return FASTKV_EINVAL;
+    ProfScope ps_(K_DECODE, (hipStream_t)stream);
+    hipLaunchKernelGGL(decode_rope_kernel, dim3(H + Hkv, B), dim3(128), 0, (hipStream_t)stream, (uint16_t *)q, q_strides[0], q_strides[1], H,
+                       (uint16_t *)k, k_strides[0], k_strides[1], Hkv, (const uint16_t *)cosv, (const uint16_t *)sinv, cs_batch_stride, D);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void *out, void *stream)
+{
+    if (!gate || !up || !out || n < 0 || (n & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)out) & 15)) return FASTKV_EINVAL;
+    if (n == 0) return FASTKV_OK;
+    ProfScope ps_(K_DECODE, (hipStream_t)stream);
+    hipLaunchKernelGGL(decode_silu_mul_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)gate,
+                       (const uint16_t *)up, (uint16_t *)out, n);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

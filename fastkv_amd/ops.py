@@ -250,3 +250,36 @@ def decode_attention(q: torch.Tensor, kslab: torch.Tensor, vslab: torch.Tensor, 
                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "decode_attention")
     return out
+
+
+def decode_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """RMSNorm of the step's hidden states [..., hidden] (fp16) in one launch; arithmetic of LlamaRMSNorm."""
+    _require_cuda(x, weight)
+    hidden = x.shape[-1]
+    assert x.dtype == torch.float16 and weight.dtype == torch.float16 and x.stride(-1) == 1 and weight.is_contiguous()
+    x2 = x.reshape(-1, hidden)
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    check(load().fastkv_decode_rmsnorm_f16(x2.data_ptr(), x2.shape[0], x2.stride(0), hidden, weight.data_ptr(), ctypes.c_float(eps),
+                                           out.data_ptr(), _stream()), "decode_rmsnorm")
+    return out
+
+
+def decode_rope_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> None:
+    """apply_rotary_pos_emb on the step's q [B,H,1,D] / k [B,Hkv,1,D], IN PLACE; cos / sin [B,1,D] fp16."""
+    _require_cuda(q, k, cos, sin)
+    B, H, one, D = q.shape
+    assert one == 1 and k.shape[2] == 1 and q.stride(3) == 1 and k.stride(3) == 1 and cos.shape == (B, 1, D) and cos.stride(2) == 1 \
+        and sin.stride() == cos.stride() and cos.dtype == torch.float16 and q.dtype == torch.float16
+    I2 = ctypes.c_int64 * 2
+    check(load().fastkv_decode_rope_f16(B, H, k.shape[1], D, q.data_ptr(), I2(q.stride(0), q.stride(1)), k.data_ptr(),
+                                        I2(k.stride(0), k.stride(1)), cos.data_ptr(), sin.data_ptr(), cos.stride(0), _stream()),
+          "decode_rope")
+
+
+def decode_silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """silu(gate) * up (fp16, contiguous, same shape) in one launch."""
+    _require_cuda(gate, up)
+    assert gate.shape == up.shape and gate.is_contiguous() and up.is_contiguous() and gate.dtype == torch.float16
+    out = torch.empty_like(gate)
+    check(load().fastkv_decode_silu_mul_f16(gate.data_ptr(), up.data_ptr(), gate.numel(), out.data_ptr(), _stream()), "decode_silu_mul")
+    return out

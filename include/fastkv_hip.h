@@ -263,6 +263,20 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
                                 float scaling, int32_t nsplit, void *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The step's small operators as single launches (the stock modules issue 7 / 8 / 2 elementwise launches for them; at one
+ * token per step those launches, not the bytes, are the cost).  Same arithmetic as the modules they stand in for:
+ *   rmsnorm   LlamaRMSNorm / MistralRMSNorm: fp32 mean of squares, x * rsqrt(var + eps) -> fp16, * weight -> fp16
+ *             x [rows, hidden] with a row stride, out [rows, hidden] contiguous
+ *   rope      apply_rotary_pos_emb on q [B,H,1,D] and k [B,Hkv,1,D] IN PLACE (strides {batch, head}); cos / sin [B,1,D]
+ *   silu_mul  act_fn(gate) * up of the MLP, n elements (multiple of 8)
+ */
+int fastkv_decode_rmsnorm_f16(const void *x, int64_t rows, int64_t x_row_stride, int32_t hidden, const void *weight, float eps, void *out,
+                              void *stream);
+int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q, const int64_t q_strides[2], void *k,
+                           const int64_t k_strides[2], const void *cosv, const void *sinv, int64_t cs_batch_stride, void *stream);
+int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void *out, void *stream);
+
+/*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
  * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b)) so tests can compare the GPU bit-for-bit with the CPU oracle.

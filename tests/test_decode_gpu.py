@@ -127,3 +127,36 @@ def test_graph_replayed_decode_matches_eager_dynamic_cache(monkeypatch):
         assert torch.equal(kb[:, :, :128], keys_a[i][:, :, :128])                                # the compacted prefill rows
         if agree == steps:
             assert float((kb[:, :, 128:].float() - keys_a[i][:, :, 128:].float()).abs().max()) <= 5e-2
+
+
+def test_single_launch_step_operators_match_the_stock_modules():
+    """decode_rmsnorm / decode_rope_ / decode_silu_mul against the modules they stand in for during a static decode step
+    (transformers' LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP's act_fn(gate) * up), fp16 on the GPU.  RoPE repeats the stock
+    fp16 rounding sequence (bit-exact); the other two differ at most by an fp16 ulp where an fp32 intermediate rounds the
+    other way."""
+    from transformers.models.llama import modeling_llama as ML
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(2, 1, 4096, generator=g, device=dev, dtype=torch.float16) * 3
+    norm = ML.LlamaRMSNorm(4096, eps=1e-5).to(dev).half()
+    norm.weight.data = torch.randn(4096, generator=g, device=dev, dtype=torch.float16)
+    want, got = norm(x), ops.decode_rmsnorm(x, norm.weight, norm.variance_epsilon)
+    assert float((got.float() - want.float()).abs().max()) <= 2e-3 * float(want.abs().max())
+    assert float((got != want).float().mean()) < 0.02
+    # rope
+    q = torch.randn(2, 1, 32, 128, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+    k = torch.randn(2, 1, 8, 128, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+    ang = torch.rand(2, 1, 64, generator=g, device=dev) * 6.28
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1).half(), torch.cat([ang.sin(), ang.sin()], -1).half()
+    wq, wk = ML.apply_rotary_pos_emb(q, k, cos, sin)
+    q2, k2 = q.clone(), k.clone()
+    ops.decode_rope_(q2, k2, cos, sin)
+    assert torch.equal(q2, wq) and torch.equal(k2, wk)
+    # silu * up
+    a = torch.randn(2, 1, 14336, generator=g, device=dev, dtype=torch.float16) * 2
+    b = torch.randn(2, 1, 14336, generator=g, device=dev, dtype=torch.float16)
+    want = torch.nn.functional.silu(a) * b
+    got = ops.decode_silu_mul(a, b)
+    assert float((got.float() - want.float()).abs().max()) <= 2e-3 * float(want.abs().max())
+    assert float((got != want).float().mean()) < 0.02
