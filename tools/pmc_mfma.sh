@@ -3,7 +3,7 @@
 tag=${1:-x}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/${tag}_pmc_mfma -- python $R/bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $R/gpurun_out/${tag}_pmc_mfma.log
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/${tag}_pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $R/gpurun_out/${tag}_pmc_mfma.log
 cd $R
 python - <<PY
 import csv, glob, collections, statistics as st, json

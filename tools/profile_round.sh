@@ -1,13 +1,13 @@
 #!/bin/bash
 # Produces the round's measurement artefacts under gpurun_out/ (copy the summaries into profiles/):
 #   bench JSON line, rocprofv3 --kernel-trace --stats of the same command, FETCH_SIZE / WRITE_SIZE PMC passes.
-tag=${1:-r01}
+tag=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/${tag}_bench.json 2> $R/gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python $R/bench.py > $R/gpurun_out/${tag}_trace_bench.json 2> $R/gpurun_out/${tag}_trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $R/gpurun_out/${tag}_pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $R/gpurun_out/${tag}_pmc_write.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $R/bench.py > $R/gpurun_out/${tag}_trace_bench.json 2> $R/gpurun_out/${tag}_trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $R/gpurun_out/${tag}_pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $R/gpurun_out/${tag}_pmc_write.log
 cd $R
 python - <<PY
 import csv, glob, collections, statistics as st, json
@@ -25,4 +25,5 @@ for name,counter in (("fetch","FETCH_SIZE"),("write","WRITE_SIZE")):
 json.dump(out, open(f'gpurun_out/{tag}_pmc_summary.json','w'), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
+bash tools/pmc_mfma.sh ${tag} > /dev/null 2>&1
 python tools/profile_summarise.py ${tag} > /dev/null; cat gpurun_out/${tag}_bench.json | cut -c1-400

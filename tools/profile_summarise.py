@@ -23,6 +23,8 @@ shutil.copy(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_bench.
 shutil.copy(os.path.join(G, f"{tag}_trace_bench.json"), os.path.join(P, f"{tag}_bench_under_rocprofv3.json"))
 shutil.copy(one(f"{tag}_trace/*/*_kernel_stats.csv"), os.path.join(P, f"{tag}_rocprofv3_kernel_stats.csv"))
 shutil.copy(os.path.join(G, f"{tag}_pmc_summary.json"), os.path.join(P, f"{tag}_pmc_fetch_write_summary.json"))
+if os.path.exists(os.path.join(G, f"{tag}_pmc_mfma_summary.json")):
+    shutil.copy(os.path.join(G, f"{tag}_pmc_mfma_summary.json"), os.path.join(P, f"{tag}_pmc_mfma_summary.json"))
 
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(one(f"{tag}_trace/*/*_kernel_trace.csv"))):
