@@ -96,6 +96,19 @@ __device__ __forceinline__ float fix_to_f32(uint64_t s)
     return bits_f32(((uint32_t)(exp2 - 40 + 127) << 23) | (mant & 0x7fffffu));
 }
 
+// two fp32 -> one packed fp16 pair, round to nearest even per component: v_cvt_pk_f16_f32 (gfx950), ONE instruction where
+// f2h twice + a pack take three.  Bit-identical to f2h per component (checked element-wise on the GPU over every fp16
+// rounding boundary and its neighbours: fastkv_debug_contract op 12, tests/test_hip_parity.py).  The empty asm keeps the
+// producer of the pair opaque, as in f2h (no single-rounding mix instruction may swallow a preceding multiply).
+typedef _Float16 fk_h16x2 __attribute__((ext_vector_type(2)));
+typedef float fk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2h2(float lo, float hi)
+{
+    fk_f32x2 v = {lo, hi};
+    asm("" : "+v"(v));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fk_h16x2));
+}
+
 // ---- two elements per instruction: v_pk_mul/fma/add_f32 are IEEE per component, so every component below is bit-identical
 // to the scalar function above (same operations, same order); only rint / convert / select / integer steps stay scalar
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -129,6 +142,33 @@ template <bool NONPOS = false> __device__ __forceinline__ f32x2 det_expf2(f32x2 
     out.y = bits_f32((uint32_t)((int32_t)f32_bits(p.y) + (int32_t)n.y * (1 << 23)));
     if (!ok0) out.x = (d.x != d.x) ? d.x : 0.0f;
     if (!ok1) out.y = (d.y != d.y) ? d.y : 0.0f;
+    return out;
+}
+
+// det_expf2 for arguments the caller knows to be <= 0 and not NaN: the range test becomes a clamp (v_max_f32) and nothing
+// is selected afterwards.  For d >= -87 the result is det_expf(d) bit for bit; for d < -87 (and -inf) it is exp(-87) ~ 1.6e-38
+// instead of 0 -- indistinguishable downstream: below 2^-41 the fixed-point addend is 0 (exp_to_fix) and the probability
+// e * (1/sum) with sum >= 1 rounds to the fp16 zero either way (fused.hip phase B explains when a tile may take this path).
+__device__ __forceinline__ f32x2 det_expf2_clamped(f32x2 d)
+{
+    f32x2 dc = {fmaxf(d.x, -87.0f), fmaxf(d.y, -87.0f)};
+    f32x2 n = dc * splat2(1.44269504088896341f);
+    n.x = __builtin_rintf(n.x);
+    n.y = __builtin_rintf(n.y);
+    f32x2 r = fma2(n, splat2(-0.693359375f), dc);
+    r = fma2(n, splat2(2.12194440e-4f), r);
+    f32x2 p = splat2(1.9875691500e-4f);
+    p = fma2(p, r, splat2(1.3981999507e-3f));
+    p = fma2(p, r, splat2(8.3334519073e-3f));
+    p = fma2(p, r, splat2(4.1665795894e-2f));
+    p = fma2(p, r, splat2(1.6666665459e-1f));
+    p = fma2(p, r, splat2(5.0000001201e-1f));
+    const f32x2 r2 = r * r;
+    p = fma2(p, r2, r);
+    p = p + splat2(1.0f);
+    f32x2 out;
+    out.x = bits_f32((uint32_t)((int32_t)f32_bits(p.x) + (int32_t)n.x * (1 << 23)));
+    out.y = bits_f32((uint32_t)((int32_t)f32_bits(p.y) + (int32_t)n.y * (1 << 23)));
     return out;
 }
 

@@ -32,8 +32,8 @@
 namespace fk {
 
 #ifdef FK_STAMP
-__device__ unsigned long long g_fstamps[4096 * 16];
-#define FKF_STAMP(slot) do { if (lane == 0) g_fstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 16 + (slot)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_fstamps[4096 * 48];
+#define FKF_STAMP(slot) do { if (lane == 0) g_fstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096 * 48 + (slot)] = wall_clock64(); } while (0)
 #else
 #define FKF_STAMP(slot) do { } while (0)
 #endif
@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             }
         }
     __syncthreads();
+    FKF_STAMP(16);
     if (NPH >= 2) k_fetch<NB>(sB, kb_s[0], ks_s, tile_key0(0), S, 1, lane);
     else if (tile_valid(1)) k_fetch<NB>(sB, kb_s[(1 / PS) % NS], ks_s, tile_key0(1), S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -196,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][NW];
     float ev[PER][2][NW];
+    uint32_t tile_nan = 0;                                       // bit t: tile t's contraction held a NaN (wave-uniform)
 
     // ================================================================ phase A of stream s: logits of its tiles, row maxima,
     // publication of the workgroup's 32 partial maxima as {token, value} granules
@@ -240,15 +242,18 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                redo_tile_if_nan<NPH, NB>(acc0, acc1, kb_s[s], ks_s, key0, S, lane, my, As + s * AS_FLOATS + lane, n31, sh);
+                FKF_STAMP(17 + 2 * (t % 2));
+                if (redo_tile_if_nan<NPH, NB>(acc0, acc1, kb_s[s], ks_s, key0, S, lane, my, As + s * AS_FLOATS + lane, n31, sh))
+                    tile_nan |= 1u << t;
                 const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
                 if (key0 + TK <= n) {
                     // tile entirely among the candidates: no window mask, every column counts; the running maxima stay
                     // packed fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf)
 #pragma unroll
                     for (int i = 0; i < NW; ++i) {
-                        const f32x2 scv = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[(i + 8) & 15]))}, sqrtD, rsqrtD);   // utils.py:94
-                        const uint32_t wd = (uint32_t)f2h(scv.x) | ((uint32_t)f2h(scv.y) << 16);
+                        const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[(i + 8) & 15]);             // matmul -> fp16
+                        const f32x2 scv = scale_div2((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);   // utils.py:94
+                        const uint32_t wd = f2h2(scv.x, scv.y);
                         mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
                                                                                           __builtin_bit_cast(h16x2, wd)));
                         lg[t][i] = wd;
@@ -259,8 +264,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                         const int rw = (i & 3) + 4 * hi;                                     // window row of both rows of the word: m % W
                         const int rB = NB == 2 ? i : (i + 8) & 15;
                         // utils.py:94: matmul -> fp16, / sqrt(D) -> fp16 (both halves of the pair in one packed sequence)
-                        const f32x2 scv = scale_div2((f32x2){h2f(f2h(acc0[i])), h2f(f2h(NB == 2 ? acc1[i] : acc0[rB]))}, sqrtD, rsqrtD);
-                        uint16_t s0 = f2h(scv.x), s1 = f2h(scv.y);
+                        const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[rB]);
+                        const f32x2 scv = scale_div2((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);
+                        const uint32_t sw = f2h2(scv.x, scv.y);
+                        uint16_t s0 = (uint16_t)(sw & 0xffffu), s1 = (uint16_t)(sw >> 16);
                         if (jA >= n && (jA - n) > rw) s0 = f2h(h2f(s0) + (-65504.0f));       // utils.py:95-101
                         if (jB >= n && (jB - n) > rw) s1 = f2h(h2f(s1) + (-65504.0f));
                         if (jA < S) mx[i] = fmaxf(mx[i], h2f(s0));
@@ -268,6 +275,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                         lg[t][i] = (uint32_t)s0 | ((uint32_t)s1 << 16);
                     }
                 }
+                FKF_STAMP(18 + 2 * (t % 2));
             }
         }
 #pragma unroll
@@ -282,12 +290,14 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             const int i = halfwave_red_index(lane);
             if ((lane & 1) == 0) s_pf[s][w][(i & 3) + 8 * (i >> 2) + 4 * hi] = r;
         }
+        FKF_STAMP(21);
         if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's histogram zeros have reached memory
         __syncthreads();
         if (w == 0 && lane < 32)
             __hip_atomic_store(pmax + ((size_t)bgv_s[s] * nblk + blk) * 32 + lane,
                                granule(token, f32_bits(fmaxf(fmaxf(s_pf[s][0][lane], s_pf[s][1][lane]), fmaxf(s_pf[s][2][lane], s_pf[s][3][lane])))),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FKF_STAMP(22);
     };
 
     // ================================================================ hand-off 1 of stream s: row maxima of the head -> s_gm[s]
@@ -298,6 +308,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         if (w == 0 && !wait_first_granules(pm, 32, nblk, token, lane, sp)) s_abort = 1;
         __syncthreads();
         if (s_abort) return false;
+        FKF_STAMP(23);
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
             float v = -INFINITY;
@@ -321,6 +332,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             __syncthreads();
             if (s_abort) return false;
         }
+        FKF_STAMP(24);
         if (threadIdx.x < 32) {
             float v = s_rf[0][threadIdx.x];
 #pragma unroll
@@ -339,32 +351,34 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
         for (int i = 0; i < 16; ++i) gm[i] = s_gm[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
         uint32_t ahi[16], alo[16], nanbits = 0;
+        bool gm_ok = true;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; }
+        for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; gm_ok = gm_ok && __builtin_fabsf(gm[i]) < INFINITY; }
+        const bool gm_finite = __all(gm_ok);                         // wave-uniform: +-inf or NaN row maxima send every tile the general way
 #pragma unroll
         for (int lt = 0; lt < PS; ++lt) {
             constexpr int t0 = s * PS;
             const int t = t0 + lt;
             const int key0 = tile_wt(t) * TK;                        // >= S when the wave has no tile t: nothing is counted
-            if (key0 + TK <= S) {
-                // full tile: every column counts and x <= max, so no column masks and no clamp; a NaN poisons the row anyway,
-                // whatever its conversion adds to the sums
+            if (key0 + TK <= S && !((tile_nan >> t) & 1u) && gm_finite) {
+                // Full tile of finite logits under finite row maxima (the only tiles a well-formed prompt has): every column
+                // counts, x <= max and d = x - max is never NaN, so the range test of det_expf is a clamp and no NaN
+                // bookkeeping is needed (det_expf2_clamped: bit-identical sums and probabilities).  Everything else -- a NaN
+                // among the tile's results, a row whose maximum is +-inf (d = inf - inf), ragged tiles -- takes the general
+                // path below, which selects and tracks NaNs per element.
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
                     const int rB = NB == 2 ? i : (i + 8) & 15;
                     const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-                    const f32x2 e = det_expf2<true>(x - (f32x2){gm[i], gm[rB]});
+                    const f32x2 e = det_expf2_clamped(x - (f32x2){gm[i], gm[rB]});
                     ev[t][0][i] = e.x;
                     ev[t][1][i] = e.y;
                     uint32_t h0, l0, h1, l1;
                     exp_to_fix2(e, h0, l0, h1, l1);
                     if (NB == 2) {
-                        if (__builtin_isunordered(e.x, e.y)) nanbits |= 1u << i;
                         ahi[i] += h0 + h1;
                         alo[i] += l0 + l1;
                     } else {
-                        if (e.x != e.x) nanbits |= 1u << i;
-                        if (e.y != e.y) nanbits |= 1u << rB;
                         ahi[i] += h0; alo[i] += l0;
                         ahi[rB] += h1; alo[rB] += l1;
                     }
@@ -390,6 +404,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 }
             }
         }
+        FKF_STAMP(25);
         // per lane at most 2*PS <= 8 elements per row (hi <= 2^16, lo <= 2^24 each): the 32-bit lane sums are exact; they
         // are combined to the 2^-40 fixed-point value before the half-wave reduction
         {
@@ -406,6 +421,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 s_pb[s][w][m] = (nanbits >> i) & 1u;
             }
         }
+        FKF_STAMP(26);
         __syncthreads();
         if (w == 0) {
             const int row = lane >> 1;
@@ -423,6 +439,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         if (w == 0 && !wait_first_granules(psu, 64, nblk, token, lane, sp)) s_abort = 1;
         __syncthreads();
         if (s_abort) return false;
+        FKF_STAMP(27);
         const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
         for (;;) {
             uint64_t s2 = 0;
@@ -451,6 +468,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             __syncthreads();
             if (s_abort) return false;
         }
+        FKF_STAMP(28);
         if (threadIdx.x < 32) {
             uint64_t sm = 0;
             uint32_t bad = 0;
@@ -484,6 +502,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         float ri[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) ri[i] = s_ri[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
+        FKF_STAMP(29);
         if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
         for (int lt = 0; lt < PS; ++lt) {
@@ -499,7 +518,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 for (int u = 0; u < 4; ++u) {
                     const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
                     const f32x2 pr = (f32x2){ev[t][0][wd], ev[t][1][wd]} * (f32x2){ri[wd], ri[rB]};
-                    p[u] = (f32x2){h2f(f2h(pr.x)), h2f(f2h(pr.y))};
+                    const uint32_t ph = f2h2(pr.x, pr.y);                                 // utils.py:103 -> fp16
+                    p[u] = (f32x2){h2f((uint16_t)(ph & 0xffffu)), h2f((uint16_t)(ph >> 16))};
                 }
                 f32x2 a = splat2(0.0f);
                 a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
@@ -516,6 +536,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 }
             }
         }
+        FKF_STAMP(30);
         __syncthreads();
         // halo: pooling reaches `pad` positions into the neighbouring workgroups of the head.  Every workgroup publishes its
         // first and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the flag)
@@ -596,6 +617,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             }
             if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
         }
+        FKF_STAMP(31);
         if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
         if (want_hist && last_vh) {
             __syncthreads();

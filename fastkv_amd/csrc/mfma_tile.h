@@ -172,14 +172,15 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
 // mfma_phase_mx is exact for finite K only: a NaN among a tile's results (non-finite K or Q) sends the wave back over the
 // tile with the vector-ALU conversion (synchronous staging through the wave's slab: rare), whose results are the fmaf chain
 // on any input.  `Ap` = the wave's A-operand pointer for phase 0 (As + lane).
+// Returns whether the tile's results held a NaN (wave-uniform): such a tile keeps the general softmax path later on.
 template <int NPH, int NB = 2>
-__device__ __forceinline__ void redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, const uint16_t *__restrict__ kb, int64_t ks_s, int key0,
+__device__ __forceinline__ bool redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, const uint16_t *__restrict__ kb, int64_t ks_s, int key0,
                                                  int S, int lane, unsigned char *my, const float *Ap, int n31, int sh)
 {
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) bad = bad || (NB == 2 ? __builtin_isunordered(acc0[i], acc1[i]) : acc0[i] != acc0[i]);   // one compare per pair
-    if (!__any(bad)) return;
+    if (!__any(bad)) return false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 #pragma unroll 1
@@ -197,6 +198,7 @@ __device__ __forceinline__ void redo_tile_if_nan(f32x16 &acc0, f32x16 &acc1, con
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    return true;
 }
 
 }  // namespace fk

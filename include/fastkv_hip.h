@@ -279,7 +279,7 @@ int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void
 /*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),
- * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b)) so tests can compare the GPU bit-for-bit with the CPU oracle.
+ * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b), 9-11 packed twins of 0 / 3 / 8, 12 packed fp16 round trip) so tests can compare the GPU bit-for-bit with the CPU oracle.
  */
 int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream);
 /* Test hook: `wgs` 256-thread workgroups that each hold `lds_bytes` of LDS for `usec` microseconds -- "another kernel is

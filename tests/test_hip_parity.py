@@ -256,6 +256,17 @@ def test_arithmetic_contract_on_gpu(dev):
     # fp32 -> fp16 -> fp32 incl. the subnormal range; plain mul / add
     z = torch.cat([torch.rand(100000, generator=gen) * 2e-4, torch.rand(100000, generator=gen) * 70000])
     assert torch.equal(bits(run(2, z)[0]), bits(z.half().float()))
+    # the packed conversion (v_cvt_pk_f16_f32): same bits as the scalar one on random values and on EVERY fp16 rounding
+    # boundary (the midpoint of two neighbouring fp16 values, one fp32 ulp below it and one above it), both signs, overflow
+    assert torch.equal(bits(run(12, z)[0]), bits(z.half().float()))
+    h = torch.arange(0, 0x7C00, dtype=torch.int32).to(torch.int16).view(torch.float16).float()      # all finite non-negative fp16
+    mid = (h[:-1] + h[1:]) / 2                                                                        # exact in fp32
+    mb = mid.view(torch.int32)
+    pts = torch.cat([mid, (mb - 1).view(torch.float32), (mb + 1).view(torch.float32), h, torch.tensor([65519.0, 65520.0, 65536.0, 1e30])])
+    pts = torch.cat([pts, -pts])
+    if pts.numel() % 2:
+        pts = torch.cat([pts, pts[:1]])
+    assert torch.equal(bits(run(12, pts)[0]), bits(pts.half().float())) and torch.equal(bits(run(2, pts)[0]), bits(pts.half().float()))
     a, b = torch.rand(100000, generator=gen) * 1e-3, torch.rand(100000, generator=gen)
     assert torch.equal(bits(run(6, a, b)[0]), bits(a * b)) and torch.equal(bits(run(7, a, b)[0]), bits(a + b))
     # fixed-point softmax sum: conversion both ways
