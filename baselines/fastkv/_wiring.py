@@ -58,7 +58,8 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
             init_fastkv(self)                                     # utils.py:137-138
             self.tsp_idx = None
 
-        def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, fastkv_sp=None,
+                    **kwargs):
             input_shape = hidden_states.shape[:-1]
             hidden_shape = (*input_shape, -1, self.head_dim)
             q_len = input_shape[1]
@@ -70,6 +71,9 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                 ops.decode_rope_(query_states, key_states, cos, sin)      # in place on the fresh projections, one launch
             else:
                 query_states, key_states = modeling.apply_rotary_pos_emb(query_states, key_states, cos, sin)
+
+            if fastkv_sp is not None and q_len > 1:
+                return self._forward_sequence_parallel(query_states, key_states, value_states, past_key_values, fastkv_sp, input_shape)
 
             if past_key_values is not None:
                 if q_len > 1:                                     # prefill: compress what goes into the cache
@@ -106,17 +110,44 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
             attn_output = attn_output.reshape(*input_shape, -1).contiguous()
             return self.o_proj(attn_output), attn_weights
 
+        def _forward_sequence_parallel(self, query_states, key_states, value_states, past_key_values, sp, input_shape):
+            """Prefill of ONE prompt whose sequence is split over ranks (fastkv_amd/sp_model.py): this rank's queries / keys /
+            values are positions [pos0, pos0 + S_r).  Same two things as the single-device branch -- the cache gets
+            update_kv's rows (llama_model.py:139-142), attention runs causally over the full current K/V (:181-183) -- with
+            the sequence-sharded operator and an all-gather of the K/V shards."""
+            from fastkv_amd import sp_model
+            from fastkv_amd.dist import sp_update_kv
+            cl = self.kv_cluster
+            self.tsp_idx = None
+            if past_key_values is not None:
+                early, cap, tsp = sp_model.plan_for(cl, sp.total)
+                if early:                                         # utils.py:89-91: nothing is dropped, the shard's rows are cached
+                    k_c, v_c = key_states, value_states
+                else:
+                    dt = key_states.dtype
+                    k16, q16, v16 = (t if t.dtype == torch.float16 else t.half() for t in (key_states, query_states, value_states))
+                    k_c, v_c, self.tsp_idx, _ = sp_update_kv(k16, q16, v16, window_size=cl.window_size, kernel_size=cl.kernel_size,
+                                                             pooling=cl.pooling, capacity=cap, tsp_len=tsp,
+                                                             order=getattr(cl, "kv_order", None) or getattr(cl, "order", "score"),
+                                                             group=sp.group, local_ops=sp.local_ops,
+                                                             shard_lengths=sp.shard_lengths, replicate=sp.replicate)
+                    k_c, v_c = k_c.to(dt), v_c.to(dt)
+                past_key_values.update(k_c, v_c, self.layer_idx)
+            k_cat, v_cat = sp_model.gather_kv(key_states, value_states, sp)
+            attn_output = sp_model.sp_attention(query_states, k_cat, v_cat, self.scaling)
+            return self.o_proj(attn_output.reshape(*input_shape, -1).contiguous()), None
+
     return FastKVAttention
 
 
 def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None,
-                                use_cache=False, position_embeddings=None, **kwargs):
+                                use_cache=False, position_embeddings=None, fastkv_sp=None, **kwargs):
     static = _static_step(past_key_values, hidden_states)
     residual = hidden_states
     hidden_states = _norm(self.input_layernorm, hidden_states, static)
     hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                       past_key_values=past_key_values, use_cache=use_cache,
-                                      position_embeddings=position_embeddings, **kwargs)
+                                      position_embeddings=position_embeddings, fastkv_sp=fastkv_sp, **kwargs)
     hidden_states = residual + hidden_states
     residual = hidden_states
     hidden_states = _norm(self.post_attention_layernorm, hidden_states, static)
@@ -124,7 +155,14 @@ def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, positi
     hidden_states = residual + hidden_states
     # [FastKV] token-selective propagation: keep only the selected tokens from this layer on
     tsp_idx = getattr(self.self_attn, "tsp_idx", None)
-    if self.self_attn.kv_cluster.tsp_layer and tsp_idx is not None:
+    if self.self_attn.kv_cluster.tsp_layer and tsp_idx is not None and fastkv_sp is not None:
+        # sequence-parallel prompt: tsp_idx holds GLOBAL positions (= the position ids of a prompt that starts at 0); every rank
+        # contributes the surviving rows it owns, from here on all ranks hold the reduced sequence (fastkv_amd/sp_model.py)
+        from fastkv_amd import sp_model
+        self.new_position_ids = tsp_idx
+        hidden_states = sp_model.tsp_assemble(hidden_states, tsp_idx, fastkv_sp)
+        fastkv_sp.reduced = True
+    elif self.self_attn.kv_cluster.tsp_layer and tsp_idx is not None:
         self.new_position_ids = torch.gather(position_ids, dim=1, index=tsp_idx)
         if hidden_states.is_cuda:
             hidden_states = ops.gather_rows(hidden_states.contiguous(), tsp_idx)          # HIP row gather
@@ -145,6 +183,10 @@ def make_model_forward(modeling, mask_fn_for):
             inputs_embeds = self.embed_tokens(input_ids)
         if use_cache and past_key_values is None:
             past_key_values = make_cache(self.config)
+        sp = getattr(self, "_fastkv_sp", None)                    # sequence-parallel prefill (fastkv_amd/sp_model.py)
+        if sp is not None and position_ids is None:
+            position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + sp.pos0).unsqueeze(0)
+            position_ids = position_ids.expand(inputs_embeds.shape[0], -1)
         if position_ids is None:
             if getattr(past_key_values, "static_decode", False):
                 raise ValueError("static decode (graph-capturable) needs position_ids as a device tensor: a host-side position "
@@ -152,7 +194,9 @@ def make_model_forward(modeling, mask_fn_for):
             past_seen = past_key_values.get_seq_length() if past_key_values is not None else 0
             position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + past_seen).unsqueeze(0)
             position_ids = position_ids.expand(inputs_embeds.shape[0], -1)
-        if getattr(past_key_values, "static_decode", False) and inputs_embeds.shape[1] == 1:
+        if sp is not None:
+            causal_mask = None                                    # the sharded attention builds its own (lower-right causal) mask
+        elif getattr(past_key_values, "static_decode", False) and inputs_embeds.shape[1] == 1:
             causal_mask = None                                    # one new token attends to the whole cache: nothing to mask
         else:
             causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
@@ -162,7 +206,7 @@ def make_model_forward(modeling, mask_fn_for):
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:
             hidden_states = decoder_layer(hidden_states, attention_mask=causal_mask, position_embeddings=position_embeddings,
                                           position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,
-                                          **kwargs)
+                                          fastkv_sp=sp if (sp is not None and not sp.reduced) else None, **kwargs)
             new_position_ids = getattr(decoder_layer, "new_position_ids", None)
             if new_position_ids is not None:                      # after the TSP layer: fewer tokens, new rotary tables
                 position_ids = new_position_ids
@@ -176,6 +220,17 @@ def make_model_forward(modeling, mask_fn_for):
                                                        past_key_values=None, position_ids=None)
         hidden_states = _norm(self.norm, hidden_states, _static_step(past_key_values, hidden_states))
         hidden_states = hidden_states[:, -1:, :]                  # only the last token feeds lm_head
+        if sp is not None and not sp.reduced:
+            # no TSP reduction happened (short prompt / no TSP layer): the prompt's last token lives on the last rank
+            import torch.distributed as dist
+            src = sp.world - 1 if sp.group is None else dist.get_global_rank(sp.group, sp.world - 1)
+            hidden_states = hidden_states.contiguous()
+            if hidden_states.is_cuda and dist.get_backend(sp.group) == "gloo":
+                h = hidden_states.cpu()
+                dist.broadcast(h, src=src, group=sp.group)
+                hidden_states = h.to(hidden_states.device)
+            else:
+                dist.broadcast(hidden_states, src=src, group=sp.group)
         return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
 
     return model_forward_fastkv

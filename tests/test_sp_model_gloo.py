@@ -1,0 +1,125 @@
+"""Sequence-parallel prefill of the whole (tiny, CPU) model over 2-3 gloo ranks against the single-process model
+(fastkv_amd/sp_model.py).  The cluster is the oracle-backed stand-in (the product has no CPU path); what is
+under test is the sharded wiring: K/V all-gather + lower-right causal attention, the sequence-sharded operator inside the
+attention module, the TSP re-shard (every rank contributes the surviving rows it owns), the replicated layers behind it, and
+the last-token broadcast when no TSP reduction happens.
+
+Tolerance: the sharded attention sums in another order than the single-process SDPA call (fp32 model: ~1e-6); the selection
+itself is exact arithmetic on fp16 inputs, so index sets agree unless a last-bit difference of the fp32 projections crosses
+an fp16 rounding boundary AND a selection threshold -- the prompts below do not."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q_out):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from baselines.monkeypatch import replace_llama, set_model
+        from benchmark import prefill
+        from fastkv_amd.sp_model import SPContext, sp_prefill
+        from oracle import fastkv_oracle as O
+        from sp_oracle_ops import OracleLocalOps
+        from test_wiring import _args, _oracle_cluster
+        O.set_threads(2)
+        lens, S = case["lens"], sum(case["lens"])
+
+        def build():
+            a = _args(method="fastkv", max_capacity_prompts=case["cap"], tsp_len=case["tsp_len"], tsp_idx=case["tsp_idx"],
+                      pooling=case["pooling"])
+            a.context_lengths = [S]
+            replace_llama("fastkv")
+            torch.manual_seed(31)
+            m = prefill.build_model(a, "cpu")
+            set_model(m, a)
+            for layer in m.model.layers:
+                layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+            return m
+
+        ids = torch.randint(0, 1000, (1, S), generator=torch.Generator().manual_seed(33))
+        ref_model = build()
+        with torch.no_grad():
+            ref = ref_model(ids, attention_mask=torch.ones_like(ids))
+        ref_tsp = [l.self_attn.tsp_idx for l in ref_model.model.layers]
+        model = build()
+        lo, hi = sum(lens[:rank]), sum(lens[:rank + 1])
+        ctx = SPContext(shard_lengths=lens, local_ops=OracleLocalOps(), replicate=True)
+        with torch.no_grad():
+            out = sp_prefill(model, ids[:, lo:hi], ctx)
+        msg = []
+        if not torch.allclose(out.logits, ref.logits, atol=2e-4, rtol=1e-4):
+            msg.append(f"logits differ by {float((out.logits - ref.logits).abs().max()):.3e}")
+        for i, layer in enumerate(model.model.layers):
+            t, rt = layer.self_attn.tsp_idx, ref_tsp[i]
+            if (t is None) != (rt is None) or (t is not None and not torch.equal(t, rt)):
+                msg.append(f"tsp_idx of layer {i} differs")
+            kc, rk = out.past_key_values.layers[i].keys, ref.past_key_values.layers[i].keys
+            vc, rv = out.past_key_values.layers[i].values, ref.past_key_values.layers[i].values
+            if case.get("early_out"):
+                rk, rv = rk[:, :, lo:hi], rv[:, :, lo:hi]           # nothing dropped, nothing re-sharded: every rank caches its shard's rows
+            if kc.shape != rk.shape:
+                msg.append(f"cache of layer {i}: shape {tuple(kc.shape)} vs {tuple(rk.shape)}")
+            elif i <= case["tsp_idx"] or case.get("early_out"):
+                # sharded layers: the operator saw bit-identical fp16 inputs in both runs (token-local ops only before it)
+                if not torch.allclose(kc, rk, atol=2e-4) or not torch.allclose(vc, rv, atol=2e-4):
+                    msg.append(f"cache of layer {i} differs")
+            else:
+                # layers behind the re-shard run on hidden states that differ in the last fp32 bits (another summation order in
+                # the sharded attention): a score within that noise of its neighbour may swap two rows or flip one index.  The
+                # caches must hold the same rows up to such swaps: >= 90 % of the rows of every head have a partner.
+                for h in range(kc.shape[1]):
+                    d = torch.cdist(kc[0, h], rk[0, h])
+                    frac = float((d.min(dim=1).values < 1e-3).float().mean())
+                    if frac < 0.9:
+                        msg.append(f"cache of layer {i} head {h}: only {frac:.2f} of the rows have a partner")
+        q_out.put((rank, True if not msg else "; ".join(msg)))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q_out.put((rank, "EXC " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    # layer 0 sharded, layer 1 = TSP layer (sharded, re-shard behind it), layers 2-3 replicated on every rank
+    dict(lens=[100, 120, 80], cap=64, tsp_len=96, tsp_idx=1, pooling="avgpool"),
+    # TSP at layer 0, maxpool, two ragged shards
+    dict(lens=[210, 90], cap=48, tsp_len=80, tsp_idx=0, pooling="maxpool"),
+    # budgets above the prompt: early-out in every layer, no TSP reduction -> the last rank's last token is broadcast
+    dict(lens=[64, 64], cap=512, tsp_len=2048, tsp_idx=1, pooling="avgpool", early_out=True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_sequence_parallel_prefill_matches_single_process_model(case):
+    world = len(case["lens"])
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] is True for r in res), res
