@@ -215,7 +215,7 @@ def whole_model_ttft(work):
 
 
 # ------------------------------------------------------------------------------------------------- multi-GPU legs
-LEGS = ("seq_sharded_weak", "seq_sharded_128k", "tp")
+LEGS = ("seq_sharded_weak", "seq_sharded_128k", "tp", "sp_ttft_128k")
 N_LEG_LAYERS = CFG["tsp_idx"] + 1          # the 16 layers that see the whole prompt; the last one is the TSP layer
 
 
@@ -233,6 +233,8 @@ def run_leg(name, steps, rank, world, dev, dist):
     gen = torch.Generator(device=dev)
     gen.manual_seed(2000 + rank)
     W, ks, pooling, cap, tsp = CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], CFG["tsp_len"]
+    if name == "sp_ttft_128k":
+        return run_sp_ttft(steps, rank, world, dev, dist)
     if name.startswith("seq_sharded"):
         S_r = CFG["S"] if name == "seq_sharded_weak" else 131072 // world
         S_glob = S_r * world
@@ -280,6 +282,50 @@ def run_leg(name, steps, rank, world, dev, dist):
     info.update({"layers": N_LEG_LAYERS, "steps": steps, "ms_per_step": round(ms, 3), "tokens_per_s": round(S_glob / (ms * 1e-3), 1),
                  "collectives_per_step_measured": (c1 - c0) // 2, "backend": dist.get_backend()})
     return info
+
+
+def run_sp_ttft(steps, rank, world, dev, dist):
+    """BASELINE.json configs[2] as a WHOLE-MODEL number: TTFT of ONE 131,072-token prompt, random-init Llama-3-8B geometry,
+    sequence-parallel prefill over `world` ranks (fastkv_amd/sp_model.py: K/V all-gather + lower-right causal attention,
+    sequence-sharded update_kv, TSP re-shard at layer 15, replicated layers behind it).  1 warm-up + 2 timed runs."""
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import prefill
+    from fastkv_amd.sp_model import SPContext, sp_prefill
+    S = 131072
+    if S % world:
+        return {"skipped": f"131072 tokens do not split over {world} ranks"}
+    a = prefill.parse_args(["--model_path", "llama3-8b", "--method", "fastkv", "--max_capacity_prompts", str(CFG["budget"]),
+                            "--tsp_len", str(CFG["tsp_len"]), "--tsp_idx", str(CFG["tsp_idx"]), "--pooling", CFG["pooling"],
+                            "--device", "cuda", "--save_txt", ""])
+    a.save_txt = False
+    a.context_lengths = [S]
+    replace_llama("fastkv")
+    torch.manual_seed(4242)                                       # the same random weights on every rank
+    with torch.cuda.device(dev):
+        model = prefill.build_model(a, dev)
+    set_model(model, a)
+    lens = [S // world] * world
+    ids = torch.ones(1, lens[rank], dtype=torch.int64, device=dev)       # the reference's all-ones prompt (prefill.py:55)
+    times = []
+    for it in range(3):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = sp_prefill(model, ids, SPContext(shard_lengths=lens))
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if it:
+            times.append(float(tt.item()))
+        del out
+    ms = sum(times) / len(times) * 1e3
+    return {"prompt_tokens": S, "tokens_per_rank": lens[0], "model": "random-init Llama-3-8B geometry, fp16, 32 layers", "ttft_ms": round(ms, 2),
+            "tokens_per_s": round(S / (ms * 1e-3), 1), "scaling": "strong", "runs": len(times), "backend": dist.get_backend(),
+            "max_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+            "note": "whole-model TTFT (not the hot path alone): attention by K/V all-gather, 5 collectives per layer up to the TSP layer, none behind it"}
 
 
 def leg_child_main(a):
@@ -477,7 +523,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         for i, name in enumerate(LEGS):
-            res = spawn_leg(name, i, max(3, a.steps // 4), rank)
+            res = spawn_leg(name, i, max(3, a.steps // 4), rank, timeout_s=600 if name.startswith("sp_ttft") else 240)
             if rank == 0:
                 out[name] = res
     if rank == 0:
