@@ -125,6 +125,36 @@ def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, ke
     return tuple(out)
 
 
+def update_kv_per_query_head(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, kernel_size: int, pooling: str,
+                             capacity: int, order: str = "score", return_indices: bool = False):
+    """The selection rule of the SnapKV baseline (/root/reference/baselines/snapkv/utils.py:57-102): the same window scoring,
+    pooling and top-k as `update_kv`, but per QUERY head (no sum over the heads of a KV group, utils.py:112 of fastkv) and
+    without TSP; the cache then holds H rows sets: K/V [B,H,capacity,D].
+
+    q [B,H,S,D]; k, v either [B,H,S,D] (already repeated, as the SnapKV attention module does before the call:
+    snapkv/llama_model.py:161-170) or [B,Hkv,S,D]: the H/Hkv query heads of a group then read the group's K/V rows through a
+    zero head stride -- no `repeat_kv` copy is made (the reference materialises it: 4x the K/V bytes at G = 4).
+    No kernel of its own: each batch row is the ordinary operator on the problem (batch = KV head, kv heads = query heads of
+    the group, G = 1)."""
+    _check_qkv(q, k, v)
+    B, H, S, D = q.shape
+    Hkv = k.shape[1]
+    assert H % Hkv == 0 and k.shape == v.shape and k.shape[0] == B and k.shape[2] == S and k.shape[3] == D
+    G = H // Hkv
+    ko = torch.empty(B, H, capacity, D, dtype=torch.float16, device=q.device)
+    vo = torch.empty_like(ko)
+    idx = torch.empty(B, H, capacity - window, dtype=torch.int64, device=q.device) if return_indices else None
+    for b in range(B):
+        qb = q[b].as_strided((Hkv, G, S, D), (G * q.stride(1), q.stride(1), q.stride(2), 1), q[b].storage_offset())
+        kb = k[b].as_strided((Hkv, G, S, D), (k.stride(1), 0, k.stride(2), 1), k[b].storage_offset())
+        vb = v[b].as_strided((Hkv, G, S, D), (v.stride(1), 0, v.stride(2), 1), v[b].storage_offset())
+        out = update_kv(qb, kb, vb, window, kernel_size, pooling, capacity, 0, order, return_indices=return_indices,
+                        out=(ko[b].view(Hkv, G, capacity, D), vo[b].view(Hkv, G, capacity, D)))
+        if return_indices:
+            idx[b] = out[3].view(H, capacity - window)
+    return (ko, vo, idx) if return_indices else (ko, vo)
+
+
 def scores(q: torch.Tensor, k: torch.Tensor, window: int, kernel_size: int, pooling: str, want_tsp: bool = True):
     """attn_cache c[B,Hkv,n] (utils.py:112) and optionally the TSP row t[B,n] (utils.py:127)."""
     _check_qkv(q, k)

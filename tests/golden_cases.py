@@ -55,3 +55,9 @@ for _s in range(12):
                                               cap=2048, tsp_len=2048)
     SWEEP_CASES[f"sweep_recipe_{_s:02d}"] = dict(seed=200 + _s, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="avgpool",
                                                  cap=3276, tsp_len=6553)
+
+# Per-query-head selection (the SnapKV baseline's rule, tests/golden/make_snapkv.py)
+SNAPKV_CASES = {
+    "snap_avg": dict(seed=31, B=1, H=8, Hkv=2, S=700, D=128, W=8, ks=5, pooling="avgpool", cap=96),
+    "snap_max_b2": dict(seed=32, B=2, H=8, Hkv=4, S=1500, D=128, W=16, ks=7, pooling="maxpool", cap=200),
+}

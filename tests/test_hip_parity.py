@@ -633,3 +633,29 @@ def test_seed_sweep_32k_on_gpu(dev):
                                          return_indices=True)
         check_against_sweep(name, idx.cpu(), tsp.cpu(), z, meta)
         assert torch.equal(ko.cpu(), expected_kv(k, idx.cpu(), case["W"]))
+
+
+def test_per_query_head_selection_snapkv_rule(dev):
+    """ops.update_kv_per_query_head: the SnapKV baseline's rule (selection per QUERY head, /root/reference/baselines/snapkv/
+    utils.py:57-102) through the ordinary operator -- with K/V already repeated to H heads (what the SnapKV attention module
+    passes) and with the un-repeated [B,Hkv,S,D] tensors read through a zero head stride (no repeat_kv copy).  Both equal the
+    oracle bit for bit and canonical_topk of the REFERENCE's scores (tests/golden/snapkv.npz)."""
+    import os
+    from fastkv_amd import ops
+    from golden_cases import SNAPKV_CASES
+    from helpers import GOLDEN
+    from oracle import fastkv_oracle as O
+    z = np.load(os.path.join(GOLDEN, "snapkv.npz"))
+    for name, c in SNAPKV_CASES.items():
+        q, k, v = make_qkv(c["seed"], c["B"], c["H"], c["Hkv"], c["S"], c["D"], c["W"])
+        G = c["H"] // c["Hkv"]
+        kr, vr = (t.repeat_interleave(G, dim=1) for t in (k, v))
+        qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+        krd, vrd = (_to_dev(t, dev) for t in (kr, vr))
+        for order in ("index", "score"):
+            want = O.update_kv(q, kr, vr, c["W"], c["ks"], c["pooling"], c["cap"], 0, order)
+            for kk_, vv_ in ((kd, vd), (krd, vrd)):
+                ko, vo, idx = ops.update_kv_per_query_head(qd, kk_, vv_, c["W"], c["ks"], c["pooling"], c["cap"], order, return_indices=True)
+                assert torch.equal(idx.cpu(), want[2]) and torch.equal(ko.cpu(), want[0]) and torch.equal(vo.cpu(), want[1]), (name, order)
+            if order == "index":
+                assert torch.equal(idx.cpu(), torch.from_numpy(z[name + ".idx"].astype(np.int64))), name
