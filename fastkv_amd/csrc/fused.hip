@@ -125,6 +125,28 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     float *As = reinterpret_cast<float *>(smem + SLAB_BYTES);  // [NS][AS_FLOATS]
     const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
 
+    // tile t of the wave (0 .. PER-1): stream t / PS, tile wt(t) of that stream's row of tiles (contiguous keys per workgroup)
+    auto tile_wt = [&](int t) { return wave_id * PS + (t % PS); };
+    auto tile_valid = [&](int t) { return t < PER && tile_wt(t) < nwt; };
+    auto tile_key0 = [&](int t) { const int wt = tile_wt(t); return (wt < nwt ? wt : 0) * TK; };
+
+    // ---------------------------------------------------------------- A operands (see score_logits_mfma_kernel)
+    constexpr int QV = 32 * (D / 8) / 256;
+    uint4 qv[NS][QV];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int u = 0; u < QV; ++u) {
+            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const int i = rowl / W, r = rowl - i * W;
+            qv[s][u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)((g_s[s] * VH + vh_s[s]) * G + i) * qs_h +
+                                                       (int64_t)(n + r) * qs_s + ch * 8);
+        }
+    KStage sA, sB;
+    k_fetch<NB>(sA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // (the control block is read only now: its round trip hides behind the query / first-tile loads issued above instead of
+    // standing in front of them)
     // control block (fastkv_workspace_init): a missing initialisation must not turn into a silent wrong answer.  The token
     // of this launch is the epoch left by the previous one + 1 (the compaction kernel bumps it): never a launch argument,
     // which a graph replay would freeze; the granules in memory still carry earlier tokens (or whatever the allocation held).
@@ -152,26 +174,6 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         for (int i = lo + (int)threadIdx.x; i < hi2; i += 256) zero_area[first + i] = 0;
     }
 
-    // tile t of the wave (0 .. PER-1): stream t / PS, tile wt(t) of that stream's row of tiles (contiguous keys per workgroup)
-    auto tile_wt = [&](int t) { return wave_id * PS + (t % PS); };
-    auto tile_valid = [&](int t) { return t < PER && tile_wt(t) < nwt; };
-    auto tile_key0 = [&](int t) { const int wt = tile_wt(t); return (wt < nwt ? wt : 0) * TK; };
-
-    // ---------------------------------------------------------------- A operands (see score_logits_mfma_kernel)
-    constexpr int QV = 32 * (D / 8) / 256;
-    uint4 qv[NS][QV];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int u = 0; u < QV; ++u) {
-            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
-            const int i = rowl / W, r = rowl - i * W;
-            qv[s][u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)((g_s[s] * VH + vh_s[s]) * G + i) * qs_h +
-                                                       (int64_t)(n + r) * qs_s + ch * 8);
-        }
-    KStage sA, sB;
-    k_fetch<NB>(sA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
