@@ -270,7 +270,7 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     if (p->tsp_len) {
         e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
                           reinterpret_cast<const uint32_t *>(ws + L.off_thist), arrive + (size_t)p->B * p->Hkv,
-                          seltab + (size_t)p->B * p->Hkv * nchunks * 32, st, ctrl);
+                          seltab + (size_t)p->B * p->Hkv * nchunks * 64, st, ctrl);       // 32 granules = 64 words per chunk
         if (e != hipSuccess) return fail();
     }
     // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction

@@ -64,7 +64,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_thist = o;  o += (size_t)p.B * HIST12 * 4;                            // ... and of the TSP rows (adjacent: zeroed together)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
-    L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 128, 256);   // ... and one 128-B line per chunk
+    L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 256, 256);   // ... and 32 8-byte granules per chunk
     L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum / halo granules
     // fused score with more than 4 query heads per KV head: per-position head-sum granules between virtual heads
     L.off_fchain = o; o += (p.H / p.Hkv > 4) ? align_up((size_t)512 * 1024 * 8, 256) : 0;          // [unit span][positions]: 512 Ki granules at most

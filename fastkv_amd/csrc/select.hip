@@ -274,11 +274,12 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint16_t
 // threshold prefix by itself.  What a workgroup cannot know alone -- the low nibble of the k-th value and how many
 // winners precede its chunk -- goes through a small table in the workspace:
 //   phase 1  count the chunk's keys above the threshold prefix and the nibble histogram of those carrying it; publish the
-//            17 counters (one 128-B line per chunk), release, bump the row's arrival counter
-//   phase 2  wait until all chunks of the row have arrived (all workgroups of the launch are co-resident: the host
-//            takes this path only for <= SPL_MAX_WGS workgroups), sum the tables -> k-th value, quota of ties, and the
-//            number of winners before this chunk; ordered compaction of the chunk straight to the output lists.
-// The arrival counters are zeroed by row_stats together with the histograms.
+//            17 counters as 8-byte {token, value} granules (one write-through store each: the data is the flag -- no drain,
+//            no arrival counter; round 1 drained the stores and bumped a counter: two more memory round trips)
+//   phase 2  sweep the granules of all chunks of the row until every tag is this call's token (all workgroups of the
+//            launch are co-resident: the host takes this path only for <= SPL_MAX_WGS workgroups; the wait is bounded,
+//            fk_device.h SpinCtl), sum the tables -> k-th value, quota of ties, and the number of winners before this
+//            chunk; ordered compaction of the chunk straight to the output lists.
 constexpr int SPL_THREADS = 256, SPL_CHUNK = SPL_THREADS * 8, SPL_LINE = 32, SPL_MAX_WGS = 1024;
 
 struct SplShared {
@@ -292,8 +293,8 @@ struct SplShared {
 __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_t *__restrict__ scores, int64_t row_stride, int n, int k,
                                                                    int append, int64_t *__restrict__ idx_out, int64_t idx_row_stride,
                                                                    uint16_t *__restrict__ key_out, int64_t key_row_stride,
-                                                                   const uint32_t *__restrict__ hist12, uint32_t *__restrict__ arrive,
-                                                                   uint32_t *__restrict__ table, uint32_t *__restrict__ ctrl,
+                                                                   const uint32_t *__restrict__ hist12,
+                                                                   uint64_t *__restrict__ table, uint32_t *__restrict__ ctrl,
                                                                    uint32_t *__restrict__ host_flag, uint64_t spin_ticks)
 {
     __shared__ SplShared sh;
@@ -307,7 +308,8 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
     const uint16_t *row = scores + (size_t)rowi * row_stride;
     int64_t *out = idx_out + (size_t)rowi * idx_row_stride;
     uint16_t *kout = key_out ? key_out + (size_t)rowi * key_row_stride : nullptr;
-    uint32_t *tab = table + ((size_t)rowi * nchunks) * SPL_LINE;
+    uint64_t *tab = table + ((size_t)rowi * nchunks) * SPL_LINE;
+    const uint32_t token = handoff_token(ctrl[2]);
 
     // this thread's 8 keys (rows of the fused operator are 16-B aligned with a padded stride: the vector that straddles n
     // is readable; a vector wholly past n re-reads the row's last one and is ignored)
@@ -367,27 +369,26 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
         if (lane == 0 && cg) atomicAdd(&sh.cg12, cg);
     }
     __syncthreads();
-    if (w == 0) {
-        if (lane < 17)
-            __hip_atomic_store(&tab[chunk * SPL_LINE + lane], lane < 16 ? sh.h4[lane] : sh.cg12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the counters were stored write-through (sc1) and are drained here; every later load of them is an sc1 load: no
-        // release / acquire fences (each would write back or invalidate a whole L2) -- relaxed arrive, relaxed polls
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            __hip_atomic_fetch_add(&arrive[rowi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(&arrive[rowi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)nchunks) {
-                __builtin_amdgcn_s_sleep(4);
-                if (spin_failed(sp)) { s_abort = 1; break; }          // chunks of this row never arrived: give up, loudly (host flag)
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
-    if (s_abort) return;
+    if (w == 0 && lane < 17)
+        __hip_atomic_store(&tab[chunk * SPL_LINE + lane], ((uint64_t)token << 32) | (lane < 16 ? sh.h4[lane] : sh.cg12), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     // ---------------- phase 2: totals over the row and over the chunks before this one
-    for (int i = tid; i < nchunks * 17; i += SPL_THREADS) {
+    const int ng = nchunks * 17;
+    for (;;) {                                                           // until every chunk's granules carry this call's token
+        bool ok = true;
+        for (int i = tid; i < ng; i += SPL_THREADS) {
+            const int cc = i / 17, f = i - cc * 17;
+            ok = ok && (uint32_t)(__hip_atomic_load(&tab[cc * SPL_LINE + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token;
+        }
+        if (__syncthreads_and(ok)) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (tid == 0 && spin_failed(sp)) s_abort = 1;                    // chunks of this row never arrived: give up, loudly (host flag)
+        __syncthreads();
+        if (s_abort) return;
+    }
+    for (int i = tid; i < ng; i += SPL_THREADS) {
         const int cc = i / 17, f = i - cc * 17;
-        const uint32_t v = __hip_atomic_load(&tab[cc * SPL_LINE + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t v = (uint32_t)__hip_atomic_load(&tab[cc * SPL_LINE + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v) {
             atomicAdd(&sh.tot[f], v);
             if (cc < chunk) atomicAdd(&sh.pre[f], v);
@@ -469,11 +470,12 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
     uint32_t *host_flag = ctrl ? abort_flag_device() : nullptr;
     const int64_t nchunks = (n + SPL_CHUNK - 1) / SPL_CHUNK;
     const bool vec = ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && (row_stride % 8 == 0) && (row_stride >= ((n + 7) & ~(int64_t)7));
-    if (hist12 && arrive && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec) {
+    (void)arrive;                                                        // (round 1's arrival counters: the granules carry the signal now)
+    if (hist12 && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec) {
         ProfScope ps_(K_SELECT_SPLIT, st);
         hipLaunchKernelGGL(select_split_kernel, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
-                           (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12, arrive, table, ctrl,
-                           host_flag, spin_limit_ticks());
+                           (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12,
+                           reinterpret_cast<uint64_t *>(table), ctrl, host_flag, spin_limit_ticks());
         return hipGetLastError();
     }
     const int64_t kal = (k + 7) & ~(int64_t)7;
