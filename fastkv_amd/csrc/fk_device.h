@@ -22,6 +22,14 @@ __device__ __forceinline__ uint16_t f2h(float f)
     asm("" : "+v"(f));
     return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
+// A FINAL score (the c and t rows the selection ranks): every NaN becomes the canonical quiet NaN 0x7e00.  Sign and payload of a
+// generated NaN differ between this GPU and the oracle's x86 (positive vs the negative "default NaN") and mono16 orders NaNs
+// by their bits; 0x7e00 ranks above +inf, where torch.topk puts a NaN (utils.py:109, :115).  oracle/fastkv_oracle.c: f2h_score.
+__device__ __forceinline__ uint16_t f2h_score(float f)
+{
+    const uint16_t h = f2h(f);
+    return (h & 0x7fffu) > 0x7c00u ? (uint16_t)0x7e00u : h;
+}
 __device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 

@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
                 if (!last_vh) __hip_atomic_store(chain_out + lp, granule(token, f32_bits(gsum)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const uint16_t c16 = f2h(gsum);
+            const uint16_t c16 = f2h_score(gsum);
             if (is_out && last_vh) {
                 c_out[(size_t)bg * c_row_stride + j] = c16;
                 if (all_idx) {                                   // capacity == S: identity selection + keys (see score_finalize)

@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) score_finalize_kernel(const uint16_t *__r
             }
         }
     }
-    const uint16_t c16 = f2h(gsum);
+    const uint16_t c16 = f2h_score(gsum);
     if (is_out) c_out[(size_t)(b * Hkv + g) * c_row_stride + (j - cw.own_lo)] = c16;
     if (all_idx) {
         // k == n (post-TSP layers in constant mode): every candidate is selected, so the "selection" is the
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256) tsp_rowsum_kernel(const uint16_t *__restr
     float a = 0.0f;
     const int jc = j < n ? j : n - 1;
     for (int g = 0; g < Hkv; ++g) a = a + h2f(c[(size_t)(b * Hkv + g) * c_row_stride + jc]);
-    const uint16_t t16 = f2h(a);
+    const uint16_t t16 = f2h_score(a);
     if (j < n) t_out[(size_t)b * t_row_stride + j] = t16;
     if (thist) {
         hist12_add(s_hist, mono16(t16) >> 4, j < n, threadIdx.x & 63);

@@ -49,6 +49,11 @@
 
 static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
 static inline uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+/* Final scores (the c and t rows the selection ranks): every NaN becomes the canonical quiet NaN 0x7e00.  The sign and payload
+   of a GENERATED NaN (inf - inf, 0 * inf) are not portable -- x86 produces the negative "default NaN", the GPU a positive one --
+   and the ranking key orders NaNs by their bits.  With 0x7e00 a NaN ranks above +inf, which is where torch.topk puts it
+   (utils.py:109, :115). */
+static inline uint16_t f2h_score(float f) { uint16_t h = f2h(f); return (h & 0x7fffu) > 0x7c00u ? (uint16_t)0x7e00u : h; }
 
 static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -267,7 +272,7 @@ int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_
             for (int j = lo; j < hi; j++) {
                 float a = 0.0f;
                 for (int i = 0; i < G; i++) a = a + h2f(pooled[((int64_t)b * H + g * G + i) * n + j]);
-                c_out[(int64_t)bg * n + j] = f2h(a);
+                c_out[(int64_t)bg * n + j] = f2h_score(a);
             }
         }
     if (t_out) {
@@ -278,7 +283,7 @@ int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_
                 for (int j = lo; j < hi; j++) {
                     float a = 0.0f;
                     for (int g = 0; g < Hkv; g++) a = a + h2f(c_out[((int64_t)b * Hkv + g) * n + j]);
-                    t_out[(int64_t)b * n + j] = f2h(a);
+                    t_out[(int64_t)b * n + j] = f2h_score(a);
                 }
             }
     }
@@ -526,7 +531,7 @@ int fastkv_oracle_sp_scores(const uint16_t *logits, int B, int H, int Hkv, int W
         for (int j = 0; j < n_own; j++) {
             float a = 0.0f;
             for (int i = 0; i < G; i++) a = a + h2f(pooled[((int64_t)b * H + g * G + i) * n_own + j]);
-            c_out[(int64_t)bg * n_own + j] = f2h(a);
+            c_out[(int64_t)bg * n_own + j] = f2h_score(a);
         }
     }
     if (t_out)
@@ -534,7 +539,7 @@ int fastkv_oracle_sp_scores(const uint16_t *logits, int B, int H, int Hkv, int W
             for (int j = 0; j < n_own; j++) {
                 float a = 0.0f;
                 for (int g = 0; g < Hkv; g++) a = a + h2f(c_out[((int64_t)b * Hkv + g) * n_own + j]);
-                t_out[(int64_t)b * n_own + j] = f2h(a);
+                t_out[(int64_t)b * n_own + j] = f2h_score(a);
             }
     free(rinv); free(srow); free(pooled);
     return FK_OK;

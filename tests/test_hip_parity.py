@@ -433,11 +433,29 @@ def test_fused_path_on_special_values(dev):
         ops.set_score_engine("auto")
     torch.cuda.synchronize()
 
-    def canon(x):                                   # NaN payloads / signs are not specified: same NaN positions, same other bits
-        return torch.where(torch.isnan(x), torch.full_like(x, float("nan")).view(torch.int16), x.view(torch.int16))
+    def bits(x):
+        return x.view(torch.int16)
 
-    assert torch.equal(canon(c_f), canon(c_v)) and torch.equal(canon(t_f), canon(t_v))
+    assert torch.equal(bits(c_f), bits(c_v)) and torch.equal(bits(t_f), bits(t_v))
     assert torch.isnan(c_f[0, 0]).any() and not torch.isnan(c_f[0, 1]).any()
+    # ... and against the ORACLE, selection included.  A generated NaN has no portable sign (x86: negative default NaN, this
+    # GPU: positive), so both sides store every NaN score as 0x7e00 (f2h_score): it then ranks first on both, as in torch.topk.
+    nan_bits = bits(c_f)[torch.isnan(c_f)]
+    assert bool((nan_bits == 0x7e00).all()) and bool((bits(t_f)[torch.isnan(t_f)] == 0x7e00).all())
+    q2 = q.clone()
+    q2[0, 5, S - 3, 17] = float("inf")               # a window row with +inf: inf - inf in the softmax of that row
+    q2d = _to_dev(q2, dev)
+    for qq, qqd, pooling, order in ((q, qd, "maxpool", "score"), (q2, q2d, "avgpool", "index"), (q2, q2d, "maxpool", "score")):
+        want = O.update_kv(qq, k2, v, W, 7, pooling, 300, 600, order, return_scores=True)
+        for engine in ("auto", "valu"):
+            try:
+                ops.set_score_engine(engine)
+                got = ops.update_kv(qqd, k2d, vd, W, 7, pooling, 300, 600, order, return_indices=True, return_scores=True)
+            finally:
+                ops.set_score_engine("auto")
+            assert torch.equal(bits(got[4].cpu()), bits(want[4])), (pooling, order, engine)
+            assert torch.equal(got[3].cpu(), want[2]) and torch.equal(got[2].cpu(), want[3]), (pooling, order, engine)
+            assert torch.equal(bits(got[0].cpu()), bits(want[0])) and torch.equal(bits(got[1].cpu()), bits(want[1]))
 
 
 def test_keep_all_in_index_order_is_a_copy(dev):

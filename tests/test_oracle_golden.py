@@ -107,6 +107,29 @@ def test_canonical_topk_tie_rule():
     assert O.canonical_topk(z, 7, "index").tolist() == list(range(7))       # fully degenerate row
 
 
+def test_nan_scores_are_canonical_and_rank_first():
+    """A NaN or Inf in K (inf - inf in the softmax) turns the whole softmax row, hence every score of that KV head and of the
+    TSP row, into NaN.  torch.topk -- the reference's selection, utils.py:109/:115 -- treats NaN as the largest value; the
+    oracle stores every NaN score as 0x7e00 (sign and payload of a GENERATED NaN differ between x86 and the GPU) and its
+    ranking key puts that above +inf, so an all-NaN row selects the lowest positions and a NaN outranks every finite score."""
+    W, S = 8, 600
+    q, k, v = make_qkv(99, 1, 8, 2, S, 64, W)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        k2 = k.clone()
+        k2[0, 0, 100, 3] = bad
+        for pooling in ("avgpool", "maxpool"):
+            _, _, idx, tsp, c, t = O.update_kv(q, k2, v, W, 7, pooling, 64, 128, "score", return_scores=True)
+            if bad != float("-inf"):                                            # -inf: exp(-inf) = 0, nothing becomes NaN
+                assert bool(torch.isnan(c[0, 0]).all()) and bool(torch.isnan(t[0]).all())
+                assert bool((c[0, 0].view(torch.int16) == 0x7e00).all()) and bool((t[0].view(torch.int16) == 0x7e00).all())
+                assert idx[0, 0, :64 - W].tolist() == list(range(64 - W))       # all tied: lowest positions
+                assert tsp[0].tolist() == list(range(128 - W)) + list(range(S - W, S))
+            assert not bool(torch.isnan(c[0, 1]).any())                         # the other KV head is untouched
+    row = torch.tensor([1.0, float("nan"), float("inf"), 3.0, float("nan")], dtype=torch.float16)
+    assert O.canonical_topk(row, 3, "score").tolist() == [1, 4, 2]              # NaN, NaN (ascending position), +inf
+    assert O.canonical_topk(row, 3, "index").tolist() == torch.topk(row.float(), 3).indices.sort().values.tolist() == [1, 2, 4]
+
+
 def test_arithmetic_contract_scalars():
     L = O.lib()
     import math

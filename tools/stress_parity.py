@@ -1,0 +1,59 @@
+"""One-off stress run (not part of the test suite): N random geometries of the operator on the GPU against the CPU oracle,
+bit for bit -- scores, indices, K/V rows, TSP index -- biased towards the fused path's shapes (W = 8, G in {4, 8}), long and
+ragged prompts, both row orders, peaked inputs, special values sprinkled in.  usage: python tools/stress_parity.py [N] [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+from fastkv_amd import ops
+from gen_inputs import make_qkv
+from oracle import fastkv_oracle as O
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+dev = torch.device("cuda:0")
+t0 = time.time()
+fails = 0
+for it in range(N):
+    fusedish = rng.random() < 0.7
+    W = 8 if fusedish else rng.choice([1, 4, 8, 16])
+    G = rng.choice([4, 4, 8]) if fusedish else rng.choice([1, 2, 3, 4, 8])
+    Hkv = rng.choice([1, 2, 4, 8])
+    D = rng.choice([64, 128, 128, 128, 256])
+    B = rng.choice([1, 1, 1, 2])
+    ks = rng.choice([1, 3, 5, 7, 7, 13])
+    S = rng.choice([rng.randint(W + 2 + ks, 3000), rng.randint(3000, 20000), rng.choice([2048, 4096, 8192, 16384, 32768])])
+    if B * Hkv * S * D > 40e6:
+        B, Hkv = 1, min(Hkv, 4)
+    cap = rng.choice([rng.randint(W + 1, S), min(S, rng.choice([256, 512, 2048])), S]) if S > W + 2 else S
+    cap = max(W + 1, min(cap, S))
+    tsp_len = rng.choice([0, rng.randint(W + 1, S - 1)]) if S - 1 > W + 1 else 0
+    pooling = rng.choice(["avgpool", "maxpool"])
+    order = rng.choice(["index", "score"])
+    peaked = rng.choice([0, 0, 50])
+    q, k, v = make_qkv(9000 + it, B, Hkv * G, Hkv, S, D, W, peaked=peaked)
+    special = rng.random() < 0.1
+    if special:                                              # special values: inf / nan / huge in a few K rows and one Q row
+        k = k.clone(); q = q.clone()
+        for _ in range(3):
+            k[rng.randrange(B), rng.randrange(Hkv), rng.randrange(S), rng.randrange(D)] = rng.choice([float("inf"), float("-inf"), float("nan"), 60000.0, -60000.0])
+        if rng.random() < 0.5:
+            q[0, rng.randrange(Hkv * G), S - 1 - rng.randrange(W), rng.randrange(D)] = rng.choice([float("inf"), float("nan"), 30000.0])
+    tag = dict(it=it, B=B, H=Hkv * G, Hkv=Hkv, S=S, D=D, W=W, ks=ks, cap=cap, tsp_len=tsp_len, pooling=pooling, order=order, peaked=peaked, special=special)
+    want = O.update_kv(q, k, v, W, ks, pooling, cap, tsp_len, order, return_scores=True)
+    qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
+    got = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
+    torch.cuda.synchronize()
+    ok = torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)) and torch.equal(got[3].cpu(), want[2]) and \
+        torch.equal(got[0].cpu().view(torch.int16), want[0].view(torch.int16)) and torch.equal(got[1].cpu().view(torch.int16), want[1].view(torch.int16)) and \
+        ((got[2] is None and want[3] is None) or torch.equal(got[2].cpu(), want[3]))
+    if not ok:
+        fails += 1
+        what = dict(scores=torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), idx=torch.equal(got[3].cpu(), want[2]),
+                    k=torch.equal(got[0].cpu().view(torch.int16), want[0].view(torch.int16)), v=torch.equal(got[1].cpu().view(torch.int16), want[1].view(torch.int16)),
+                    tsp=(got[2] is None and want[3] is None) or torch.equal(got[2].cpu(), want[3]))
+        nd = int((got[4].cpu().view(torch.int16) != want[4].view(torch.int16)).sum())
+        print("MISMATCH", tag, what, "score elements differing", nd, "nan in oracle scores", int(torch.isnan(want[4]).sum()), flush=True)
+print(f"{N} cases, {fails} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if fails else 0)
