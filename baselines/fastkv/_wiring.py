@@ -41,6 +41,58 @@ def _mlp(module, hidden_states, static):
     return module(hidden_states)
 
 
+def _gemv_ok(*linears) -> bool:
+    return all(isinstance(m, torch.nn.Linear) and m.bias is None and m.weight.dtype == torch.float16 and m.weight.is_contiguous()
+               and m.in_features % 512 == 0 and m.in_features * 2 <= 65536 for m in linears)
+
+
+def _static_layer_ok(layer, hidden_states, position_embeddings, past_key_values) -> bool:
+    """Whole-layer fast path of a one-token step (see `_static_layer`): stock Llama / Mistral module shapes, fp16, no biases,
+    batch 1 or 2 (the input rows of the widest projection live in LDS), the layer's cache a slab in static-decode mode."""
+    if os.environ.get("FASTKV_DECODE_GEMV", "1") == "0" or hidden_states.shape[0] not in (1, 2):
+        return False
+    attn, mlp = layer.self_attn, layer.mlp
+    layers = getattr(past_key_values, "layers", None)
+    slab = layers[attn.layer_idx] if layers is not None and attn.layer_idx < len(layers) else None
+    if not (isinstance(slab, SlabLayer) and slab.static_decode) or position_embeddings[0].dtype != torch.float16:
+        return False
+    if not all(hasattr(m, "variance_epsilon") and m.weight.dtype == torch.float16
+               for m in (layer.input_layernorm, layer.post_attention_layernorm)):
+        return False
+    if getattr(getattr(mlp, "config", None), "hidden_act", None) != "silu" or not hasattr(mlp, "gate_proj"):
+        return False
+    if mlp.down_proj.in_features * 2 * hidden_states.shape[0] > 65536:
+        return False
+    return _gemv_ok(attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj)
+
+
+def _static_layer(layer, x, position_embeddings, past_key_values):
+    """One decoder layer of a one-token step over the slab cache in 9 launches (the stock modules: ~17 + 7 hipBLASLt GEMVs):
+    [RMSNorm + q/k/v projections] -> RoPE -> append -> attention (2) -> [o_proj + residual] -> [RMSNorm + gate/up + SiLU*up]
+    -> [down_proj + residual]; the bracketed ones are `ops.decode_gemv` (csrc/gemv.hip).  Same data flow as
+    /root/reference/baselines/fastkv/llama_model.py:100-190 (q_len == 1 branch) + the stock MLP."""
+    attn, mlp = layer.self_attn, layer.mlp
+    slab = past_key_values.layers[attn.layer_idx]
+    B = x.shape[0]
+    D = attn.head_dim
+    nq, nk = attn.q_proj.out_features, attn.k_proj.out_features
+    ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
+    qkv = ops.decode_gemv(x, [attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight], norm_weight=ln1.weight, eps=ln1.variance_epsilon)
+    q = qkv[..., :nq].view(B, 1, nq // D, D).transpose(1, 2)
+    k = qkv[..., nq:nq + nk].view(B, 1, nk // D, D).transpose(1, 2)
+    v = qkv[..., nq + nk:].view(B, 1, nk // D, D).transpose(1, 2)
+    cos, sin = position_embeddings
+    ops.decode_rope_(q, k, cos, sin)
+    ops.decode_append(slab.kslab, slab.vslab, k, v, slab.len_dev)
+    a = ops.decode_attention(q, slab.kslab, slab.vslab, slab.len_dev, attn.scaling)
+    slab.host_step()
+    attn.tsp_idx = None
+    h1 = ops.decode_gemv(a, [attn.o_proj.weight], residual=x)
+    m = ops.decode_gemv(h1, [mlp.gate_proj.weight, mlp.up_proj.weight], norm_weight=ln2.weight, eps=ln2.variance_epsilon, glu=True)
+    layer.new_position_ids = None
+    return ops.decode_gemv(m, [mlp.down_proj.weight], residual=h1)
+
+
 def make_cache(config):
     """DynamicCache as in the reference, or (FASTKV_SLAB_CACHE=1) pre-sized per-layer slabs that the compaction writes
     into directly and decode steps append to in place (fastkv_amd/cache.py)."""
@@ -143,6 +195,8 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
 def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None,
                                 use_cache=False, position_embeddings=None, fastkv_sp=None, **kwargs):
     static = _static_step(past_key_values, hidden_states)
+    if static and fastkv_sp is None and _static_layer_ok(self, hidden_states, position_embeddings, past_key_values):
+        return _static_layer(self, hidden_states, position_embeddings, past_key_values)
     residual = hidden_states
     hidden_states = _norm(self.input_layernorm, hidden_states, static)
     hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,

@@ -45,17 +45,30 @@ def graph_decode(model, pkv, tok, steps, timed):
         out_tok.index_copy_(0, step_no, nxt[0])
         step_no.add_(1)
 
-    total, _ = timed(step)                                        # eager: step 1
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):                    # records step 2 (nothing runs during the capture)
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    for _ in range(steps - 1):
-        dt, _ = timed(g.replay)
-        total += dt
+    # the vocabulary projection of the step (1 GB of weights for Llama-3) through the weight-streaming GEMV as well
+    from baselines.fastkv._wiring import _gemv_ok
+    from fastkv_amd import ops
+    lm = getattr(model, "lm_head", None)
+    patched = lm is not None and os.environ.get("FASTKV_DECODE_GEMV", "1") != "0" and _gemv_ok(lm) and tok.shape[0] in (1, 2, 4)
+    if patched:
+        stock = lm.forward
+        lm.forward = lambda h: ops.decode_gemv(h, [lm.weight]) if (h.is_cuda and h.dim() == 3 and h.shape[1] == 1
+                                                                   and h.dtype == torch.float16) else stock(h)
+    try:
+        total, _ = timed(step)                                    # eager: step 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):                # records step 2 (nothing runs during the capture)
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(steps - 1):
+            dt, _ = timed(g.replay)
+            total += dt
+    finally:
+        if patched:
+            del lm.forward                                        # back to the class's forward
     pkv.finish_static_decode()                                    # host mirrors <- device lengths
     return total, [int(x) for x in out_tok.tolist()]
 

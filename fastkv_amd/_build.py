@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfastkv_hip.so")
-SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "sp.hip", "decode.hip", "capi.hip", "debug.hip", "prof.hip"]
+SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "sp.hip", "decode.hip", "gemv.hip", "capi.hip", "debug.hip", "prof.hip"]
 HEADERS = ["fk_device.h", "fk_host.h", "prof.h", "rank.h", "mfma_tile.h", os.path.join("..", "..", "include", "fastkv_hip.h")]
 # -ffp-contract=off: the arithmetic contract (csrc/fk_device.h) spells every fma out; nothing may be fused or split
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-result"]

@@ -313,3 +313,31 @@ def decode_silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(gate)
     check(load().fastkv_decode_silu_mul_f16(gate.data_ptr(), up.data_ptr(), gate.numel(), out.data_ptr(), _stream()), "decode_silu_mul")
     return out
+
+
+def decode_gemv(x: torch.Tensor, weights, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0, glu: bool = False,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The projections of a one-token step in ONE launch (csrc/gemv.hip): x [B,1,K] fp16 times up to three `nn.Linear` weights
+    [N_i,K] that share it -> [B,1,sum N_i]; `norm_weight`: RMSNorm of x first; `glu`: silu(W0 x) * (W1 x); `residual`
+    [B,1,N]: added to the result.  Rounding points of the stock fp16 modules."""
+    _require_cuda(x, *weights)
+    B, one, K = x.shape
+    assert one == 1 and x.dtype == torch.float16 and x.stride(2) == 1 and 1 <= len(weights) <= 3
+    for w in weights:
+        assert w.dtype == torch.float16 and w.is_contiguous() and w.shape[1] == K
+    rows = [int(w.shape[0]) for w in weights]
+    n_out = rows[0] if glu else sum(rows)
+    out = torch.empty(B, 1, n_out, dtype=torch.float16, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == torch.float16 and residual.stride(2) == 1
+    if norm_weight is not None:
+        assert norm_weight.dtype == torch.float16 and norm_weight.is_contiguous() and norm_weight.numel() == K
+    n = len(weights)
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in weights])
+    rp = (ctypes.c_int32 * n)(*rows)
+    rc = load().fastkv_decode_gemv_f16(B, K, x.data_ptr(), x.stride(0), norm_weight.data_ptr() if norm_weight is not None else None,
+                                       ctypes.c_float(eps), n, wp, rp, 1 if glu else 0,
+                                       residual.data_ptr() if residual is not None else None,
+                                       residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), _stream())
+    check(rc, "decode_gemv")
+    return out

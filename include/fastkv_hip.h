@@ -276,6 +276,19 @@ int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q
                            const int64_t k_strides[2], const void *cosv, const void *sinv, int64_t cs_batch_stride, void *stream);
 int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void *out, void *stream);
 
+/* Weight-streaming GEMV of the decode step (csrc/gemv.hip): out[b, :] = W x[b, :] for ONE input row per batch element
+ * (B = 1, 2 or 4; K % 512 == 0, B*K*2 <= 64 KiB), fp16 in / fp32 accumulate / fp16 out.  Replaces the q/k/v/o and MLP
+ * `nn.Linear` calls of the attention module and MLP during a one-token step
+ * (/root/reference/baselines/fastkv/llama_model.py:118-120, :186; the stock LlamaMLP) -- one launch each for
+ *   n_mats <= 3 matrices sharing the input, `rows[i]` rows of K contiguous fp16 each, outputs concatenated;
+ *   norm_weight != NULL: the input is RMS-normalised first (LlamaRMSNorm arithmetic, `eps`);
+ *   glu != 0 (n_mats == 2, rows[0] == rows[1]): out = fp16(fp16(silu(W0 x)) * fp16(W1 x)), rows[0] columns;
+ *   residual != NULL: out = fp16(fp16(W x) + residual).
+ * Row strides in elements.  Agrees with the stock modules to fp16 tolerance (another accumulation order), not bit for bit. */
+int fastkv_decode_gemv_f16(int32_t B, int32_t K, const void *x, int64_t x_row_stride, const void *norm_weight, float eps,
+                           int32_t n_mats, const void *const *weights, const int32_t *rows, int32_t glu, const void *residual,
+                           int64_t res_row_stride, void *out, int64_t out_row_stride, void *stream);
+
 /*
  * Test hook (not part of the operator): evaluates primitive `op` of the arithmetic contract element-wise
  * (0 det_exp(a), 1 a/b, 2 fp16 round trip, 3 fixed-point round trip (+raw in out64), 4 fma(a,b,out),

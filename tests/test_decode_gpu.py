@@ -162,3 +162,51 @@ def test_single_launch_step_operators_match_the_stock_modules():
     assert float((got.float() - want.float()).abs().max()) <= 2e-3 * float(want.abs().max())
     assert float((got != want).float().mean()) < 0.02
     torch.set_grad_enabled(True)
+
+
+@pytest.mark.parametrize("B,K,rows,norm,glu,res", [
+    (1, 4096, [4096, 1024, 1024], True, False, False),     # RMSNorm + q/k/v of Llama-3-8B
+    (1, 4096, [4096], False, False, True),                 # o_proj + residual
+    (1, 4096, [14336, 14336], True, True, False),          # RMSNorm + gate/up + SiLU*up
+    (1, 14336, [4096], False, False, True),                # down_proj + residual (28 segments: the one-segment tail loop runs)
+    (2, 1536, [1000, 24], True, False, True),              # ragged row counts, three segments, batch 2
+    (4, 1024, [77], False, False, False),                  # batch 4
+    (1, 4096, [128256], False, False, False),              # lm_head
+    (2, 512, [6, 6], False, True, False),                  # a single segment, fewer columns than one wave handles
+])
+def test_decode_gemv_matches_stock_modules(B, K, rows, norm, glu, res):
+    """ops.decode_gemv against the stock fp16 modules it stands in for (nn.Linear / LlamaRMSNorm / silu * up / residual add),
+    evaluated by PyTorch on the GPU.  Same rounding points, another accumulation order: the fp32 accumulators differ by
+    ~1e-3 relative at K = 4096, so outputs agree to a few fp16 ulps of the row's scale -- and exactly with an fp64
+    evaluation of the same rounding sequence to half that."""
+    from transformers.models.llama import modeling_llama as ML
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(K + B)
+    x = torch.randn(B, 1, K, generator=g, device=dev, dtype=torch.float16) * 2
+    ws = [(torch.randn(n, K, generator=g, device=dev, dtype=torch.float16) * K ** -0.5).contiguous() for n in rows]
+    nw = (torch.randn(K, generator=g, device=dev, dtype=torch.float16) * 0.5 + 1).contiguous() if norm else None
+    n_out = rows[0] if glu else sum(rows)
+    r = torch.randn(B, 1, n_out, generator=g, device=dev, dtype=torch.float16) if res else None
+    with torch.no_grad():
+        xin = x
+        if norm:
+            m = ML.LlamaRMSNorm(K, eps=1e-5).to(dev).half()
+            m.weight.data = nw
+            xin = m(x)
+        ys = [torch.nn.functional.linear(xin, w) for w in ws]
+        want = torch.nn.functional.silu(ys[0]) * ys[1] if glu else torch.cat(ys, dim=-1)
+        if res:
+            want = r + want
+        # the same rounding sequence with exact (fp64) dot products
+        y64 = [(xin.double() @ w.double().t()).half() for w in ws]
+        want64 = (torch.nn.functional.silu(y64[0].float()).half().float() * y64[1].float()).half() if glu else torch.cat(y64, dim=-1)
+        if res:
+            want64 = (r.float() + want64.float()).half()
+    got = ops.decode_gemv(x, ws, norm_weight=nw, eps=1e-5, glu=glu, residual=r)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    scale = float(want64.float().abs().max())
+    assert float((got.float() - want64.float()).abs().max()) <= 2e-3 * scale + 1e-3
+    assert float((got.float() - want.float()).abs().max()) <= 4e-3 * scale + 1e-3
+    assert float((got != want64).float().mean()) < 0.05
