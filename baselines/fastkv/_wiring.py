@@ -67,9 +67,9 @@ def _static_layer_ok(layer, hidden_states, position_embeddings, past_key_values)
 
 
 def _static_layer(layer, x, position_embeddings, past_key_values):
-    """One decoder layer of a one-token step over the slab cache in 9 launches (the stock modules: ~17 + 7 hipBLASLt GEMVs):
-    [RMSNorm + q/k/v projections] -> RoPE -> append -> attention (2) -> [o_proj + residual] -> [RMSNorm + gate/up + SiLU*up]
-    -> [down_proj + residual]; the bracketed ones are `ops.decode_gemv` (csrc/gemv.hip).  Same data flow as
+    """One decoder layer of a one-token step over the slab cache in 5 launches (the stock modules: ~17 + 7 hipBLASLt GEMVs):
+    [RMSNorm + q/k/v projections] -> [RoPE + append + attention + merge] -> [o_proj + residual] -> [RMSNorm + gate/up +
+    SiLU*up] -> [down_proj + residual]: `ops.decode_gemv` (csrc/gemv.hip) and `ops.decode_step_attention` (csrc/decode.hip).  Same data flow as
     /root/reference/baselines/fastkv/llama_model.py:100-190 (q_len == 1 branch) + the stock MLP."""
     attn, mlp = layer.self_attn, layer.mlp
     slab = past_key_values.layers[attn.layer_idx]
@@ -82,9 +82,7 @@ def _static_layer(layer, x, position_embeddings, past_key_values):
     k = qkv[..., nq:nq + nk].view(B, 1, nk // D, D).transpose(1, 2)
     v = qkv[..., nq + nk:].view(B, 1, nk // D, D).transpose(1, 2)
     cos, sin = position_embeddings
-    ops.decode_rope_(q, k, cos, sin)
-    ops.decode_append(slab.kslab, slab.vslab, k, v, slab.len_dev)
-    a = ops.decode_attention(q, slab.kslab, slab.vslab, slab.len_dev, attn.scaling)
+    a = ops.decode_step_attention(q, k, v, cos, sin, slab.kslab, slab.vslab, slab.len_dev, attn.scaling)
     slab.host_step()
     attn.tsp_idx = None
     h1 = ops.decode_gemv(a, [attn.o_proj.weight], residual=x)

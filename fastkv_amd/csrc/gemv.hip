@@ -53,6 +53,36 @@ __global__ void __launch_bounds__(256) decode_gemv_kernel(GemvArgs a)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_x[];          // [BB][K]
     __shared__ float s_part[BB][4];
     const int K = a.K, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int OR = NR;                                                   // rows handled per wave and iteration
+    const int glu = a.glu;
+    const int nout = glu ? a.n0 : a.n0 + a.n1 + a.n2;                        // output columns
+    const int orows = glu ? NR / 2 : NR;                                     // output columns per wave and iteration
+    const uint16_t *wr[OR];
+    auto set_rows = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < OR; ++i) {
+            int r = r0 + (glu ? (i >> 1) : i);                               // glu: rows 2j / 2j+1 = gate / up of column r0 + j
+            r = r < nout ? r : nout - 1;
+            const uint16_t *base;
+            if (glu) base = (i & 1) ? a.w1 : a.w0;
+            else if (r < a.n0) base = a.w0;
+            else if (r < a.n0 + a.n1) { base = a.w1; r -= a.n0; }
+            else { base = a.w2; r -= a.n0 + a.n1; }
+            wr[i] = base + (int64_t)r * K + lane * 8;
+        }
+    };
+    // The weights do not depend on the input: the first U segments of the wave's first rows are requested BEFORE the input row
+    // is staged (and normalised), so the launch pays one memory round trip, not two.
+    const int r_first = (blockIdx.x * 4 + w) * orows;
+    const bool pre = r_first < nout && K >= 512 * U;
+    gv_u4 wv[OR][U];
+    if (pre) {
+        set_rows(r_first);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < OR; ++i) wv[i][u] = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(wr[i] + u * 512));
+    }
     // ---- the input row(s) -> LDS, normalised on the way if asked
     if (a.nw) {
         float ss[BB];
@@ -99,23 +129,7 @@ __global__ void __launch_bounds__(256) decode_gemv_kernel(GemvArgs a)
     }
     __syncthreads();
 
-    constexpr int OR = NR;                                                   // rows handled per wave and iteration
-    const int glu = a.glu;
-    const int nout = glu ? a.n0 : a.n0 + a.n1 + a.n2;                        // output columns
-    const int orows = glu ? NR / 2 : NR;                                     // output columns per wave and iteration
-    for (int r0 = (blockIdx.x * 4 + w) * orows; r0 < nout; r0 += gridDim.x * 4 * orows) {
-        const uint16_t *wr[OR];
-#pragma unroll
-        for (int i = 0; i < OR; ++i) {
-            int r = r0 + (glu ? (i >> 1) : i);                               // glu: rows 2j / 2j+1 = gate / up of column r0 + j
-            r = r < nout ? r : nout - 1;
-            const uint16_t *base;
-            if (glu) base = (i & 1) ? a.w1 : a.w0;
-            else if (r < a.n0) base = a.w0;
-            else if (r < a.n0 + a.n1) { base = a.w1; r -= a.n0; }
-            else { base = a.w2; r -= a.n0 + a.n1; }
-            wr[i] = base + (int64_t)r * K + lane * 8;
-        }
+    for (int r0 = r_first; r0 < nout; r0 += gridDim.x * 4 * orows) {
         float acc[OR][BB];
 #pragma unroll
         for (int i = 0; i < OR; ++i)
@@ -123,12 +137,16 @@ __global__ void __launch_bounds__(256) decode_gemv_kernel(GemvArgs a)
             for (int b = 0; b < BB; ++b) acc[i][b] = 0.0f;
         // K is a multiple of 512 (host check): whole 1 KB segments only, U at a time, then the remaining ones singly
         int c = 0;
+        bool loaded = pre && r0 == r_first;                                  // the first batch is already on its way
+        if (!loaded) set_rows(r0);
         for (; c + 512 * U <= K; c += 512 * U) {
-            gv_u4 wv[OR][U];
+            if (!loaded) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int i = 0; i < OR; ++i) wv[i][u] = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(wr[i] + c + u * 512));
+                    for (int i = 0; i < OR; ++i) wv[i][u] = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(wr[i] + c + u * 512));
+            }
+            loaded = false;
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -139,14 +157,14 @@ __global__ void __launch_bounds__(256) decode_gemv_kernel(GemvArgs a)
                 }
         }
         for (; c < K; c += 512) {
-            gv_u4 wv[OR];
+            gv_u4 wt[OR];
 #pragma unroll
-            for (int i = 0; i < OR; ++i) wv[i] = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(wr[i] + c));
+            for (int i = 0; i < OR; ++i) wt[i] = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(wr[i] + c));
 #pragma unroll
             for (int b = 0; b < BB; ++b) {
                 const gv_u4 xv = *reinterpret_cast<const gv_u4 *>(s_x + b * K + c + lane * 8);
 #pragma unroll
-                for (int i = 0; i < OR; ++i) acc[i][b] = gv_dot8(wv[i], xv, acc[i][b]);
+                for (int i = 0; i < OR; ++i) acc[i][b] = gv_dot8(wt[i], xv, acc[i][b]);
             }
         }
 #pragma unroll

@@ -341,3 +341,34 @@ def decode_gemv(x: torch.Tensor, weights, norm_weight: Optional[torch.Tensor] = 
                                        residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), _stream())
     check(rc, "decode_gemv")
     return out
+
+
+_step_counters = {}
+
+
+def decode_step_attention(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                          kslab: torch.Tensor, vslab: torch.Tensor, len_dev: torch.Tensor, scaling: float, nsplit: int = 0) -> torch.Tensor:
+    """RoPE + append + GQA attention + slice merge of a one-token step in ONE launch: q [B,H,1,D] / k_new, v_new [B,Hkv,1,D] are
+    the RAW projections, cos / sin [B,1,D] fp16; returns fp16 [B,1,H*D], the slab gains the row, len_dev is advanced."""
+    _require_cuda(q, k_new, v_new, cos, sin, kslab, vslab, len_dev)
+    B, H, one, D = q.shape
+    Hkv, rows = kslab.shape[1], kslab.shape[2]
+    assert one == 1 and q.stride(3) == 1 and k_new.shape == (B, Hkv, 1, D) and v_new.shape == k_new.shape and k_new.stride(3) == 1 \
+        and v_new.stride(3) == 1 and cos.shape == (B, 1, D) and cos.stride(2) == 1 and sin.stride() == cos.stride() \
+        and cos.dtype == torch.float16 and q.dtype == torch.float16 and kslab.stride() == vslab.stride() and len_dev.dtype == torch.int32
+    nsplit = nsplit or DECODE_NSPLIT
+    L = load()
+    out = torch.empty(B, 1, H * D, dtype=torch.float16, device=q.device)
+    ws = _workspace(L.fastkv_decode_workspace_bytes(B, H, D, nsplit), q.device, "decode")
+    key = (q.device.index, _stream())
+    cnt = _step_counters.get(key)
+    if cnt is None:
+        cnt = _step_counters[key] = torch.zeros(1024, dtype=torch.int32, device=q.device)
+    I2, I3 = ctypes.c_int64 * 2, ctypes.c_int64 * 3
+    rc = L.fastkv_decode_step_attention_f16(B, H, Hkv, D, q.data_ptr(), I2(q.stride(0), q.stride(1)), k_new.data_ptr(),
+                                            I2(k_new.stride(0), k_new.stride(1)), v_new.data_ptr(), I2(v_new.stride(0), v_new.stride(1)),
+                                            cos.data_ptr(), sin.data_ptr(), cos.stride(0), kslab.data_ptr(), vslab.data_ptr(),
+                                            I3(*kslab.stride()[:3]), rows, len_dev.data_ptr(), ctypes.c_float(scaling), nsplit,
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), cnt.data_ptr(), _stream())
+    check(rc, "decode_step_attention")
+    return out

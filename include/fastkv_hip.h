@@ -270,6 +270,16 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
  *   rope      apply_rotary_pos_emb on q [B,H,1,D] and k [B,Hkv,1,D] IN PLACE (strides {batch, head}); cos / sin [B,1,D]
  *   silu_mul  act_fn(gate) * up of the MLP, n elements (multiple of 8)
  */
+/* The attention part of a one-token step in ONE launch (RoPE + append + attention + merge: what
+ * fastkv_decode_rope_f16 + fastkv_decode_append_f16 + fastkv_decode_attention_f16 do in four): q / k_new / v_new are the RAW
+ * projections of the step, cos / sin [B,1,D] the rotary tables of its position; the rotated K row and the V row are written to
+ * slab row *len_dev, the output is fp16 [B,1,H*D], *len_dev is advanced.  `counters`: 1024 uint32 of device memory, zeroed
+ * ONCE by the caller; the launch leaves them zero (graph-replayable). */
+int fastkv_decode_step_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, const void *q, const int64_t q_strides[2],
+                                     const void *k_new, const int64_t kn_strides[2], const void *v_new, const int64_t vn_strides[2],
+                                     const void *cosv, const void *sinv, int64_t cs_batch_stride, void *kslab, void *vslab,
+                                     const int64_t slab_strides[3], int32_t rows, int32_t *len_dev, float scaling, int32_t nsplit,
+                                     void *out, void *workspace, size_t workspace_bytes, void *counters, void *stream);
 int fastkv_decode_rmsnorm_f16(const void *x, int64_t rows, int64_t x_row_stride, int32_t hidden, const void *weight, float eps, void *out,
                               void *stream);
 int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q, const int64_t q_strides[2], void *k,

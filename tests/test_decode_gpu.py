@@ -210,3 +210,42 @@ def test_decode_gemv_matches_stock_modules(B, K, rows, norm, glu, res):
     assert float((got.float() - want64.float()).abs().max()) <= 2e-3 * scale + 1e-3
     assert float((got.float() - want.float()).abs().max()) <= 4e-3 * scale + 1e-3
     assert float((got != want64).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,L0,rows", [
+    (1, 32, 8, 128, 2048, 2304),       # Llama-3-8B layer after a budget-2048 prefill
+    (1, 32, 8, 128, 0, 64),            # an empty cache: the step's own row is all there is
+    (2, 8, 8, 64, 63, 200),            # MHA, head_dim 64, batch 2 (the new row opens a new 64-row tile)
+    (1, 8, 1, 128, 3276, 3500),        # G = 8
+    (1, 16, 8, 256, 130, 256),         # G = 2, head_dim 256
+])
+def test_fused_step_attention_matches_the_separate_kernels_and_fp32(B, H, Hkv, D, L0, rows):
+    """ops.decode_step_attention (RoPE + append + attention + merge in one launch, arrival counters) over 4 steps, two slice
+    counts: the slab rows it writes are bit-identical to apply_rotary_pos_emb's K row / the V row, the length advances, the
+    counters are zero again, and the output matches an fp32 reference over the rotated tensors to fp16 tolerance."""
+    from transformers.models.llama import modeling_llama as ML
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B * 77 + L0)
+    kslab = torch.randn(B, Hkv, rows, D, generator=g, device=dev, dtype=torch.float16)
+    vslab = torch.randn(B, Hkv, rows, D, generator=g, device=dev, dtype=torch.float16)
+    len_dev = torch.tensor([L0], dtype=torch.int32, device=dev)
+    scaling = D ** -0.5
+    for step in range(4):
+        qkv = torch.randn(B, 1, (H + 2 * Hkv) * D, generator=g, device=dev, dtype=torch.float16)     # as the fused projection leaves it
+        q = qkv[..., :H * D].view(B, 1, H, D).transpose(1, 2)
+        k = qkv[..., H * D:(H + Hkv) * D].view(B, 1, Hkv, D).transpose(1, 2)
+        v = qkv[..., (H + Hkv) * D:].view(B, 1, Hkv, D).transpose(1, 2)
+        ang = torch.rand(B, 1, D // 2, generator=g, device=dev) * 6.28
+        cos, sin = torch.cat([ang.cos(), ang.cos()], -1).half(), torch.cat([ang.sin(), ang.sin()], -1).half()
+        wq, wk = ML.apply_rotary_pos_emb(q, k, cos, sin)
+        nsplit = (0, 5)[step % 2]
+        out = ops.decode_step_attention(q, k, v, cos, sin, kslab, vslab, len_dev, scaling, nsplit=nsplit)
+        torch.cuda.synchronize()
+        L = L0 + step + 1
+        assert int(len_dev.item()) == L
+        assert torch.equal(kslab[:, :, L - 1], wk[:, :, 0]) and torch.equal(vslab[:, :, L - 1], v[:, :, 0])
+        ref = _ref_step(wq, kslab, vslab, L, scaling)
+        tol = 2e-3 * float(ref.abs().max()) + 1e-3
+        assert float((out.float() - ref).abs().max()) <= tol, (step, float((out.float() - ref).abs().max()), tol)
+    assert int(ops._step_counters[(dev.index, ops._stream())].abs().sum()) == 0
