@@ -293,6 +293,17 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
+int fastkv_pool_f16(const void *in, int64_t rows, int64_t in_row_stride, int64_t n, int32_t kernel, int32_t pooling, void *out,
+                    int64_t out_row_stride, void *stream)
+{
+    if (!in || !out || rows < 0 || rows > 65535 || n < 0 || n >= (1ll << 31) || kernel < 1 || !(kernel & 1) || in_row_stride < n ||
+        out_row_stride < n || (pooling != FASTKV_POOL_AVG && pooling != FASTKV_POOL_MAX))
+        return FASTKV_EINVAL;
+    hipError_t e = launch_pool_rows((const uint16_t *)in, in_row_stride, rows, n, kernel, pooling, (uint16_t *)out, out_row_stride,
+                                    (hipStream_t)stream);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
 int fastkv_head_sum_f16(const void *c, int64_t B, int64_t R, int64_t n, void *t_out, void *stream)
 {
     if (!c || !t_out || B < 0 || R < 1 || n < 0 || R > (1 << 20) || n >= (1ll << 31)) return FASTKV_EINVAL;

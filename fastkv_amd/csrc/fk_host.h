@@ -94,6 +94,8 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
 hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st);
 hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st);
+hipError_t launch_pool_rows(const uint16_t *in, int64_t in_stride, int64_t rows, int64_t n, int ksize, int pooling, uint16_t *out,
+                            int64_t out_stride, hipStream_t st);
 hipError_t launch_sp_logits(const fastkv_problem &p, const void *q_win, const int64_t *qs, const void *k, const int64_t *ks,
                             uint16_t *logits, int Sp, int col_off, float *qf_scratch, hipStream_t st);
 hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, int mode, float *gmax,

@@ -520,6 +520,38 @@ __global__ void __launch_bounds__(256) tsp_rowsum_kernel(const uint16_t *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------ pool_rows
+// out[row, j] = pool(in[row, j - pad .. j + pad]) over fp16 rows, padding 0 (avg, count_include_pad as F.avg_pool1d) or -inf
+// (max): the pooling of utils.py:105-108 as a stage of its own -- the GemFilter rule pools AFTER its head sum
+// (/root/reference/baselines/gemfilter/utils.py:31-33).  fp32 taps in tap order, /kernel, -> fp16; NaN scores canonical.
+__global__ void __launch_bounds__(256) pool_rows_kernel(const uint16_t *__restrict__ in, int64_t in_stride, int n, int ksize, int pooling,
+                                                        uint16_t *__restrict__ out, int64_t out_stride)
+{
+    const int row = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int pad = ksize / 2;
+    const uint16_t *r = in + (size_t)row * in_stride;
+    const bool avg = pooling == FASTKV_POOL_AVG;
+    float pv = avg ? 0.0f : -INFINITY;
+    for (int t = j - pad; t <= j + pad; ++t) {
+        if (t < 0 || t >= n) continue;                          // avg: the padding adds 0; max: -inf never wins
+        const float x = h2f(r[t]);
+        if (avg) pv = pv + x;
+        else if (x > pv || x != x) pv = x;
+    }
+    if (avg) pv = pv / (float)ksize;
+    out[(size_t)row * out_stride + j] = f2h_score(pv);
+}
+
+hipError_t launch_pool_rows(const uint16_t *in, int64_t in_stride, int64_t rows, int64_t n, int ksize, int pooling, uint16_t *out,
+                            int64_t out_stride, hipStream_t st)
+{
+    if (rows == 0 || n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, st, in, in_stride, (int)n, ksize,
+                       pooling, out, out_stride);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 // K streaming + contraction: logits[b,h,r, col_off + j] = fp16(q_r . k_j) for the p.S keys of `k` (raw, unscaled).
 // q rows are q[b, h, q_row0 + r, :].  `qf` = fp32 scratch of the vector-ALU engine (unused by the matrix-pipe engine).

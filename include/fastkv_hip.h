@@ -191,6 +191,17 @@ typedef struct fastkv_sp_window {
  */
 int fastkv_head_sum_f16(const void *c, int64_t B, int64_t R, int64_t n, void *t_out, void *stream);
 
+/*
+ * Pooling of fp16 score rows as a stage of its own (the arithmetic of utils.py:105-108: stride 1, padding kernel/2, fp32 taps
+ * in tap order, avg divides by `kernel` whatever the padding covers): out[row, j] for `rows` rows of n elements (row strides in
+ * elements; in-place is NOT allowed).  The GemFilter rule needs it behind a head sum
+ * (/root/reference/baselines/gemfilter/utils.py:25-38 `standard_dis_index`: last-query logits -> sum over heads -> avg_pool1d ->
+ * topk = fastkv_sp_logits_f16 with window 1 -> fastkv_head_sum_f16 -> fastkv_pool_f16 -> fastkv_select_f16;
+ * fastkv_amd/variants.py).
+ */
+int fastkv_pool_f16(const void *in, int64_t rows, int64_t in_row_stride, int64_t n, int32_t kernel, int32_t pooling, void *out,
+                    int64_t out_row_stride, void *stream);
+
 /* scratch for the calls below: fp32 query block (vector-ALU engine) + B*H*window floats */
 size_t fastkv_sp_workspace_bytes(const fastkv_problem *p);
 /* raw fp16 logits of the p->S keys in `k` against the window queries q_win [B,H,window,D] (utils.py:94 matmul),

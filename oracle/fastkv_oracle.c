@@ -546,6 +546,54 @@ int fastkv_oracle_sp_scores(const uint16_t *logits, int B, int H, int Hkv, int W
 }
 
 /* exposed scalar helpers so the tests can pin the arithmetic contract element-wise */
+/* ---------------------------------------------------------------- the GemFilter rule (test infrastructure like the rest)
+ * /root/reference/baselines/gemfilter/utils.py:25-33 `standard_dis_index` up to the topk: raw inner products of ONE query row
+ * per head with every key (matmul -> fp16), optionally summed over the heads (fp32, ascending head -> fp16), optionally
+ * avg_pool1d(ksize, padding ksize/2, stride 1: fp32 taps in tap order, / ksize -> fp16).  out: [B][R][n], R = 1 or H. */
+int fastkv_oracle_last_query_scores(const uint16_t *q0, const int64_t *qs, const uint16_t *k, const int64_t *ks, int B, int H, int Hd,
+                                    int n, int D, int sum_over_heads, int pool, int ksize, uint16_t *out)
+{
+    if (!q0 || !k || !out || H % Hd || qs[3] != 1 || ks[3] != 1 || ksize < 1 || !(ksize & 1)) return FK_EINVAL;
+    const int G = H / Hd, R = sum_over_heads ? 1 : H;
+    uint16_t *lg = (uint16_t *)malloc((size_t)B * H * n * sizeof(uint16_t));
+    uint16_t *rows = (uint16_t *)malloc((size_t)B * R * n * sizeof(uint16_t));
+    if (!lg || !rows) { free(lg); free(rows); return FK_EINVAL; }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bh = 0; bh < B * H; bh++) {
+        int b = bh / H, h = bh % H;
+        const uint16_t *kb = k + b * ks[0] + (int64_t)(h / G) * ks[1];
+        const uint16_t *qr = q0 + b * qs[0] + h * qs[1];
+        for (int j = 0; j < n; j++) {
+            float acc = 0.0f;
+            const uint16_t *kr = kb + (int64_t)j * ks[2];
+            for (int d = 0; d < D; d++) acc = fmaf(h2f(qr[d]), h2f(kr[d]), acc);
+            lg[(int64_t)bh * n + j] = f2h(acc);
+        }
+    }
+    for (int b = 0; b < B; b++)
+        for (int r = 0; r < R; r++)
+            for (int j = 0; j < n; j++) {
+                if (sum_over_heads) {
+                    float a = 0.0f;
+                    for (int h = 0; h < H; h++) a = a + h2f(lg[((int64_t)b * H + h) * n + j]);
+                    rows[((int64_t)b * R + r) * n + j] = f2h_score(a);
+                } else {
+                    rows[((int64_t)b * R + r) * n + j] = lg[((int64_t)b * H + r) * n + j];
+                }
+            }
+    for (int br = 0; br < B * R; br++) {
+        if (pool) {
+            pool_chunk(rows + (int64_t)br * n, n, ksize, 0, 0, n, out + (int64_t)br * n);
+            for (int j = 0; j < n; j++) { uint16_t *o = out + (int64_t)br * n + j; if ((*o & 0x7fffu) > 0x7c00u) *o = 0x7e00u; }
+        } else {
+            memcpy(out + (int64_t)br * n, rows + (int64_t)br * n, (size_t)n * sizeof(uint16_t));
+        }
+    }
+    free(lg);
+    free(rows);
+    return FK_OK;
+}
+
 float fastkv_oracle_det_expf(float d) { return det_expf(d); }
 float fastkv_oracle_fix_to_f32(uint64_t s) { return fix_to_f32(s); }
 uint64_t fastkv_oracle_exp_to_fix(float e) { uint32_t hi, lo; exp_to_fix(e, &hi, &lo); return ((uint64_t)hi << 24) + lo; }

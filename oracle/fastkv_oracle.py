@@ -181,3 +181,25 @@ class OracleFastKVCluster:
         ko, vo, _, tsp_idx = update_kv(query_states, key_states, value_states, self.window_size, self.kernel_size,
                                        self.pooling, self.max_capacity_prompt, tsp_len, self.order)
         return ko, vo, tsp_idx
+
+
+def standard_dis_index(data: torch.Tensor, queries: torch.Tensor, k: int, norm=1, pool: bool = False, kernel_size: int = 5,
+                       sum_over_heads: bool = False, return_scores: bool = False):
+    """CPU restatement of /root/reference/baselines/gemfilter/utils.py:25-38 (`standard_dis_index`): (distances, indices) with
+    the canonical tie rule (value descending, lowest position first)."""
+    B, H, _, D = queries.shape
+    Hd, n = data.shape[1], data.shape[2]
+    q0 = queries[:, :, :1].contiguous()
+    data = data if data.stride(3) == 1 else data.contiguous()
+    R = 1 if sum_over_heads else H
+    out = torch.empty(B, R, n, dtype=torch.float16)
+    L = lib()
+    L.fastkv_oracle_last_query_scores.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                                  ctypes.POINTER(ctypes.c_int64)] + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+    _check(L.fastkv_oracle_last_query_scores(q0.data_ptr(), _strides(q0), data.data_ptr(), _strides(data), B, H, Hd, n, D,
+                                             int(sum_over_heads), int(pool), kernel_size, out.data_ptr()), "last_query_scores")
+    idx = torch.stack([torch.stack([canonical_topk(out[b, r], k, "score") for r in range(R)]) for b in range(B)])
+    dist = torch.gather(out, 2, idx)
+    if norm != 1:
+        dist = dist / norm
+    return (dist, idx, out) if return_scores else (dist, idx)

@@ -61,3 +61,13 @@ SNAPKV_CASES = {
     "snap_avg": dict(seed=31, B=1, H=8, Hkv=2, S=700, D=128, W=8, ks=5, pooling="avgpool", cap=96),
     "snap_max_b2": dict(seed=32, B=2, H=8, Hkv=4, S=1500, D=128, W=16, ks=7, pooling="maxpool", cap=200),
 }
+
+
+# The GemFilter rule (/root/reference/baselines/gemfilter/utils.py:25-38 `standard_dis_index`; find_context calls it with
+# pool=True, sum_over_heads=True on the last query row): tests/golden/make_gemfilter.py -> gemfilter.npz
+GEMFILTER_CASES = {
+    "gem_ctx": dict(seed=41, B=1, H=8, Hkv=2, S=3000, D=128, k=256, pool=True, ks=5, sum_over_heads=True),
+    "gem_heads": dict(seed=42, B=1, H=4, Hkv=4, S=1000, D=64, k=64, pool=False, ks=5, sum_over_heads=False),
+    "gem_heads_pool": dict(seed=43, B=2, H=8, Hkv=4, S=1200, D=128, k=100, pool=True, ks=7, sum_over_heads=False),
+    "gem_8b": dict(seed=44, B=1, H=32, Hkv=8, S=8192, D=128, k=1024, pool=True, ks=5, sum_over_heads=True),
+}

@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs, and
 against the golden vectors captured from the reference.  Bit-exact: scores, indices, K/V rows."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -677,3 +679,33 @@ def test_per_query_head_selection_snapkv_rule(dev):
                 assert torch.equal(idx.cpu(), want[2]) and torch.equal(ko.cpu(), want[0]) and torch.equal(vo.cpu(), want[1]), (name, order)
             if order == "index":
                 assert torch.equal(idx.cpu(), torch.from_numpy(z[name + ".idx"].astype(np.int64))), name
+
+
+def test_gemfilter_rule_on_gpu(dev):
+    """fastkv_amd.variants.standard_dis_index (window-1 logits -> head sum -> pool -> select through the C ABI) against the
+    oracle's restatement of /root/reference/baselines/gemfilter/utils.py:25-38 and the vectors captured from the reference:
+    ranked tensor, indices (in order) and distances bit for bit; unrepeated keys give what repeated keys give."""
+    import numpy as np
+    from fastkv_amd import variants
+    from golden_cases import GEMFILTER_CASES
+    from helpers import GOLDEN, f16_from_bits
+    from oracle import fastkv_oracle as O
+    z = np.load(os.path.join(GOLDEN, "gemfilter.npz"))
+    for name, c in GEMFILTER_CASES.items():
+        q, k, _ = make_qkv(c["seed"], c["B"], c["H"], c["Hkv"], c["S"], c["D"], 8)
+        ql = q[:, :, -1:, :]
+        wd, wi = O.standard_dis_index(k, ql, c["k"], pool=c["pool"], kernel_size=c["ks"], sum_over_heads=c["sum_over_heads"])
+        qd, kd = _to_dev(ql.contiguous(), dev), _to_dev(k, dev)
+        gd, gi = variants.standard_dis_index(kd, qd, c["k"], pool=c["pool"], kernel_size=c["ks"], sum_over_heads=c["sum_over_heads"])
+        assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu().view(torch.int16), wd.view(torch.int16)), name
+        assert torch.equal(gi.cpu(), torch.from_numpy(z[name + ".idx"].astype(np.int64))), name
+        assert torch.equal(gd.cpu().view(torch.int16), f16_from_bits(z[name + ".ref_dist"]).view(torch.int16)), name
+        kr = kd.repeat_interleave(c["H"] // c["Hkv"], dim=1)                    # as find_context passes them (repeat_kv)
+        gd2, gi2 = variants.standard_dis_index(kr, qd, c["k"], pool=c["pool"], kernel_size=c["ks"], sum_over_heads=c["sum_over_heads"])
+        assert torch.equal(gi2, gi) and torch.equal(gd2, gd), name
+    # ragged length (n % 8 != 0), max-free, norm
+    q, k, _ = make_qkv(7, 1, 8, 2, 1003, 128, 8)
+    wd, wi = O.standard_dis_index(k, q[:, :, -1:, :], 77, norm=4, pool=True, kernel_size=5, sum_over_heads=True)
+    gd, gi = variants.standard_dis_index(_to_dev(k, dev), _to_dev(q[:, :, -1:, :].contiguous(), dev), 77, norm=4, pool=True, kernel_size=5,
+                                         sum_over_heads=True)
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)

@@ -231,3 +231,32 @@ def test_per_query_head_rule_matches_reference_snapkv():
         d = ulp_diff(sc, f16_from_bits(z[name + ".scores"]))
         assert int(d.max()) <= 1 and int((d > 0).sum()) <= max(1, int(0.001 * d.numel())), name
         assert torch.equal(idx, torch.from_numpy(z[name + ".idx"].astype(np.int64))), name
+
+
+def test_gemfilter_rule_matches_reference_standard_dis_index():
+    """The GemFilter rule (last-query inner products -> [head sum] -> [avg_pool1d] -> topk;
+    /root/reference/baselines/gemfilter/utils.py:25-38) against vectors captured from the reference function
+    (tests/golden/make_gemfilter.py).  On these inputs the ranked tensor is BIT-IDENTICAL to the reference's (its CPU fp16
+    matmul accumulates like the oracle's fma chain; there is no exp in this rule), so the indices must equal canonical_topk of
+    the reference's tensor exactly, in order; the reference's own pick -- ties broken arbitrarily by torch.topk -- lies between
+    {x > v_k} and {x >= v_k}."""
+    import os
+    from golden_cases import GEMFILTER_CASES
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "gemfilter.npz"))
+    for name, c in GEMFILTER_CASES.items():
+        q, k, _ = make_qkv(c["seed"], c["B"], c["H"], c["Hkv"], c["S"], c["D"], 8)
+        dist, idx, sc = O.standard_dis_index(k, q[:, :, -1:, :], c["k"], pool=c["pool"], kernel_size=c["ks"],
+                                             sum_over_heads=c["sum_over_heads"], return_scores=True)
+        ref = f16_from_bits(z[name + ".scores"])
+        assert torch.equal(sc.view(torch.int16), ref.view(torch.int16)), name
+        want = torch.from_numpy(z[name + ".idx"].astype(np.int64))
+        assert torch.equal(idx, want) and torch.equal(dist, torch.gather(sc, 2, idx)), name
+        ridx = torch.from_numpy(z[name + ".ref_idx"].astype(np.int64))
+        rdist = f16_from_bits(z[name + ".ref_dist"])
+        assert torch.equal(rdist.view(torch.int16), dist.view(torch.int16)), name       # the k largest VALUES are unambiguous
+        for b in range(idx.shape[0]):
+            for r in range(idx.shape[1]):
+                vk = float(ref[b, r][want[b, r][-1]])
+                rs = set(ridx[b, r].tolist())
+                assert set(torch.nonzero(ref[b, r].float() > vk).flatten().tolist()) <= rs <= set(torch.nonzero(ref[b, r].float() >= vk).flatten().tolist())
