@@ -68,6 +68,9 @@ def plan_for(cluster, S: int):
     return False, cap, tsp
 
 
+_GQA_NATIVE = None          # does SDPA take grouped K/V heads with the lower-right causal bias on this build? (probed once)
+
+
 def _staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
@@ -93,11 +96,23 @@ def sp_attention(query_states, k_cat, v_cat, scaling: float):
     """Local queries [B,H,S_r,D] over keys [0, pos0 + S_r): causal, lower-right aligned (query i sees keys 0 .. pos0 + i)."""
     from torch.nn.attention.bias import causal_lower_right
     G = query_states.shape[1] // k_cat.shape[1]
+    bias = causal_lower_right(query_states.shape[2], k_cat.shape[2])
+    global _GQA_NATIVE
+    if G > 1 and _GQA_NATIVE is not False and query_states.is_cuda:
+        # grouped-query attention inside the kernel: the gathered K/V (the largest tensors of the sharded prefill) are not
+        # expanded to H heads -- 4x fewer bytes at G = 4.  Probed once: a backend without it raises, and the expanded form runs.
+        try:
+            out = F.scaled_dot_product_attention(query_states, k_cat, v_cat, attn_mask=bias, scale=scaling, enable_gqa=True)
+            _GQA_NATIVE = True
+            return out.transpose(1, 2)
+        except (RuntimeError, TypeError):
+            if _GQA_NATIVE:
+                raise
+            _GQA_NATIVE = False
     if G > 1:                                                      # repeat_kv (utils.py:13-22)
         B, Hkv, L, D = k_cat.shape
         k_cat = k_cat[:, :, None].expand(B, Hkv, G, L, D).reshape(B, Hkv * G, L, D)
         v_cat = v_cat[:, :, None].expand(B, Hkv, G, L, D).reshape(B, Hkv * G, L, D)
-    bias = causal_lower_right(query_states.shape[2], k_cat.shape[2])
     out = F.scaled_dot_product_attention(query_states, k_cat, v_cat, attn_mask=bias, scale=scaling)
     return out.transpose(1, 2)                                     # [B,S_r,H,D]
 
