@@ -60,7 +60,13 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     const uint4 kval = *reinterpret_cast<const uint4 *>(ksrc + srow * ks_s + sub * 8);
     const uint4 vval = *reinterpret_cast<const uint4 *>(vsrc + srow * vs_s + sub * 8);
     int d = rc;
-    if (keys) {
+    if (keys && keys_in_lds == 2) {
+        // ORDER_SCORE with the slots already known (rank_group_kernel ran first: many heads): one 2-byte load per row
+        if (rc < kk) {
+            d = keys[(size_t)bg * ((kk + 7) & ~7) + rc];
+            if (idx_sorted && sub == 0) idx_sorted[(size_t)bg * kk + d] = srow;
+        }
+    } else if (keys) {
         // ORDER_SCORE: the winner at ascending-position slot r goes to slot rank(r) (value descending, ties by position);
         // the LPR lanes of the row share the comparison counting, which runs under the latency of the row loads above
         const int kal = (kk + 7) & ~7;
@@ -91,6 +97,78 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     }
 }
 
+// keys[row][0..kk) (order-preserving 16-bit keys of the winners in ascending position) -> the winners' ORDER_SCORE slots, IN
+// PLACE: slot = number of winners with a larger key, or the same key at an earlier position.  One 1024-thread workgroup per
+// row: the keys are grouped by value range (<= 4096 bins between the row's smallest and largest key, LDS histogram + suffix
+// sums + atomic cursors), a winner's slot is the number of winners in higher bins plus a count over its own bin's few
+// members.  O(k) per head where the counting inside compact_kv is O(k^2): with FEW heads that counting is spread over the
+// chip's idle vector ALUs and costs less than this extra launch; with MANY heads (>= 64: batched prompts, the bench's roofline
+// shape) it is what bounds the copy (174 us against 104 us in index order) and this kernel (all heads in parallel) takes
+// over.  A row whose keys are all equal degenerates to one bin and k^2 / 1024 comparisons per thread (~10 us at k = 2040).
+constexpr int RG_BINS = 4096;
+__global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__ keys, int kk, int kal)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];
+    uint32_t *s_start = reinterpret_cast<uint32_t *>(rg_smem);             // [RG_BINS] counts, then: winners in higher bins
+    uint32_t *s_cnt = s_start + RG_BINS;                                    // [RG_BINS] members of the bin
+    uint32_t *s_cur = s_cnt + RG_BINS;                                      // [RG_BINS] scatter cursors
+    uint32_t *s_grp = s_cur + RG_BINS;                                      // [kal] composites grouped by bin
+    uint16_t *s_key = reinterpret_cast<uint16_t *>(s_grp + kal);            // [kal]
+    __shared__ uint32_t s_w[16], s_mn[16], s_mx[16];
+    uint16_t *kr = keys + (size_t)blockIdx.x * kal;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t mn = 0xffffu, mx = 0;
+    for (int i = threadIdx.x; i < kk; i += 1024) {
+        const uint32_t x = kr[i];
+        s_key[i] = (uint16_t)x;
+        mn = min(mn, x);
+        mx = max(mx, x);
+    }
+    for (int i = threadIdx.x; i < RG_BINS; i += 1024) { s_start[i] = 0; s_cur[i] = 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
+    if (lane == 0) { s_mn[w] = mn; s_mx[w] = mx; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn = min(mn, s_mn[i]); mx = max(mx, s_mx[i]); }
+    int sh = 0;
+    while (((mx - mn) >> sh) >= (uint32_t)RG_BINS) ++sh;
+    for (int i = threadIdx.x; i < kk; i += 1024) atomicAdd(&s_start[(s_key[i] - mn) >> sh], 1u);
+    __syncthreads();
+    // suffix sums over the bins: thread t owns bins 4t .. 4t+3
+    {
+        const int b0 = threadIdx.x * 4;
+        const uint32_t c0 = s_start[b0], c1 = s_start[b0 + 1], c2 = s_start[b0 + 2], c3 = s_start[b0 + 3];
+        const uint32_t own = c0 + c1 + c2 + c3;
+        uint32_t v = own;                                                   // -> sum over this and the higher lanes of the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = (uint32_t)__shfl_down((int)v, o, 64); if (lane + o < 64) v += nb; }
+        if (lane == 0) s_w[w] = v;
+        __syncthreads();
+        uint32_t higher = 0;
+        for (int i = w + 1; i < 16; ++i) higher += s_w[i];
+        const uint32_t above = v - own + higher;                            // winners in the bins of higher threads
+        s_cnt[b0] = c0; s_cnt[b0 + 1] = c1; s_cnt[b0 + 2] = c2; s_cnt[b0 + 3] = c3;
+        s_start[b0 + 3] = above;
+        s_start[b0 + 2] = above + c3;
+        s_start[b0 + 1] = above + c3 + c2;
+        s_start[b0] = above + c3 + c2 + c1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kk; i += 1024) {
+        const uint32_t key = s_key[i], bin = (key - mn) >> sh;
+        s_grp[s_start[bin] + atomicAdd(&s_cur[bin], 1u)] = (key << 16) | (uint32_t)(65535 - i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kk; i += 1024) {
+        const uint32_t key = s_key[i], bin = (key - mn) >> sh, me = (key << 16) | (uint32_t)(65535 - i);
+        const uint32_t lo = s_start[bin], n = s_cnt[bin];
+        uint32_t c = 0;
+        for (uint32_t u = 0; u < n; ++u) c += s_grp[lo + u] > me ? 1u : 0u;   // larger key, or the same key at an earlier position
+        kr[i] = (uint16_t)(lo + c);
+    }
+}
+
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
                           hipStream_t st, uint32_t *epoch_bump, const int64_t *out_strides)
@@ -102,8 +180,15 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
     const int64_t os_b = out_strides ? out_strides[0] : (int64_t)p.Hkv * p.capacity * p.D;
     ProfScope ps_(K_COMPACT, st);
     const size_t kal = ((size_t)(p.capacity - p.window) + 7) & ~(size_t)7;
-    const int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                // 32 KiB of LDS at most
-    const size_t dyn = keys_in_lds ? kal * sizeof(uint16_t) : 0;
+    int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                      // 32 KiB of LDS at most
+    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 2688) {           // (its LDS: 48 KiB of bins + 6 bytes per winner <= 64 KiB)
+        // many heads: every head's key list becomes its slot list (workspace memory of this call)
+        const int kk_ = p.capacity - p.window;
+        const size_t lds = (size_t)3 * RG_BINS * 4 + kal * 4 + kal * 2;
+        hipLaunchKernelGGL(rank_group_kernel, dim3((unsigned)(p.B * p.Hkv)), dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+        keys_in_lds = 2;
+    }
+    const size_t dyn = keys_in_lds == 1 ? kal * sizeof(uint16_t) : 0;
 #define FK_COMPACT(LPRV)                                                                                                   \
     hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), dyn, st, (const uint16_t *)k, ks[0], ks[1], ks[2],       \
                        (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \

@@ -142,14 +142,21 @@ def _run(worker, world, case, extra_args, timeout=900):
              [t.share_memory_() if t is not None else None for t in shared[3:]]
     # (contiguous() makes q/k/v [B,H,S,D]-contiguous for the hand-over; the ranks rebuild the module's layout themselves)
     ctx = mp.get_context("spawn")
-    q_out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, case, *extra_args, shared, q_out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q_out.get(timeout=timeout) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=120)
+    for attempt in range(2):
+        q_out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, world, port, case, *extra_args, shared, q_out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q_out.get(timeout=timeout) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+        # a rank that could not rendezvous (the probed port was taken in between, a peer died while connecting) is the test
+        # rig's problem and gets one more try on a fresh port; a wrong RESULT never does
+        rig = [r for r in res if isinstance(r[1], str) and r[1].startswith("EXC") and
+               any(t in r[1] for t in ("Address already in use", "Connection refused", "Connection reset", "connectFullMesh", "Broken pipe"))]
+        if not rig or attempt == 1:
+            break
     assert all(r[1] is True for r in res), res
 
 

@@ -709,3 +709,31 @@ def test_gemfilter_rule_on_gpu(dev):
     gd, gi = variants.standard_dis_index(_to_dev(k, dev), _to_dev(q[:, :, -1:, :].contiguous(), dev), 77, norm=4, pool=True, kernel_size=5,
                                          sum_over_heads=True)
     assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
+
+
+def test_score_order_with_many_heads_groups_instead_of_counting(dev):
+    """With >= 64 (batch x KV head) rows the ORDER_SCORE slots come from one grouping pass per head (rank_group_kernel) instead of the
+    comparison counting inside the copy kernel.  Same result: the stand-alone ranked compaction equals the explicit
+    score-ordered gather (heavy ties: quantised scores), and the whole operator at B * Hkv = 64 equals the oracle."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    B, Hkv, S, D, W = 16, 8, 640, 64, 8
+    g = torch.Generator().manual_seed(5)
+    k = torch.randn(B, Hkv, S, D, generator=g).half()
+    v = torch.randn(B, Hkv, S, D, generator=g).half()
+    sc = (torch.rand(B * Hkv, S - W, generator=g) * 8).floor().half() / 8          # 64 distinct values: long tie runs
+    kd, vd, scd = _to_dev(k, dev), _to_dev(v, dev), sc.to(dev)
+    for kk in (1, 2, 3, 100, 257, S - W):
+        asc = ops.select(scd, kk, "index").view(B, Hkv, kk).contiguous()
+        srt = ops.select(scd, kk, "score").view(B, Hkv, kk).contiguous()
+        ko, vo, got = ops.compact(kd, vd, asc, W, scores=scd.view(B, Hkv, S - W), return_sorted=True)
+        assert torch.equal(got, srt), kk
+        assert torch.equal(ko.cpu(), expected_kv(k, srt.cpu(), W)) and torch.equal(vo.cpu(), expected_kv(v, srt.cpu(), W)), kk
+    q, k2, v2 = make_qkv(91, 8, 32, 8, 1100, 128, 8)
+    want = O.update_kv(q, k2, v2, 8, 7, "maxpool", 300, 500, "score")
+    got = ops.update_kv(_to_dev(q, dev), _to_dev(k2, dev), _to_dev(v2, dev), 8, 7, "maxpool", 300, 500, "score", return_indices=True)
+    assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])
+    assert torch.equal(got[3].cpu(), want[2]) and torch.equal(got[2].cpu(), want[3])
+    want = O.update_kv(q, k2, v2, 8, 7, "avgpool", 1100, 0, "score")               # keep-all layers: every candidate ranked
+    got = ops.update_kv(_to_dev(q, dev), _to_dev(k2, dev), _to_dev(v2, dev), 8, 7, "avgpool", 1100, 0, "score", return_indices=True)
+    assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[3].cpu(), want[2])
