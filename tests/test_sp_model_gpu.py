@@ -114,12 +114,18 @@ def _worker(rank, world, port, lens, q_out):
 def test_sequence_parallel_prefill_on_gpu(lens):
     world = len(lens)
     ctx = mp.get_context("spawn")
-    q_out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, lens, q_out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q_out.get(timeout=900) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=120)
+    for attempt in range(2):
+        q_out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, lens, q_out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q_out.get(timeout=900) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+        # one more try on a fresh port when a rank could not rendezvous (test rig); a wrong result is never retried
+        rig = [r for r in res if isinstance(r[1], str) and r[1].startswith("EXC") and
+               any(t in r[1] for t in ("Address already in use", "Connection refused", "Connection reset", "connectFullMesh", "Broken pipe"))]
+        if not rig or attempt == 1:
+            break
     assert all(r[1] is True for r in res), res
