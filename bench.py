@@ -103,8 +103,10 @@ def profile_read(lib):
 def compact_roofline_shape(lib, dev, steps):
     """Same row geometry as the 32k config (256-B rows at 2 KiB pitch, 2040+8 rows per head) but 32 'layers' in one
     launch: 2 x 2 GiB sources, 539 MB of algorithmic traffic, nothing served from the 256 MiB Infinity Cache.
-    Both row orders: `index` (rows in ascending position: a pure gather) and `score` (the reference's order, utils.py:113:
-    the kernel also ranks the winners by their keys -- what the product's default path runs)."""
+    Both row orders: `index` (rows in ascending position: a pure gather) and `score` (the reference's order, utils.py:113,
+    what the product's default path produces: with this shape's 256 heads the winners' slots come from one grouping pass per
+    head, `rank_group_kernel`, launched inside the same timed bracket as the copy; a single layer's 8 heads are ranked by
+    comparison counting inside the copy kernel instead -- `compact.per_layer_avg_us`)."""
     from fastkv_amd import ops
     B, Hkv, S, D, W, cap = 32, CFG["Hkv"], CFG["S"], CFG["D"], CFG["window"], CFG["budget"]
     k = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
