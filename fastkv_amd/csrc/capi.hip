@@ -103,6 +103,13 @@ int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255)) return FASTKV_EINVAL;
     if (workspace_bytes < CTRL_BYTES) return FASTKV_EWORKSPACE;
+    // Everything behind the control block is cleared: the allocation may lie on memory of an EARLIER workspace (a grown
+    // workspace, a caching allocator) that still holds hand-off granules, and a block without a live control word restarts
+    // its epoch -- hence its tokens -- at zero, i.e. at exactly the tokens those granules carry.  A cleared granule (token 0)
+    // never matches.  (Found by tools/stress_parity.py: one call in 800 read a neighbour's stale pooling halo.)
+    if (workspace_bytes > CTRL_BYTES &&
+        hipMemsetAsync(static_cast<char *>(workspace) + CTRL_BYTES, 0, workspace_bytes - CTRL_BYTES, (hipStream_t)stream) != hipSuccess)
+        return FASTKV_ELAUNCH;
     hipLaunchKernelGGL(fastkv_ctrl_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint32_t *>(workspace));
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
@@ -250,8 +257,13 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
                                 select_all ? keys : nullptr, kal, &epoch_bump);
     if (e != hipSuccess) return FASTKV_ELAUNCH;
-    // From here on a fused scoring launch may be in the stream (epoch_bump set): if a later stage cannot be launched the epoch
-    // is advanced by a one-thread kernel before returning, so that the next call never re-uses this launch's hand-off token.
+    // The epoch advances on EVERY call that gets this far, not only behind a fused scoring launch: the split selection tags its
+    // counters with the same token, and a call on the staged scoring path (another window size, few query heads) that left the
+    // epoch where it was would hand the NEXT call -- whose hand-off areas sit at other, shape-dependent offsets -- granules
+    // that already carry its token.  (tools/stress_parity.py: a pooling halo read from the previous call's selection table.)
+    epoch_bump = reinterpret_cast<uint32_t *>(ws) + 2;
+    // From here on token-tagged kernels may be in the stream: if a later stage cannot be launched the epoch is advanced by a
+    // one-thread kernel before returning, so that the next call never re-uses this call's hand-off token.
     auto fail = [&]() {
         if (epoch_bump) (void)launch_epoch_bump(epoch_bump, st);
         return FASTKV_ELAUNCH;

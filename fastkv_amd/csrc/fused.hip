@@ -18,9 +18,10 @@
 //     the records with sc1 loads and checks the tags.  No fences, no atomics on shared words, order-free integer / max
 //     combination.
 //   * halo: the same granules, one-to-one between adjacent workgroups.
-//   The token is a mix of the epoch in the workspace control block (fastkv_workspace_init zeroes the block once; the
-//   compaction kernel of the same operator call advances the epoch), never a launch argument that a graph replay would
-//   freeze: a granule left by an earlier launch never matches.
+//   The token is a mix of the epoch in the workspace control block (fastkv_workspace_init clears the workspace once; the
+//   compaction kernel of EVERY operator call advances the epoch, whichever scoring path ran: the split selection tags its
+//   counters with the same token), never a launch argument that a graph replay would freeze: a granule left by an earlier
+//   launch never matches.
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"

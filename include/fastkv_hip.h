@@ -67,9 +67,12 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  * Call ONCE per workspace allocation (256-B aligned, any size >= 8 KiB), before its first use by
  * `fastkv_update_kv_f16` / `fastkv_score_f16`: the first 8 KiB of an operator workspace are a control block (magic word,
  * call epoch of the fused scoring kernel's hand-offs) that the library keeps consistent from then on, so no per-call
- * memset is needed and graph replays are safe.  The call is idempotent (a live control block keeps its epoch), so it may be
- * repeated or end up inside a captured graph.  A workspace that was never initialised makes the scoring kernel trap
- * (a loud HIP error at the next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
+ * memset is needed and graph replays are safe.  Every operator call advances the epoch, so the token its kernels tag their
+ * hand-off records with is never seen again; the call also clears the rest of the workspace (stream-ordered memset), because an
+ * allocation on top of an EARLIER workspace's memory would otherwise restart the token sequence over that workspace's
+ * records.  It is idempotent for the control block (a live one keeps its epoch), so it may be repeated between calls or end
+ * up inside a captured graph.  A workspace that was never initialised makes the scoring kernel trap (a loud HIP error at the
+ * next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
  *
  * Residency.  The fused scoring kernel and the split selection exchange partial results between workgroups INSIDE a launch,
  * so a waiting workgroup needs its partners to be resident.  The library sizes those grids to what the device holds when

@@ -737,3 +737,43 @@ def test_score_order_with_many_heads_groups_instead_of_counting(dev):
     want = O.update_kv(q, k2, v2, 8, 7, "avgpool", 1100, 0, "score")               # keep-all layers: every candidate ranked
     got = ops.update_kv(_to_dev(q, dev), _to_dev(k2, dev), _to_dev(v2, dev), 8, 7, "avgpool", 1100, 0, "score", return_indices=True)
     assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[3].cpu(), want[2])
+
+
+def test_every_operator_call_spends_its_handoff_token(dev):
+    """Found by tools/stress_parity.py (1 call in 800, deterministic in its sequence): a call on the STAGED scoring path (window
+    4: no fused launch) still runs the split selection, whose counters are granules tagged with the workspace's current token,
+    but it used to leave the epoch where it was -- the next call (fused path, hand-off areas at other, shape-dependent
+    offsets) then found granules that already carried ITS token and took a pooling halo from them.  Now every call advances
+    the epoch.  Checked directly (the epoch word of the control block moves by one per call, whatever the path) and by the
+    original sequence (cases 48 -> 49 of `stress_parity.py 60 777`), repeated."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    c48 = dict(B=1, H=16, Hkv=8, S=16384, D=128, W=4, ks=3, cap=256, tsp_len=10882, pooling="maxpool", order="score", seed=9048)
+    c49 = dict(B=1, H=8, Hkv=2, S=12499, D=128, W=8, ks=7, cap=512, tsp_len=6295, pooling="maxpool", order="index", seed=9049)
+
+    def run(c, want=None):
+        q, k, v = make_qkv(c["seed"], c["B"], c["H"], c["Hkv"], c["S"], c["D"], c["W"])
+        if want is None:
+            want = O.update_kv(q, k, v, c["W"], c["ks"], c["pooling"], c["cap"], c["tsp_len"], c["order"], return_scores=True)
+        got = ops.update_kv(_to_dev(q, dev), _to_dev(k, dev), _to_dev(v, dev), c["W"], c["ks"], c["pooling"], c["cap"], c["tsp_len"],
+                            c["order"], return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), c
+        assert torch.equal(got[3].cpu(), want[2]) and torch.equal(got[2].cpu(), want[3]) and torch.equal(got[0].cpu(), want[0]), c
+        return want
+
+    def epoch():
+        ws = ops._ws_cache[(dev.index, ops._stream(), "op")]
+        return int(ws[:16].view(torch.int32)[2].item())
+
+    w48 = run(c48)
+    e0 = epoch()
+    run(c48, w48)
+    assert epoch() == e0 + 1                                      # staged scoring + split selection: the token is spent all the same
+    w49 = run(c49)
+    assert epoch() == e0 + 2
+    for _ in range(6):
+        run(c48, w48)
+        run(c49, w49)
+
+

@@ -24,6 +24,9 @@ for it in range(N):
     B = rng.choice([1, 1, 1, 2])
     ks = rng.choice([1, 3, 5, 7, 7, 13])
     S = rng.choice([rng.randint(W + 2 + ks, 3000), rng.randint(3000, 20000), rng.choice([2048, 4096, 8192, 16384, 32768])])
+    if rng.random() < 0.12:                                  # many (batch x KV head) rows: the grouped-ranking compaction
+        B, Hkv = rng.choice([8, 16, 32]), rng.choice([4, 8])
+        S = rng.randint(W + 2 + ks, 1500)
     if B * Hkv * S * D > 40e6:
         B, Hkv = 1, min(Hkv, 4)
     cap = rng.choice([rng.randint(W + 1, S), min(S, rng.choice([256, 512, 2048])), S]) if S > W + 2 else S
@@ -55,5 +58,8 @@ for it in range(N):
                     tsp=(got[2] is None and want[3] is None) or torch.equal(got[2].cpu(), want[3]))
         nd = int((got[4].cpu().view(torch.int16) != want[4].view(torch.int16)).sum())
         print("MISMATCH", tag, what, "score elements differing", nd, "nan in oracle scores", int(torch.isnan(want[4]).sum()), flush=True)
+        gsc, wsc = got[4].cpu().view(torch.int16), want[4].view(torch.int16)
+        for ix in (gsc != wsc).nonzero()[:16].tolist():
+            print("   at", ix, "gpu %04x oracle %04x" % (int(gsc[tuple(ix)]) & 0xffff, int(wsc[tuple(ix)]) & 0xffff), flush=True)
 print(f"{N} cases, {fails} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if fails else 0)
