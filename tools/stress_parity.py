@@ -46,8 +46,27 @@ for it in range(N):
     tag = dict(it=it, B=B, H=Hkv * G, Hkv=Hkv, S=S, D=D, W=W, ks=ks, cap=cap, tsp_len=tsp_len, pooling=pooling, order=order, peaked=peaked, special=special)
     want = O.update_kv(q, k, v, W, ks, pooling, cap, tsp_len, order, return_scores=True)
     qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
-    got = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
+    # the call sequence is part of the test: engines, the scores-only entry point and the strided (cache slab) variant are mixed
+    # in at random, all sharing one workspace whose hand-off areas move with the shape
+    engine = rng.choice(["auto", "auto", "auto", "valu", "mfma"])
+    ops.set_score_engine(engine)
+    pre = rng.random() < 0.2
+    if pre:
+        c_only, t_only = ops.scores(qd, kd, W, ks, pooling)
+    slab = rng.random() < 0.15
+    if slab:
+        rows = cap + rng.randint(0, 64)
+        ks_, vs_ = (torch.zeros(B, Hkv, rows, D, dtype=torch.float16, device=dev) for _ in range(2))
+        got = list(ops.update_kv(qd, kd, vd, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True,
+                                 out=(ks_[:, :, :cap], vs_[:, :, :cap])))
+        got[0], got[1] = ks_[:, :, :cap], vs_[:, :, :cap]
+    else:
+        got = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
     torch.cuda.synchronize()
+    ops.set_score_engine("auto")
+    if pre and not (torch.equal(c_only.cpu().view(torch.int16), want[4].view(torch.int16))):
+        print("MISMATCH (scores-only entry point)", dict(it=it, engine=engine), flush=True)
+        fails += 1
     ok = torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)) and torch.equal(got[3].cpu(), want[2]) and \
         torch.equal(got[0].cpu().view(torch.int16), want[0].view(torch.int16)) and torch.equal(got[1].cpu().view(torch.int16), want[1].view(torch.int16)) and \
         ((got[2] is None and want[3] is None) or torch.equal(got[2].cpu(), want[3]))
