@@ -15,6 +15,8 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 dev = torch.device("cuda:0")
 t0 = time.time()
 fails = 0
+main_stream = torch.cuda.current_stream()
+side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 for it in range(N):
     fusedish = rng.random() < 0.7
     W = 8 if fusedish else rng.choice([1, 4, 8, 16])
@@ -50,6 +52,9 @@ for it in range(N):
     # in at random, all sharing one workspace whose hand-off areas move with the shape
     engine = rng.choice(["auto", "auto", "auto", "valu", "mfma"])
     ops.set_score_engine(engine)
+    stream = side_streams[rng.randrange(len(side_streams))] if rng.random() < 0.25 else torch.cuda.current_stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(stream)                            # every stream has its own workspace (and epoch); launches are chained
     pre = rng.random() < 0.2
     if pre:
         c_only, t_only = ops.scores(qd, kd, W, ks, pooling)
@@ -63,6 +68,7 @@ for it in range(N):
     else:
         got = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
     torch.cuda.synchronize()
+    torch.cuda.set_stream(main_stream)
     ops.set_score_engine("auto")
     if pre and not (torch.equal(c_only.cpu().view(torch.int16), want[4].view(torch.int16))):
         print("MISMATCH (scores-only entry point)", dict(it=it, engine=engine), flush=True)
