@@ -339,7 +339,12 @@ def leg_child_main(a):
     dev = torch.device("cuda", local)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=dev)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+        except (TypeError, RuntimeError, ValueError):
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("nccl")
     else:
         dist.init_process_group(backend)
     try:
@@ -403,7 +408,12 @@ def main():
         import torch.distributed as dist
         backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo": several ranks on one GPU (test boxes with a single device)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except (TypeError, RuntimeError, ValueError):                # a build without eager initialisation: lazy communicators
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
 
