@@ -77,11 +77,37 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
     __shared__ int s_last;
     const int c = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int RB = DPL <= 2 ? 64 : 32;                       // V rows in flight per batch
+    const uint16_t *kb = kslab + b * s_b + hk * s_h, *vb = vslab + b * s_b + hk * s_h;
+    // STEP: the slices partition the slab's CAPACITY, not its current length, so that a wave can request the K and V rows of
+    // its first tile before anything else -- the length, the query, the rotary tables and the new row arrive during the same
+    // memory round trip instead of in two earlier ones.  Rows at or beyond the length are in bounds, loaded and never used.
+    const int span = STEP ? rows : 0;
+    uint4 kv[D / 8];
+    uint32_t vv[RB][(DPL + 1) / 2];
+    bool loaded = false;
+    if (STEP) {
+        const int chunk_s = ((span + nsplit - 1) / nsplit + 63) / 64 * 64;
+        const int lo_s = c * chunk_s, hi_s = min(span, lo_s + chunk_s), t0 = lo_s + w * 64;
+        if (t0 < hi_s) {
+            const uint16_t *kr = kb + (int64_t)min(t0 + lane, hi_s - 1) * s_r;
+#pragma unroll
+            for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const uint16_t *vr = vb + (int64_t)min(t0 + u, hi_s - 1) * s_r + lane * DPL;
+                if (DPL == 1) vv[u][0] = *vr;
+                else if (DPL == 2) vv[u][0] = *reinterpret_cast<const uint32_t *>(vr);
+                else { const uint2 x = *reinterpret_cast<const uint2 *>(vr); vv[u][0] = x.x; vv[u][1] = x.y; }
+            }
+            loaded = true;
+        }
+    }
     const int len_old = *len_dev;
     int len = len_old + 1;                                       // the step's own row is row *len_dev
     if (len > rows) len = rows;
     const int jnew = len - 1;                                    // (a full slab overwrites its last row: the host sizes it)
-    const int chunk = ((len + nsplit - 1) / nsplit + 63) / 64 * 64;
+    const int chunk = (((STEP ? span : len) + nsplit - 1) / nsplit + 63) / 64 * 64;
     const int lo = c * chunk, hi = min(len, lo + chunk);
     const bool owner = STEP && jnew >= lo && jnew < hi;          // this workgroup's slice holds the step's row
     if (STEP) {
@@ -129,7 +155,6 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
         }
     }
     __syncthreads();
-    const uint16_t *kb = kslab + b * s_b + hk * s_h, *vb = vslab + b * s_b + hk * s_h;
     float m[G], l[G], o[G][DPL];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -149,9 +174,7 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
         // V rows of the tile (lane = head-dim elements lane*DPL ..., one coalesced row load per row) are requested TOGETHER with
         // the K rows: they do not depend on the scores, so a tile costs one memory round trip (head_dim 256: the second
         // half of the V rows follows in a second batch, registers)
-        constexpr int RB = DPL <= 2 ? 64 : 32;
         const int nrow = min(64, hi - t0);
-        uint32_t vv[RB][(DPL + 1) / 2];
         auto load_v = [&](int r0) {
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
@@ -160,19 +183,15 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
                 if (DPL == 1) vv[u][0] = *vr;
                 else if (DPL == 2) vv[u][0] = *reinterpret_cast<const uint32_t *>(vr);
                 else { const uint2 x = *reinterpret_cast<const uint2 *>(vr); vv[u][0] = x.x; vv[u][1] = x.y; }
-                if (STEP && owner && jr == jnew) {                // (wave-uniform) the step's own V row
-                    const uint16_t *vl = s_vnew + lane * DPL;
-                    if (DPL == 1) vv[u][0] = *vl;
-                    else if (DPL == 2) vv[u][0] = *reinterpret_cast<const uint32_t *>(vl);
-                    else { const uint2 x = *reinterpret_cast<const uint2 *>(vl); vv[u][0] = x.x; vv[u][1] = x.y; }
-                }
             }
         };
         {
-            uint4 kv[D / 8];                                     // the whole row in flight: one round trip per tile
+            if (!loaded) {                                       // the whole row in flight: one round trip per tile
 #pragma unroll
-            for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
-            load_v(0);
+                for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
+                load_v(0);
+            }
+            loaded = false;
 #pragma unroll
             for (int u = 0; u < D / 8; ++u) {
                 const uint32_t wds[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
@@ -214,12 +233,21 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 if (r0 + u < nrow) {
+                    uint32_t vw[(DPL + 1) / 2];
+#pragma unroll
+                    for (int e = 0; e < (DPL + 1) / 2; ++e) vw[e] = vv[u][e];
+                    if (STEP && owner && t0 + r0 + u == jnew) {   // (wave-uniform) the step's own V row: from LDS, not from the slab
+                        const uint16_t *vl = s_vnew + lane * DPL;
+                        if (DPL == 1) vw[0] = *vl;
+                        else if (DPL == 2) vw[0] = *reinterpret_cast<const uint32_t *>(vl);
+                        else { const uint2 x = *reinterpret_cast<const uint2 *>(vl); vw[0] = x.x; vw[(DPL + 1) / 2 - 1] = x.y; }
+                    }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float p = s_p[w][g][r0 + u];
 #pragma unroll
                         for (int e = 0; e < DPL; ++e) {
-                            const uint32_t wd = vv[u][e / 2];
+                            const uint32_t wd = vw[e / 2];
                             o[g][e] = __builtin_fmaf(p, h2f((uint16_t)((e & 1) ? wd >> 16 : wd & 0xffffu)), o[g][e]);
                         }
                     }
