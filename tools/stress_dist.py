@@ -30,7 +30,14 @@ if __name__ == "__main__":
         case = dict(seed=7000 + it, B=B, H=Hkv * G, Hkv=Hkv, S=S, D=D, W=W, ks=ks, pooling=rng.choice(["avgpool", "maxpool"]), cap=cap,
                     tsp_len=tsp_len, order=rng.choice(["index", "score"]), replicate=rng.random() < 0.3, discover=rng.random() < 0.3)
         try:
-            T._run(T._sp_worker, world, case, (lens,), timeout=600)
+            if rng.random() < 0.3:                               # heads over ranks instead of the sequence
+                world = rng.choice([2, 4])
+                case["Hkv"] = world * rng.choice([1, 2]); case["H"] = case["Hkv"] * G
+                case.pop("replicate"); case.pop("discover")
+                lens = "heads"
+                T._run(T._tp_worker, world, case, (), timeout=600)
+            else:
+                T._run(T._sp_worker, world, case, (lens,), timeout=600)
             print(f"it {it}: world {world} lens {lens} {case} OK", flush=True)
         except AssertionError as e:
             fails += 1
