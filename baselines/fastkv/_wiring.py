@@ -43,7 +43,7 @@ def _mlp(module, hidden_states, static):
 
 def _gemv_ok(*linears) -> bool:
     return all(isinstance(m, torch.nn.Linear) and m.bias is None and m.weight.dtype == torch.float16 and m.weight.is_contiguous()
-               and m.in_features % 512 == 0 and m.in_features * 2 <= 65536 for m in linears)
+               and m.in_features % 512 == 0 and m.in_features * 2 <= 65536 - 256 for m in linears)
 
 
 def _static_layer_ok(layer, hidden_states, position_embeddings, past_key_values) -> bool:
@@ -61,7 +61,7 @@ def _static_layer_ok(layer, hidden_states, position_embeddings, past_key_values)
         return False
     if getattr(getattr(mlp, "config", None), "hidden_act", None) != "silu" or not hasattr(mlp, "gate_proj"):
         return False
-    if mlp.down_proj.in_features * 2 * hidden_states.shape[0] > 65536:
+    if max(mlp.down_proj.in_features, attn.q_proj.in_features) * 2 * hidden_states.shape[0] > 65536 - 256:
         return False
     return _gemv_ok(attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj)
 

@@ -210,7 +210,7 @@ extern "C" int fastkv_decode_gemv_f16(int32_t B, int32_t K, const void *x, int64
 {
     if (B < 1 || K < 512 || (K & 511) || !x || !weights || !rows || !out || n_mats < 1 || n_mats > 3 || (x_row_stride & 7)) return FASTKV_EINVAL;
     if (B != 1 && B != 2 && B != 4) return FASTKV_EUNSUPPORTED;
-    if ((size_t)B * K * 2 > 64 * 1024) return FASTKV_EUNSUPPORTED;                 // the input rows live in LDS
+    if ((size_t)B * K * 2 > 64 * 1024 - 256) return FASTKV_EUNSUPPORTED;           // the input rows live in LDS (+ a few static words)
     if (glu && (n_mats != 2 || rows[0] != rows[1] || residual)) return FASTKV_EINVAL;
     GemvArgs a = {};
     a.x = (const uint16_t *)x; a.x_row = x_row_stride;

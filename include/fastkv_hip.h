@@ -303,7 +303,7 @@ int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q
 int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void *out, void *stream);
 
 /* Weight-streaming GEMV of the decode step (csrc/gemv.hip): out[b, :] = W x[b, :] for ONE input row per batch element
- * (B = 1, 2 or 4; K % 512 == 0, B*K*2 <= 64 KiB), fp16 in / fp32 accumulate / fp16 out.  Replaces the q/k/v/o and MLP
+ * (B = 1, 2 or 4; K % 512 == 0, B*K*2 <= 64 KiB - 256), fp16 in / fp32 accumulate / fp16 out.  Replaces the q/k/v/o and MLP
  * `nn.Linear` calls of the attention module and MLP during a one-token step
  * (/root/reference/baselines/fastkv/llama_model.py:118-120, :186; the stock LlamaMLP) -- one launch each for
  *   n_mats <= 3 matrices sharing the input, `rows[i]` rows of K contiguous fp16 each, outputs concatenated;
