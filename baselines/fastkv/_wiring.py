@@ -42,7 +42,10 @@ def _mlp(module, hidden_states, static):
 
 
 def _gemv_ok(*linears) -> bool:
-    return all(isinstance(m, torch.nn.Linear) and m.bias is None and m.weight.dtype == torch.float16 and m.weight.is_contiguous()
+    # plain fp16 `nn.Linear` without bias -- and without hooks: the fused step reads the weights directly, a hook on the module
+    # (an adapter, a profiler) would silently not run
+    return all(type(m) is torch.nn.Linear and m.bias is None and m.weight.dtype == torch.float16 and m.weight.is_contiguous()
+               and not m._forward_hooks and not m._forward_pre_hooks
                and m.in_features % 512 == 0 and m.in_features * 2 <= 65536 - 256 for m in linears)
 
 
