@@ -108,7 +108,8 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
                          const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl = nullptr);
 hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, const uint16_t *keys, int64_t key_row_stride,
                                int64_t rows, int64_t k, int64_t *out, int64_t out_row_stride, hipStream_t st);
-// idx: ascending-position winners; keys != nullptr => rows are placed in ORDER_SCORE (rank by comparison counting) and
+// idx: ascending-position winners; keys != nullptr => rows are placed in ORDER_SCORE (rank by comparison counting, or -- 64 or
+// more heads -- by a grouping pass that turns the key list into the slot list IN PLACE: `keys` is scratch of the call) and
 // idx_sorted_out (optional) receives the indices in that order
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
