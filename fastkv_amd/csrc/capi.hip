@@ -209,10 +209,14 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
                                         scores_out, workspace, workspace_bytes, stream);
 }
 
-int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
-                                 const int64_t k_strides[4], const void *v, const int64_t v_strides[4], void *k_out, void *v_out,
-                                 const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out,
-                                 void *workspace, size_t workspace_bytes, void *stream)
+}  // extern "C"
+
+// The operator behind fastkv_update_kv_strided_f16 (one base address + batch stride per tensor) and fastkv_update_kv_ptrs_f16
+// (`pt`: one base address per batch entry, in device memory; q / k / v / k_out / v_out are then ignored).
+static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
+                          const int64_t k_strides[4], const void *v, const int64_t v_strides[4], void *k_out, void *v_out,
+                          const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out,
+                          void *workspace, size_t workspace_bytes, void *stream, const PtrTables *pt)
 {
     if (out_strides && ((out_strides[0] & 7) || (out_strides[1] & 7) || (out_strides[2] & 7) || out_strides[2] < (p ? p->D : 0)))
         return FASTKV_EINVAL;                                  // 16-B aligned rows, at least D elements apart
@@ -220,6 +224,8 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     if ((rc = take_abort_status()) != FASTKV_OK) return rc;      // an EARLIER launch gave up (see the header)
     if ((rc = check_problem(p)) != FASTKV_OK) return rc;
     if ((rc = check_select(p)) != FASTKV_OK) return rc;
+    static const char aligned16[16] __attribute__((aligned(16))) = {0};
+    if (pt) { q = k = v = aligned16; k_out = v_out = const_cast<char *>(aligned16); }   // (the entries' addresses are the caller's to check)
     if ((rc = check_strides(q, q_strides)) != FASTKV_OK) return rc;
     if ((rc = check_strides(k, k_strides)) != FASTKV_OK) return rc;
     if ((rc = check_strides(v, v_strides)) != FASTKV_OK) return rc;
@@ -248,14 +254,15 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     if (select_all && !by_score && p->tsp_len == 0 && !scores_out) {
         // capacity == S, ascending order, nothing else asked for: the result does not depend on the scores at all -- K/V are
         // copied (candidates in position order, then the window rows), one launch
-        hipError_t e0 = launch_compact(*p, k, k_strides, v, v_strides, nullptr, nullptr, kv_idx_out, k_out, v_out, st, nullptr, out_strides);
+        hipError_t e0 = launch_compact(*p, k, k_strides, v, v_strides, nullptr, nullptr, kv_idx_out, k_out, v_out, st, nullptr, out_strides, pt);
         return e0 == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
     }
     uint32_t *epoch_bump = nullptr;                          // set when the fused score kernel ran: the compaction advances the epoch
     // (all_idx != nullptr switches the scoring stage to "identity selection": with score order only the keys are needed, so
     // the list goes to a scratch row area that nobody reads)
     hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
-                                select_all ? keys : nullptr, kal, &epoch_bump);
+                                select_all ? keys : nullptr, kal, &epoch_bump, pt);
+    if (e == hipErrorNotSupported) return FASTKV_EUNSUPPORTED;   // (nothing has been launched)
     if (e != hipSuccess) return FASTKV_ELAUNCH;
     // The epoch advances on EVERY call that gets this far, not only behind a fused scoring launch: the split selection tags its
     // counters with the same token, and a call on the staged scoring path (another window size, few query heads) that left the
@@ -288,8 +295,34 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const i
     // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction
     // derives it instead of loading it)
     e = launch_compact(*p, k, k_strides, v, v_strides, (select_all && by_score) ? nullptr : idx_asc, keys,
-                       by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump, out_strides);
+                       by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump, out_strides, pt);
     return e == hipSuccess ? FASTKV_OK : fail();
+}
+
+extern "C" {
+
+int fastkv_update_kv_strided_f16(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
+                                 const int64_t k_strides[4], const void *v, const int64_t v_strides[4], void *k_out, void *v_out,
+                                 const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *scores_out,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    return update_kv_impl(p, q, q_strides, k, k_strides, v, v_strides, k_out, v_out, out_strides, kv_idx_out, tsp_idx_out, scores_out,
+                          workspace, workspace_bytes, stream, nullptr);
+}
+
+int fastkv_update_kv_ptrs_f16(const fastkv_problem *p, const void *const *q_ptrs, const int64_t q_strides[4],
+                              const void *const *k_ptrs, const int64_t k_strides[4], const void *const *v_ptrs,
+                              const int64_t v_strides[4], void *const *k_out_ptrs, void *const *v_out_ptrs,
+                              const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    if (!q_ptrs || !k_ptrs || !v_ptrs || !k_out_ptrs || !v_out_ptrs) return FASTKV_EINVAL;
+    PtrTables pt;
+    pt.q = reinterpret_cast<const uint64_t *>(q_ptrs); pt.k = reinterpret_cast<const uint64_t *>(k_ptrs);
+    pt.v = reinterpret_cast<const uint64_t *>(v_ptrs);
+    pt.k_out = reinterpret_cast<const uint64_t *>(k_out_ptrs); pt.v_out = reinterpret_cast<const uint64_t *>(v_out_ptrs);
+    return update_kv_impl(p, nullptr, q_strides, nullptr, k_strides, nullptr, v_strides, nullptr, nullptr, out_strides, kv_idx_out,
+                          tsp_idx_out, nullptr, workspace, workspace_bytes, stream, &pt);
 }
 
 int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t src_row_stride_bytes, const int64_t *idx,

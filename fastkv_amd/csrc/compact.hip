@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
                                                          int64_t *__restrict__ idx_sorted, int Hkv, int S, int W, int cap,
                                                          int keys_in_lds, uint16_t *__restrict__ k_out,
                                                          uint16_t *__restrict__ v_out, uint32_t *__restrict__ epoch_bump,
-                                                         int64_t os_b, int64_t os_h, int64_t os_r)
+                                                         int64_t os_b, int64_t os_h, int64_t os_r, const uint64_t *__restrict__ k_tab,
+                                                         const uint64_t *__restrict__ v_tab, const uint64_t *__restrict__ ko_tab,
+                                                         const uint64_t *__restrict__ vo_tab)
 {
     // last kernel of the operator: advance the workspace epoch after a fused score launch (fused.hip)
     if (epoch_bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -37,11 +39,12 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     constexpr int RPB = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) uint16_t s_keys[];   // winner keys for the ranking (dynamic: 0 B when unused)
     const int bg = blockIdx.y, b = bg / Hkv, g = bg % Hkv;
-    const uint16_t *ksrc = k + b * ks_b + (int64_t)g * ks_h;
-    const uint16_t *vsrc = v + b * vs_b + (int64_t)g * vs_h;
+    // (per-entry base addresses instead of base + batch stride: fk_host.h PtrTables)
+    const uint16_t *ksrc = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g * ks_h;
+    const uint16_t *vsrc = (v_tab ? reinterpret_cast<const uint16_t *>(v_tab[b]) : v + b * vs_b) + (int64_t)g * vs_h;
     // output [B,Hkv,cap,D] with element strides (os_b, os_h, os_r): contiguous, or a window of a larger cache slab
-    uint16_t *kdst = k_out + b * os_b + g * os_h;
-    uint16_t *vdst = v_out + b * os_b + g * os_h;
+    uint16_t *kdst = (ko_tab ? reinterpret_cast<uint16_t *>(ko_tab[b]) : k_out + b * os_b) + g * os_h;
+    uint16_t *vdst = (vo_tab ? reinterpret_cast<uint16_t *>(vo_tab[b]) : v_out + b * os_b) + g * os_h;
     const int kk = cap - W, n = S - W;
     const int sub = threadIdx.x % LPR;
     const int r = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__
 
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
-                          hipStream_t st, uint32_t *epoch_bump, const int64_t *out_strides)
+                          hipStream_t st, uint32_t *epoch_bump, const int64_t *out_strides, const PtrTables *pt)
 {
     const int lpr = p.D / 8;
     const int rows_per_block = 256 / lpr;
@@ -192,7 +195,8 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
 #define FK_COMPACT(LPRV)                                                                                                   \
     hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), dyn, st, (const uint16_t *)k, ks[0], ks[1], ks[2],       \
                        (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \
-                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out, epoch_bump, os_b, os_h, os_r)
+                       p.capacity, keys_in_lds, (uint16_t *)k_out, (uint16_t *)v_out, epoch_bump, os_b, os_h, os_r,               \
+                       pt ? pt->k : nullptr, pt ? pt->v : nullptr, pt ? pt->k_out : nullptr, pt ? pt->v_out : nullptr)
     if (lpr == 8) FK_COMPACT(8);
     else if (lpr == 16) FK_COMPACT(16);
     else FK_COMPACT(32);

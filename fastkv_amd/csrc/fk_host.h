@@ -37,6 +37,14 @@ static inline size_t select_ws_bytes(int64_t rows, int64_t n, int64_t k)
     return align_up((size_t)rows * kal * sizeof(int64_t), 256) + align_up((size_t)rows * kal * sizeof(uint16_t), 256);
 }
 
+// Per-batch-entry base addresses instead of one base + batch stride (fastkv_update_kv_ptrs_f16: the batch entries are
+// separately allocated tensors, e.g. the layers of a model).  Device arrays of p.B addresses each; head / row strides are
+// shared by the entries.  nullptr = not used.
+struct PtrTables {
+    const uint64_t *q, *k, *v;
+    const uint64_t *k_out, *v_out;
+};
+
 static inline Layout make_layout(const fastkv_problem &p)
 {
     Layout L;
@@ -87,11 +95,11 @@ uint64_t spin_limit_ticks();
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
                         char *ws, hipStream_t st, int64_t *all_idx = nullptr, uint16_t *all_keys = nullptr,
-                        int64_t all_key_stride = 0, uint32_t **epoch_bump_later = nullptr);
+                        int64_t all_key_stride = 0, uint32_t **epoch_bump_later = nullptr, const PtrTables *pt = nullptr);
 // fused logits + softmax + window-row sum + pooling/head sum (fused.hip); false = shape not covered, take the three-kernel path
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
-                        int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err);
+                        int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err, const PtrTables *pt = nullptr);
 hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st);
 hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st);
 hipError_t launch_pool_rows(const uint16_t *in, int64_t in_stride, int64_t rows, int64_t n, int ksize, int pooling, uint16_t *out,
@@ -113,7 +121,8 @@ hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, c
 // idx_sorted_out (optional) receives the indices in that order
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
-                          hipStream_t st, uint32_t *epoch_bump = nullptr, const int64_t *out_strides = nullptr);
+                          hipStream_t st, uint32_t *epoch_bump = nullptr, const int64_t *out_strides = nullptr,
+                          const PtrTables *pt = nullptr);
 hipError_t launch_winner_keys(const uint16_t *scores, int64_t row_stride, int64_t n, const int64_t *idx, int64_t rows, int kk,
                               uint16_t *keys, hipStream_t st);
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,

@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              uint16_t *__restrict__ c_out, int64_t c_row_stride,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
-                                                             uint32_t *__restrict__ host_flag, uint64_t spin_ticks)
+                                                             uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
+                                                             const uint64_t *__restrict__ k_tab)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         vh_s[s] = hv - g_s[s] * VH;
         bg_s[s] = b * Hkv + g_s[s];
         bgv_s[s] = bg_s[s] * VH + vh_s[s];                    // hand-off records are per virtual head
-        kb_s[s] = k + b * ks_b + (int64_t)g_s[s] * ks_h;
+        kb_s[s] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[s] * ks_h;   // (per-entry base: fk_host.h PtrTables)
     }
     const int n = S - W;
     const int nwt = (S + TK - 1) / TK;
@@ -140,7 +141,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         for (int u = 0; u < QV; ++u) {
             const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
             const int i = rowl / W, r = rowl - i * W;
-            qv[s][u] = *reinterpret_cast<const uint4 *>(q + b * qs_b + (int64_t)((g_s[s] * VH + vh_s[s]) * G + i) * qs_h +
+            qv[s][u] = *reinterpret_cast<const uint4 *>((q_tab ? reinterpret_cast<const uint16_t *>(q_tab[b]) : q + b * qs_b) +
+                                                       (int64_t)((g_s[s] * VH + vh_s[s]) * G + i) * qs_h +
                                                        (int64_t)(n + r) * qs_s + ch * 8);
         }
     KStage sA, sB;
@@ -700,7 +702,7 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
 // covered and the caller must take the three-kernel path.
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
-                        int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err)
+                        int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err, const PtrTables *pt)
 {
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
     // FASTKV_FUSED_STREAMS=2: the two-heads-per-workgroup experiment (measured slower, see the kernel's comment); default 1
@@ -778,7 +780,8 @@ one_stream:
     fused_dispatch(p.D, PERT, NBV, NS, [&](auto fl) {
         decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                              p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
-                             c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks);
+                             c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
+                             pt ? pt->k : nullptr);
     });
     *err = hipGetLastError();
     return true;

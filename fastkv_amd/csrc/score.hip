@@ -623,7 +623,7 @@ hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st)
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out, int64_t t_row_stride,
                         char *ws, hipStream_t st, int64_t *all_idx, uint16_t *all_keys, int64_t all_key_stride,
-                        uint32_t **epoch_bump_later)
+                        uint32_t **epoch_bump_later, const PtrTables *pt)
 {
     float *qf = reinterpret_cast<float *>(ws + L.off_qf);
     uint16_t *logits = reinterpret_cast<uint16_t *>(ws + L.off_logits);
@@ -638,9 +638,11 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
     if (epoch_bump_later) *epoch_bump_later = nullptr;
     // one launch for the common geometry (the `logits` area then only holds the workgroups' halo granules) ...
     const bool fused = launch_score_fused(p, L, q, qs, k, ks, c_out, c_row_stride, all_idx, all_keys, all_key_stride,
-                                          ws, st, &e);
+                                          ws, st, &e, pt);
     if (fused) {
         if (e != hipSuccess) return e;
+    } else if (pt) {
+        return hipErrorNotSupported;                             // per-entry base addresses exist on the fused path only
     } else {
         // ... or logits -> row statistics / probabilities -> window-row sum + pooling + head sum
         if ((e = launch_logits(p, L, q, qs, p.S - p.window, k, ks, qf, logits, L.Sp, 0, st)) != hipSuccess) return e;

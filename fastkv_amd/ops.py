@@ -372,3 +372,75 @@ def decode_step_attention(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Ten
                                             out.data_ptr(), ws.data_ptr(), ws.numel(), cnt.data_ptr(), _stream())
     check(rc, "decode_step_attention")
     return out
+
+
+# ------------------------------------------------------------------------------------------------- separately allocated entries
+_ptr_ring = {}
+
+
+def _device_ptr_table(rows, device: torch.device) -> torch.Tensor:
+    """int64 [len(rows), n] on `device` from lists of addresses: staged through a small ring of pinned host buffers (the copy
+    is asynchronous on the current stream; a buffer is reused only after the copy that read it has completed)."""
+    n = len(rows[0])
+    key = device.index
+    ring = _ptr_ring.get(key)
+    if ring is None:
+        ring = _ptr_ring[key] = {"bufs": [torch.empty(5 * 512, dtype=torch.int64).pin_memory() for _ in range(8)],
+                                 "events": [None] * 8, "next": 0}
+    assert len(rows) * n <= 5 * 512
+    i = ring["next"]
+    ring["next"] = (i + 1) % 8
+    if ring["events"][i] is not None:
+        ring["events"][i].synchronize()
+    buf = ring["bufs"][i][:len(rows) * n].view(len(rows), n)
+    buf.copy_(torch.tensor(rows, dtype=torch.int64))
+    dev = buf.to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring["events"][i] = ev
+    return dev
+
+
+def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, capacity: int, tsp_len: int = 0, order: str = "score",
+                      outs=None, return_indices: bool = False):
+    """`update_kv` over SEPARATELY ALLOCATED entries in one launch sequence (fastkv_update_kv_ptrs_f16): qs / ks / vs are lists
+    of [1,H,S,D] / [1,Hkv,S,D] fp16 tensors of ONE geometry and ONE memory layout (e.g. the layers of a model whose compression
+    was deferred to the end of the forward pass).  Returns (k_outs, v_outs, tsp_idx [n,tsp_len] | None[, kv_idx [n,Hkv,cap-W]]);
+    `outs` = (list of k buffers, list of v buffers), [1,Hkv,cap,D] views of one stride pattern, to write into.
+    Raises FastKVNativeError(FASTKV_EUNSUPPORTED) for geometries off the fused scoring path: call `update_kv` per entry then."""
+    n = len(qs)
+    assert n >= 1 and len(ks) == n and len(vs) == n
+    q0, k0, v0 = qs[0], ks[0], vs[0]
+    _check_qkv(q0, k0, v0)
+    for q, k, v in zip(qs, ks, vs):
+        assert q.shape == q0.shape and k.shape == k0.shape and v.shape == v0.shape and q.shape[0] == 1
+        assert q.stride() == q0.stride() and k.stride() == k0.stride() and v.stride() == v0.stride()
+        assert q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16
+        assert (q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0
+    L = load()
+    p = _problem(q0, k0, window, kernel_size, pooling, capacity, tsp_len, order)
+    p.B = n
+    Hkv, D, dev = p.Hkv, p.D, q0.device
+    if outs is None:
+        kb = torch.empty(n, Hkv, capacity, D, dtype=torch.float16, device=dev)
+        vb = torch.empty_like(kb)
+        k_outs, v_outs = [kb[i:i + 1] for i in range(n)], [vb[i:i + 1] for i in range(n)]
+    else:
+        k_outs, v_outs = outs
+        for ko, vo in zip(k_outs, v_outs):
+            assert ko.shape == (1, Hkv, capacity, D) and vo.shape == ko.shape and ko.stride() == k_outs[0].stride() == vo.stride()
+            assert ko.stride(3) == 1 and (ko.data_ptr() | vo.data_ptr()) % 16 == 0
+    ostr = (ctypes.c_int64 * 3)(*k_outs[0].stride()[:3])
+    tab = _device_ptr_table([[t.data_ptr() for t in lst] for lst in (qs, ks, vs, k_outs, v_outs)], dev)
+    kv_idx = torch.empty(n, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
+    tsp = torch.empty(n, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
+    ws = _workspace(L.fastkv_workspace_bytes(ctypes.byref(p)), dev)
+    rc = L.fastkv_update_kv_ptrs_f16(ctypes.byref(p), tab[0].data_ptr(), _strides(q0), tab[1].data_ptr(), _strides(k0), tab[2].data_ptr(),
+                                     _strides(v0), tab[3].data_ptr(), tab[4].data_ptr(), ostr,
+                                     kv_idx.data_ptr() if kv_idx is not None else None, tsp.data_ptr() if tsp is not None else None,
+                                     ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "update_kv_entries")
+    out = [k_outs, v_outs, tsp]
+    if return_indices:
+        out.append(kv_idx)
+    return tuple(out)

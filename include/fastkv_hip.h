@@ -128,6 +128,24 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p,
                                  int64_t *tsp_idx_out, void *scores_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The same operator over SEPARATELY ALLOCATED batch entries: p->B entries (e.g. the layers of a model whose compression was
+ * deferred to the end of the forward pass -- the reference compresses layer by layer inside the attention forward,
+ * /root/reference/baselines/fastkv/llama_model.py:136-142, but nothing reads a layer's compressed cache before decode), each
+ * with its own q / k / v / k_out / v_out base address.  The five arrays hold p->B addresses each and live in DEVICE memory;
+ * strides [1..3] (head, row, element) are shared by the entries, [0] is ignored; out_strides as in
+ * fastkv_update_kv_strided_f16 (NULL: entries are contiguous [Hkv,capacity,D]).  kv_idx_out [B,Hkv,capacity-window] and
+ * tsp_idx_out [B,tsp_len] are ordinary batched tensors.  One launch sequence for all entries: the per-launch latencies of
+ * the small post-TSP layers (16.5 + 8.2 us each) are paid once.  Entries must be 16-B aligned (not checked: the addresses
+ * are on the device).  Fused scoring path only: FASTKV_EUNSUPPORTED (nothing launched) for geometries that would take the
+ * three-kernel path -- call the strided entry point per entry then.
+ */
+int fastkv_update_kv_ptrs_f16(const fastkv_problem *p, const void *const *q_ptrs, const int64_t q_strides[4],
+                              const void *const *k_ptrs, const int64_t k_strides[4], const void *const *v_ptrs,
+                              const int64_t v_strides[4], void *const *k_out_ptrs, void *const *v_out_ptrs,
+                              const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
+/*
  * Stage 1 alone: window-attention scores (utils.py:93-112 [+ :127 head sum]).
  *   scores_out      fp16 [B,Hkv,S-window] contiguous
  *   tsp_scores_out  optional fp16 [B,S-window]

@@ -777,3 +777,36 @@ def test_every_operator_call_spends_its_handoff_token(dev):
         run(c49, w49)
 
 
+
+
+def test_operator_over_separately_allocated_entries(dev):
+    """fastkv_update_kv_ptrs_f16 / ops.update_kv_entries: the batch entries are separate tensors (the layers of a model whose
+    compression was deferred), addressed through device-side pointer tables, processed in ONE launch sequence.  Every entry's
+    result equals the oracle's for that entry alone: the 16 keep-all layers behind the TSP layer in score order (the case the
+    call exists for), a selecting geometry with a TSP index, and output written into views of larger slabs."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    for n, (H, Hkv, S, D, W, ks, pooling, cap, tsp_len, order, slab) in ((16, (32, 8, 2048, 128, 8, 7, "maxpool", 2048, 0, "score", False)),
+                                                                      (4, (32, 8, 4096, 128, 8, 7, "avgpool", 512, 1024, "score", True)),
+                                                                      (3, (16, 2, 3001, 64, 8, 5, "maxpool", 300, 0, "index", False))):
+        ins = [make_qkv(500 + 10 * n + i, 1, H, Hkv, S, D, W) for i in range(n)]
+        qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
+        outs = None
+        if slab:
+            slabs = [torch.zeros(2, 1, Hkv, cap + 40, D, dtype=torch.float16, device=dev) for _ in range(n)]
+            outs = ([s_[0, :, :, :cap] for s_ in slabs], [s_[1, :, :, :cap] for s_ in slabs])
+        got = ops.update_kv_entries(qs, kks, vs, W, ks, pooling, cap, tsp_len, order, outs=outs, return_indices=True)
+        torch.cuda.synchronize()
+        for i, (q, k, v) in enumerate(ins):
+            want = O.update_kv(q, k, v, W, ks, pooling, cap, tsp_len, order)
+            assert torch.equal(got[0][i].cpu(), want[0]) and torch.equal(got[1][i].cpu(), want[1]), (n, i)
+            assert torch.equal(got[3][i:i + 1].cpu(), want[2]), (n, i)
+            assert (got[2] is None and want[3] is None) or torch.equal(got[2][i:i + 1].cpu(), want[3]), (n, i)
+        if slab:
+            assert all(float(s_[:, :, :, cap:].abs().max()) == 0.0 for s_ in slabs)         # nothing written past the views
+    # a geometry off the fused path is refused before anything is launched (window 4): the caller goes entry by entry
+    ins = [make_qkv(900 + i, 1, 8, 2, 1000, 128, 4) for i in range(2)]
+    qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
+    with pytest.raises(Exception) as ei:
+        ops.update_kv_entries(qs, kks, vs, 4, 7, "maxpool", 128, 0, "score")
+    assert "unsupported" in str(ei.value).lower() or "-3" in str(ei.value) or "UNSUPPORTED" in str(ei.value)
