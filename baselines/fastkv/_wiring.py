@@ -112,7 +112,7 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
             self.tsp_idx = None
 
         def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, fastkv_sp=None,
-                    **kwargs):
+                    fastkv_defer=None, **kwargs):
             input_shape = hidden_states.shape[:-1]
             hidden_shape = (*input_shape, -1, self.head_dim)
             q_len = input_shape[1]
@@ -132,7 +132,16 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                 if q_len > 1:                                     # prefill: compress what goes into the cache
                     layers = getattr(past_key_values, "layers", None)
                     slab = layers[self.layer_idx] if layers is not None and self.layer_idx < len(layers) else None
-                    if isinstance(slab, SlabLayer) and key_states.is_cuda and getattr(self.kv_cluster, "supports_out_factory", False):
+                    if fastkv_defer is not None and not isinstance(slab, SlabLayer) and \
+                            fastkv_defer.eligible(self.kv_cluster, key_states, query_states):
+                        # a layer whose compressed cache nobody needs before decode: compressed together with its peers when
+                        # the forward pass is over (fastkv_amd.cluster.DeferredCompression); attention below runs over the
+                        # full current K/V either way
+                        self.tsp_idx = None
+                        k_c = v_c = None
+                        if not fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states):
+                            k_c, v_c = key_states, value_states
+                    elif isinstance(slab, SlabLayer) and key_states.is_cuda and getattr(self.kv_cluster, "supports_out_factory", False):
                         # the compaction writes straight into the layer's cache slab; `update` then only adopts the rows
                         k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
                                                                            self.num_key_value_groups, self.layer_idx,
@@ -140,7 +149,8 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                     else:
                         k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
                                                                            self.num_key_value_groups, self.layer_idx)
-                    past_key_values.update(k_c, v_c, self.layer_idx)
+                    if k_c is not None:
+                        past_key_values.update(k_c, v_c, self.layer_idx)
                 else:                                             # decode: plain append (llama_model.py:143-145)
                     self.tsp_idx = None
                     layers = getattr(past_key_values, "layers", None)
@@ -194,7 +204,7 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
 
 
 def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None,
-                                use_cache=False, position_embeddings=None, fastkv_sp=None, **kwargs):
+                                use_cache=False, position_embeddings=None, fastkv_sp=None, fastkv_defer=None, **kwargs):
     static = _static_step(past_key_values, hidden_states)
     if static and fastkv_sp is None and _static_layer_ok(self, hidden_states, position_embeddings, past_key_values):
         return _static_layer(self, hidden_states, position_embeddings, past_key_values)
@@ -202,7 +212,7 @@ def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, positi
     hidden_states = _norm(self.input_layernorm, hidden_states, static)
     hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                       past_key_values=past_key_values, use_cache=use_cache,
-                                      position_embeddings=position_embeddings, fastkv_sp=fastkv_sp, **kwargs)
+                                      position_embeddings=position_embeddings, fastkv_sp=fastkv_sp, fastkv_defer=fastkv_defer, **kwargs)
     hidden_states = residual + hidden_states
     residual = hidden_states
     hidden_states = _norm(self.post_attention_layernorm, hidden_states, static)
@@ -258,10 +268,18 @@ def make_model_forward(modeling, mask_fn_for):
                                                    past_key_values=past_key_values, position_ids=position_ids)
         hidden_states = inputs_embeds
         position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
+        # Prefill over the reference's cache type: layers whose compressed cache is not needed while the prompt is in flight (all
+        # but the TSP layer) and whose launches are pure latency (the <= 4096-token layers behind the TSP layer) are compressed
+        # together after the last layer (fastkv_amd.cluster.DeferredCompression; FASTKV_DEFER=0: layer by layer as the reference)
+        defer = None
+        if sp is None and type(past_key_values) is DynamicCache and inputs_embeds.shape[1] > 1 and inputs_embeds.is_cuda \
+                and os.environ.get("FASTKV_DEFER", "1") != "0":
+            from fastkv_amd.cluster import DeferredCompression
+            defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")))
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:
             hidden_states = decoder_layer(hidden_states, attention_mask=causal_mask, position_embeddings=position_embeddings,
                                           position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,
-                                          fastkv_sp=sp if (sp is not None and not sp.reduced) else None, **kwargs)
+                                          fastkv_sp=sp if (sp is not None and not sp.reduced) else None, fastkv_defer=defer, **kwargs)
             new_position_ids = getattr(decoder_layer, "new_position_ids", None)
             if new_position_ids is not None:                      # after the TSP layer: fewer tokens, new rotary tables
                 position_ids = new_position_ids
@@ -273,6 +291,9 @@ def make_model_forward(modeling, mask_fn_for):
                 # over the current K/V), and no position ids: the gaps between surviving positions are not sequence boundaries.
                 causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=hidden_states, attention_mask=None,
                                                        past_key_values=None, position_ids=None)
+        if defer is not None:
+            for idx, k_c, v_c in defer.flush():                   # (layer order: the cache grows by appending)
+                past_key_values.update(k_c, v_c, idx)
         hidden_states = _norm(self.norm, hidden_states, _static_step(past_key_values, hidden_states))
         hidden_states = hidden_states[:, -1:, :]                  # only the last token feeds lm_head
         if sp is not None and not sp.reduced:

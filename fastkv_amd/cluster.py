@@ -15,6 +15,7 @@ from typing import NamedTuple, Optional
 import torch
 
 from . import ops
+from ._lib import FastKVNativeError
 
 
 class Plan(NamedTuple):
@@ -100,6 +101,62 @@ class FastKVCluster:
                                                   self.kernel_size, self.pooling, plan.capacity, plan.tsp_len,
                                                   self.kv_order, out=out)
         return k_out, v_out, tsp_indices
+
+
+class DeferredCompression:
+    """Compression of several layers in ONE launch sequence at the end of the forward pass.
+
+    The reference compresses layer by layer inside the attention forward (llama_model.py:136-142), but nothing reads a
+    layer's compressed cache before decode -- only the TSP layer's index is needed while the prompt is still in flight.  The
+    layers behind the TSP layer see 2048 tokens each: their launches are all latency (16.5 + 8.2 us per layer for 8 MiB of
+    traffic).  An attention module hands such a layer's q / k / v over with `add`; `flush` groups the collected layers by
+    geometry and runs `ops.update_kv_entries` (device-side pointer tables: no stacking copies) per group -- 16 post-TSP layers
+    in 114 us instead of 407 us -- and returns (layer_idx, k_compressed, v_compressed) in layer order for the cache.
+    Same rows, same order as the per-layer calls (tests/test_wiring_gpu.py)."""
+
+    def __init__(self, max_len: int = 4096):
+        self.max_len = max_len
+        self.items = []
+
+    def eligible(self, cluster, key_states, query_states) -> bool:
+        # (an instance whose update_kv was wrapped -- a spy, an adapter -- expects to be called: not deferred)
+        return (type(cluster) is FastKVCluster and "update_kv" not in vars(cluster) and not cluster.tsp_layer
+                and key_states.is_cuda and key_states.dtype == torch.float16
+                and query_states.dtype == torch.float16 and key_states.shape[0] == 1 and key_states.shape[2] <= self.max_len)
+
+    def add(self, layer_idx, cluster, key_states, query_states, value_states) -> bool:
+        """True: taken (the cache entry comes from `flush`).  False: the layer keeps everything (utils.py:89-91) -- the caller
+        caches key_states / value_states as they are."""
+        plan = cluster.plan(query_states.shape[2])
+        if plan.early_out:
+            return False
+        self.items.append((layer_idx, (cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order),
+                           query_states, key_states, value_states))
+        return True
+
+    def flush(self):
+        groups = {}
+        for it in self.items:
+            _, params, q, k, v = it
+            key = (params, tuple(q.shape), q.stride(), tuple(k.shape), k.stride(), v.stride())
+            groups.setdefault(key, []).append(it)
+        self.items = []
+        done = []
+        for (params, *_), its in groups.items():
+            window, ksize, pooling, cap, order = params
+            qs, ks, vs = [i[2] for i in its], [i[3] for i in its], [i[4] for i in its]
+            try:
+                if len(its) < 2:
+                    raise FastKVNativeError("single entry")
+                k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order)
+            except (FastKVNativeError, AssertionError):      # off the fused path, or a misaligned view: entry by entry
+                k_outs, v_outs = [], []
+                for q, k, v in zip(qs, ks, vs):
+                    ko, vo, _ = ops.update_kv(q, k, v, window, ksize, pooling, cap, 0, order)
+                    k_outs.append(ko)
+                    v_outs.append(vo)
+            done += [(i[0], ko, vo) for i, ko, vo in zip(its, k_outs, v_outs)]
+        return sorted(done, key=lambda t: t[0])
 
 
 def init_fastkv(self):

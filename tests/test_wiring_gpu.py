@@ -107,3 +107,44 @@ def test_llama_wiring_on_gpu_matches_oracle_cluster():
 def test_mistral_wiring_on_gpu_matches_oracle_cluster():
     """BASELINE.json configs[3]'s wiring (/root/reference/baselines/fastkv/mistral_model.py:100-107, 217-224)."""
     _capture_and_compare("mistral")
+
+
+def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch):
+    """FASTKV_DEFER (default on, DynamicCache): the layers behind the TSP layer are compressed together after the last layer
+    (fastkv_amd.cluster.DeferredCompression -> ops.update_kv_entries, one launch sequence) instead of one by one inside their
+    attention forward.  Same kernels, same inputs: caches and logits are bit-identical to the layer-by-layer run, and the
+    deferred path really ran (its entry point was called once with the 5 layers behind the TSP layer)."""
+    from baselines.monkeypatch import replace_llama, set_model
+    from benchmark import prefill
+    from fastkv_amd import ops
+
+    def run(defer):
+        monkeypatch.setenv("FASTKV_DEFER", defer)
+        monkeypatch.setenv("FASTKV_SLAB_CACHE", "0")
+        a = prefill.parse_args(["--model_path", "llama3-8b", "--num_layers", "6", "--device", "cuda", "--save_txt", "", "--method",
+                                "fastkv", "--max_capacity_prompts", "512", "--tsp_len", "1024", "--tsp_idx", "0", "--pooling", "maxpool"])
+        a.save_txt = False
+        a.context_lengths = [3000]
+        replace_llama("fastkv")
+        torch.manual_seed(11)
+        model = prefill.build_model(a, "cuda")
+        set_model(model, a)
+        ids = torch.randint(0, 1000, (1, 3000), generator=torch.Generator().manual_seed(12)).cuda()
+        with torch.no_grad():
+            out = model(ids, attention_mask=torch.ones_like(ids))
+            nxt = out.logits[:, -1].argmax(-1, keepdim=True)
+            out2 = model(nxt, past_key_values=out.past_key_values)
+        torch.cuda.synchronize()
+        pkv = out.past_key_values
+        return out.logits.float().cpu(), out2.logits.float().cpu(), [(l.keys.clone(), l.values.clone()) for l in pkv.layers]
+
+    calls = []
+    real = ops.update_kv_entries
+    monkeypatch.setattr(ops, "update_kv_entries", lambda *a, **k: (calls.append(len(a[0])), real(*a, **k))[1])
+    l1, d1, c1 = run("1")
+    assert calls == [5]
+    l0, d0, c0 = run("0")
+    assert calls == [5]
+    assert torch.equal(l1, l0) and torch.equal(d1, d0) and len(c1) == len(c0) == 6
+    for (k1, v1), (k0, v0) in zip(c1, c0):
+        assert torch.equal(k1, k0) and torch.equal(v1, v0)
