@@ -6,7 +6,9 @@ One STEP = the whole FastKV hot path of ONE Llama-3-8B prefill at 32k context (B
 TSP layer 15, budget 2048, window 8, kernel 7, maxpool, fp16):
     layers 0..15   update_kv at S=32768 (score -> select -> compact), layer 15 also produces the TSP index
     TSP propagation  hidden [1,32768,4096] -> [1,2048,4096] row gather (llama_model.py:252-259)
-    layers 16..31  update_kv at S=2048 (k == n permutation case)
+    layers 16..31  update_kv at S=2048 (k == n permutation case) -- handed to DeferredCompression and run as ONE launch sequence
+                   after the last layer, as baselines/fastkv/_wiring.py does by default (`layer_by_layer` in the line: the
+                   32 sequential calls of the reference's schedule, FASTKV_DEFER=0)
 on synthetic fp16 Q/K/V (seeded torch.randn on the device, one distinct tensor set per layer so nothing is
 cache-resident across layers), inputs already in HBM.  `value` = prompt tokens / hot-path time, summed over ranks.
 N>1: every rank runs its own prompt (independent prompts shard with no exchange) -> weak scaling.
