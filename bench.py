@@ -81,6 +81,7 @@ class HotPathPrefill:
         compress_fastkv(self.model, args)
         self.clusters = [l.self_attn.kv_cluster for l in layers]
         self.defer = os.environ.get("FASTKV_DEFER", "1") != "0"
+        self.defer_max_len = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096"))
 
     def step(self):
         """The calls the patched model makes during one prefill (baselines/fastkv/_wiring.py), without the model around them:
@@ -92,7 +93,7 @@ class HotPathPrefill:
         G = CFG["H"] // CFG["Hkv"]
         cache = [None] * len(self.layers_in)
         hidden = None
-        defer = DeferredCompression() if self.defer else None
+        defer = DeferredCompression(max_len=self.defer_max_len) if self.defer else None
         for i, (q, k, v) in enumerate(self.layers_in):
             cl = self.clusters[i]
             if defer is not None and defer.eligible(cl, k, q):
@@ -554,6 +555,21 @@ def main():
                 work.defer = True
                 out["layer_by_layer"] = {"ms_per_step": round(ms_seq, 4), "tokens_per_s": round(CFG["S"] / (ms_seq * 1e-3), 1),
                                          "note": "32 sequential update_kv calls (FASTKV_DEFER=0): the call pattern of the reference"}
+                # ... and with the 15 layers in front of the TSP layer deferred as well (FASTKV_DEFER_MAX_LEN = prompt length: two
+                # 32k layers per launch sequence; their full K/V stay alive until the end of the forward pass)
+                work.defer_max_len = CFG["S"]
+                for _ in range(2):
+                    work.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    work.step()
+                torch.cuda.synchronize()
+                ms_all = (time.perf_counter() - t0) / a.steps * 1e3
+                work.defer_max_len = 4096
+                out["deferred_all_layers"] = {"ms_per_step": round(ms_all, 4), "tokens_per_s": round(CFG["S"] / (ms_all * 1e-3), 1),
+                                              "note": "FASTKV_DEFER_MAX_LEN=32768: every layer but the TSP layer deferred (+2 GB of K/V "
+                                                      "held until the forward pass ends); not the default"}
             # the same step with the K/V rows in ascending position (FASTKV_KV_ORDER=index; attention does not depend on the row
             # order): the 16 post-TSP layers keep every candidate and become single copy launches
             for c in work.clusters:

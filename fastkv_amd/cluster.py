@@ -112,7 +112,12 @@ class DeferredCompression:
     traffic).  An attention module hands such a layer's q / k / v over with `add`; `flush` groups the collected layers by
     geometry and runs `ops.update_kv_entries` (device-side pointer tables: no stacking copies) per group -- 16 post-TSP layers
     in 114 us instead of 407 us -- and returns (layer_idx, k_compressed, v_compressed) in layer order for the cache.
+    `max_len` bounds which layers are taken: 4096 by default (the layers behind the TSP layer).  With FASTKV_DEFER_MAX_LEN at
+    the prompt length the layers in front of the TSP layer are deferred too and run two per launch sequence at 32k (135 -> 122
+    us per pair) -- at the price of keeping their full K/V alive until the end of the forward pass (2 GB at 32k).
     Same rows, same order as the per-layer calls (tests/test_wiring_gpu.py)."""
+
+    _max_entries = {}                                              # geometry -> entries per launch sequence (process-wide)
 
     def __init__(self, max_len: int = 4096):
         self.max_len = max_len
@@ -142,20 +147,26 @@ class DeferredCompression:
             groups.setdefault(key, []).append(it)
         self.items = []
         done = []
-        for (params, *_), its in groups.items():
-            window, ksize, pooling, cap, order = params
-            qs, ks, vs = [i[2] for i in its], [i[3] for i in its], [i[4] for i in its]
-            try:
-                if len(its) < 2:
-                    raise FastKVNativeError("single entry")
-                k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order)
-            except (FastKVNativeError, AssertionError):      # off the fused path, or a misaligned view: entry by entry
-                k_outs, v_outs = [], []
-                for q, k, v in zip(qs, ks, vs):
-                    ko, vo, _ = ops.update_kv(q, k, v, window, ksize, pooling, cap, 0, order)
-                    k_outs.append(ko)
-                    v_outs.append(vo)
-            done += [(i[0], ko, vo) for i, ko, vo in zip(its, k_outs, v_outs)]
+        for key, its in groups.items():
+            window, ksize, pooling, cap, order = key[0]
+            # as many entries per launch sequence as the fused scoring kernel holds resident for this geometry (found by halving,
+            # remembered per geometry): all 16 post-TSP layers at once, two 32k layers, one entry at a time off the fused path
+            pos = 0
+            while pos < len(its):
+                n = min(self._max_entries.get(key, len(its)), len(its) - pos)
+                chunk = its[pos:pos + n]
+                qs, ks, vs = [i[2] for i in chunk], [i[3] for i in chunk], [i[4] for i in chunk]
+                if n >= 2:
+                    try:
+                        k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order)
+                    except (FastKVNativeError, AssertionError):  # more than fits, off the fused path, or a misaligned view
+                        self._max_entries[key] = n // 2 if n > 3 else n - 1
+                        continue
+                else:
+                    k_outs, v_outs, _ = ops.update_kv(qs[0], ks[0], vs[0], window, ksize, pooling, cap, 0, order)
+                    k_outs, v_outs = [k_outs], [v_outs]
+                done += [(i[0], ko, vo) for i, ko, vo in zip(chunk, k_outs, v_outs)]
+                pos += n
         return sorted(done, key=lambda t: t[0])
 
 

@@ -804,6 +804,17 @@ def test_operator_over_separately_allocated_entries(dev):
             assert (got[2] is None and want[3] is None) or torch.equal(got[2][i:i + 1].cpu(), want[3]), (n, i)
         if slab:
             assert all(float(s_[:, :, :, cap:].abs().max()) == 0.0 for s_ in slabs)         # nothing written past the views
+    # two 32k layers per launch sequence (four tiles per wave) is what the residency limit allows; three are refused
+    from fastkv_amd._lib import FastKVNativeError
+    ins = [make_qkv(700 + i, 1, 32, 8, 32768, 128, 8) for i in range(3)]
+    qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
+    got = ops.update_kv_entries(qs[:2], kks[:2], vs[:2], 8, 7, "maxpool", 2048, 0, "score", return_indices=True)
+    torch.cuda.synchronize()
+    for i in range(2):
+        want = O.update_kv(*ins[i], 8, 7, "maxpool", 2048, 0, "score")
+        assert torch.equal(got[0][i].cpu(), want[0]) and torch.equal(got[1][i].cpu(), want[1]) and torch.equal(got[3][i:i + 1].cpu(), want[2])
+    with pytest.raises(FastKVNativeError):
+        ops.update_kv_entries(qs, kks, vs, 8, 7, "maxpool", 2048, 0, "score")
     # a geometry off the fused path is refused before anything is launched (window 4): the caller goes entry by entry
     ins = [make_qkv(900 + i, 1, 8, 2, 1000, 128, 4) for i in range(2)]
     qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
