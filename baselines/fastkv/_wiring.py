@@ -132,14 +132,14 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                 if q_len > 1:                                     # prefill: compress what goes into the cache
                     layers = getattr(past_key_values, "layers", None)
                     slab = layers[self.layer_idx] if layers is not None and self.layer_idx < len(layers) else None
-                    if fastkv_defer is not None and not isinstance(slab, SlabLayer) and \
-                            fastkv_defer.eligible(self.kv_cluster, key_states, query_states):
+                    if fastkv_defer is not None and fastkv_defer.eligible(self.kv_cluster, key_states, query_states):
                         # a layer whose compressed cache nobody needs before decode: compressed together with its peers when
                         # the forward pass is over (fastkv_amd.cluster.DeferredCompression); attention below runs over the
                         # full current K/V either way
                         self.tsp_idx = None
                         k_c = v_c = None
-                        if not fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states):
+                        if not fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states,
+                                                out_factory=slab.prefill_views if isinstance(slab, SlabLayer) else None):
                             k_c, v_c = key_states, value_states
                     elif isinstance(slab, SlabLayer) and key_states.is_cuda and getattr(self.kv_cluster, "supports_out_factory", False):
                         # the compaction writes straight into the layer's cache slab; `update` then only adopts the rows
@@ -268,11 +268,12 @@ def make_model_forward(modeling, mask_fn_for):
                                                    past_key_values=past_key_values, position_ids=position_ids)
         hidden_states = inputs_embeds
         position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
-        # Prefill over the reference's cache type: layers whose compressed cache is not needed while the prompt is in flight (all
+        # Prefill: layers whose compressed cache is not needed while the prompt is in flight (all
         # but the TSP layer) and whose launches are pure latency (the <= 4096-token layers behind the TSP layer) are compressed
         # together after the last layer (fastkv_amd.cluster.DeferredCompression; FASTKV_DEFER=0: layer by layer as the reference)
         defer = None
-        if sp is None and type(past_key_values) is DynamicCache and inputs_embeds.shape[1] > 1 and inputs_embeds.is_cuda \
+        if sp is None and (type(past_key_values) is DynamicCache or isinstance(past_key_values, FastKVSlabCache)) \
+                and inputs_embeds.shape[1] > 1 and inputs_embeds.is_cuda \
                 and os.environ.get("FASTKV_DEFER", "1") != "0":
             from fastkv_amd.cluster import DeferredCompression
             defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")))

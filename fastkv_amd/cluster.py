@@ -129,21 +129,26 @@ class DeferredCompression:
                 and key_states.is_cuda and key_states.dtype == torch.float16
                 and query_states.dtype == torch.float16 and key_states.shape[0] == 1 and key_states.shape[2] <= self.max_len)
 
-    def add(self, layer_idx, cluster, key_states, query_states, value_states) -> bool:
+    def add(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None) -> bool:
         """True: taken (the cache entry comes from `flush`).  False: the layer keeps everything (utils.py:89-91) -- the caller
-        caches key_states / value_states as they are."""
+        caches key_states / value_states as they are.  `out_factory` as in FastKVCluster.update_kv: the compacted rows are
+        written straight into the views it returns (a layer's cache slab)."""
         plan = cluster.plan(query_states.shape[2])
         if plan.early_out:
             return False
+        outs = None
+        if out_factory is not None:
+            B, Hkv, _, D = key_states.shape
+            outs = out_factory(B, Hkv, plan.capacity, D, key_states.dtype, key_states.device)
         self.items.append((layer_idx, (cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order),
-                           query_states, key_states, value_states))
+                           query_states, key_states, value_states, outs))
         return True
 
     def flush(self):
         groups = {}
         for it in self.items:
-            _, params, q, k, v = it
-            key = (params, tuple(q.shape), q.stride(), tuple(k.shape), k.stride(), v.stride())
+            _, params, q, k, v, outs = it
+            key = (params, tuple(q.shape), q.stride(), tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
             groups.setdefault(key, []).append(it)
         self.items = []
         done = []
@@ -156,14 +161,16 @@ class DeferredCompression:
                 n = min(self._max_entries.get(key, len(its)), len(its) - pos)
                 chunk = its[pos:pos + n]
                 qs, ks, vs = [i[2] for i in chunk], [i[3] for i in chunk], [i[4] for i in chunk]
+                outs = None if chunk[0][5] is None else ([i[5][0] for i in chunk], [i[5][1] for i in chunk])
                 if n >= 2:
                     try:
-                        k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order)
+                        k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order, outs=outs)
                     except (FastKVNativeError, AssertionError):  # more than fits, off the fused path, or a misaligned view
                         self._max_entries[key] = n // 2 if n > 3 else n - 1
                         continue
                 else:
-                    k_outs, v_outs, _ = ops.update_kv(qs[0], ks[0], vs[0], window, ksize, pooling, cap, 0, order)
+                    k_outs, v_outs, _ = ops.update_kv(qs[0], ks[0], vs[0], window, ksize, pooling, cap, 0, order,
+                                                      out=None if outs is None else (outs[0][0], outs[1][0]))
                     k_outs, v_outs = [k_outs], [v_outs]
                 done += [(i[0], ko, vo) for i, ko, vo in zip(chunk, k_outs, v_outs)]
                 pos += n

@@ -118,9 +118,9 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     from benchmark import prefill
     from fastkv_amd import ops
 
-    def run(defer):
+    def run(defer, slab="0"):
         monkeypatch.setenv("FASTKV_DEFER", defer)
-        monkeypatch.setenv("FASTKV_SLAB_CACHE", "0")
+        monkeypatch.setenv("FASTKV_SLAB_CACHE", slab)
         a = prefill.parse_args(["--model_path", "llama3-8b", "--num_layers", "6", "--device", "cuda", "--save_txt", "", "--method",
                                 "fastkv", "--max_capacity_prompts", "512", "--tsp_len", "1024", "--tsp_idx", "0", "--pooling", "maxpool"])
         a.save_txt = False
@@ -148,3 +148,9 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     assert torch.equal(l1, l0) and torch.equal(d1, d0) and len(c1) == len(c0) == 6
     for (k1, v1), (k0, v0) in zip(c1, c0):
         assert torch.equal(k1, k0) and torch.equal(v1, v0)
+    # ... and over the slab cache: the deferred launch writes every layer's rows straight into that layer's slab
+    ls, ds, cs = run("1", slab="1")
+    assert calls == [5, 5]
+    assert torch.equal(ls, l0) and len(cs) == 6
+    for (k1, v1), (k0, v0) in zip(cs, c0):
+        assert torch.equal(k1[:, :, :k0.shape[2]], k0) and torch.equal(v1[:, :, :v0.shape[2]], v0)
