@@ -788,7 +788,8 @@ def test_operator_over_separately_allocated_entries(dev):
     from oracle import fastkv_oracle as O
     for n, (H, Hkv, S, D, W, ks, pooling, cap, tsp_len, order, slab) in ((16, (32, 8, 2048, 128, 8, 7, "maxpool", 2048, 0, "score", False)),
                                                                       (4, (32, 8, 4096, 128, 8, 7, "avgpool", 512, 1024, "score", True)),
-                                                                      (3, (16, 2, 3001, 64, 8, 5, "maxpool", 300, 0, "index", False))):
+                                                                      (3, (16, 2, 3001, 64, 8, 5, "maxpool", 300, 0, "index", False)),
+                                                                      (4, (32, 8, 2048, 128, 8, 7, "maxpool", 2048, 0, "index", True))):
         ins = [make_qkv(500 + 10 * n + i, 1, H, Hkv, S, D, W) for i in range(n)]
         qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
         outs = None
