@@ -381,6 +381,10 @@ _ptr_ring = {}
 def _device_ptr_table(rows, device: torch.device) -> torch.Tensor:
     """int64 [len(rows), n] on `device` from lists of addresses: staged through a small ring of pinned host buffers (the copy
     is asynchronous on the current stream; a buffer is reused only after the copy that read it has completed)."""
+    if torch.cuda.is_current_stream_capturing():
+        # a replay would re-read the pinned staging buffer, which other calls have rewritten since
+        raise RuntimeError("fastkv_amd.update_kv_entries cannot be captured in a HIP graph (its address tables are staged through "
+                           "host memory); call update_kv per entry inside a capture")
     n = len(rows[0])
     key = device.index
     ring = _ptr_ring.get(key)
