@@ -159,6 +159,8 @@ class DeferredCompression:
             pos = 0
             while pos < len(its):
                 n = min(self._max_entries.get(key, len(its)), len(its) - pos)
+                if torch.cuda.is_current_stream_capturing():
+                    n = 1                                        # (the entries call stages its address tables through the host)
                 chunk = its[pos:pos + n]
                 qs, ks, vs = [i[2] for i in chunk], [i[3] for i in chunk], [i[4] for i in chunk]
                 outs = None if chunk[0][5] is None else ([i[5][0] for i in chunk], [i[5][1] for i in chunk])
