@@ -138,9 +138,13 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                         # full current K/V either way
                         self.tsp_idx = None
                         k_c = v_c = None
-                        if not fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states,
-                                                out_factory=slab.prefill_views if isinstance(slab, SlabLayer) else None):
+                        ready = fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states,
+                                                 out_factory=slab.prefill_views if isinstance(slab, SlabLayer) else None)
+                        if ready is None:
                             k_c, v_c = key_states, value_states
+                        else:
+                            for idx, kr, vr in ready:              # (a launch sequence became full: this layer and its peer)
+                                past_key_values.update(kr, vr, idx)
                     elif isinstance(slab, SlabLayer) and key_states.is_cuda and getattr(self.kv_cluster, "supports_out_factory", False):
                         # the compaction writes straight into the layer's cache slab; `update` then only adopts the rows
                         k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,
@@ -268,15 +272,16 @@ def make_model_forward(modeling, mask_fn_for):
                                                    past_key_values=past_key_values, position_ids=position_ids)
         hidden_states = inputs_embeds
         position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
-        # Prefill: layers whose compressed cache is not needed while the prompt is in flight (all
-        # but the TSP layer) and whose launches are pure latency (the <= 4096-token layers behind the TSP layer) are compressed
-        # together after the last layer (fastkv_amd.cluster.DeferredCompression; FASTKV_DEFER=0: layer by layer as the reference)
+        # Prefill: layers whose compressed cache is not needed while the prompt is in flight (all but the TSP layer) are compressed
+        # together with their peers -- the <= 4096-token layers behind the TSP layer after the last layer, the long ones in front of
+        # it in pairs (fastkv_amd.cluster.DeferredCompression; FASTKV_DEFER=0: layer by layer as the reference)
         defer = None
         if sp is None and (type(past_key_values) is DynamicCache or isinstance(past_key_values, FastKVSlabCache)) \
                 and inputs_embeds.shape[1] > 1 and inputs_embeds.is_cuda \
                 and os.environ.get("FASTKV_DEFER", "1") != "0":
             from fastkv_amd.cluster import DeferredCompression
-            defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")))
+            defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")),
+                                        hold_long=int(os.environ.get("FASTKV_DEFER_HOLD", "2")))
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:
             hidden_states = decoder_layer(hidden_states, attention_mask=causal_mask, position_embeddings=position_embeddings,
                                           position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,

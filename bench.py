@@ -82,6 +82,7 @@ class HotPathPrefill:
         self.clusters = [l.self_attn.kv_cluster for l in layers]
         self.defer = os.environ.get("FASTKV_DEFER", "1") != "0"
         self.defer_max_len = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096"))
+        self.defer_hold = int(os.environ.get("FASTKV_DEFER_HOLD", "2"))
 
     def step(self):
         """The calls the patched model makes during one prefill (baselines/fastkv/_wiring.py), without the model around them:
@@ -93,12 +94,16 @@ class HotPathPrefill:
         G = CFG["H"] // CFG["Hkv"]
         cache = [None] * len(self.layers_in)
         hidden = None
-        defer = DeferredCompression(max_len=self.defer_max_len) if self.defer else None
+        defer = DeferredCompression(max_len=self.defer_max_len, hold_long=self.defer_hold) if self.defer else None
         for i, (q, k, v) in enumerate(self.layers_in):
             cl = self.clusters[i]
             if defer is not None and defer.eligible(cl, k, q):
-                if not defer.add(i, cl, k, q, v):
+                ready = defer.add(i, cl, k, q, v)
+                if ready is None:
                     cache[i] = (k, v)
+                else:
+                    for j, ko, vo in ready:
+                        cache[j] = (ko, vo)
                 continue
             ko, vo, tsp = cl.update_kv(k, q, v, None, G, i)
             cache[i] = (ko, vo)
@@ -488,9 +493,9 @@ def main():
                                   "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
                       "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
            "ttft_hotpath_ms": round(ms_per_step, 4)}
-    out["config"]["post_tsp_layers"] = ("deferred: the 16 layers behind the TSP layer are compressed in ONE launch sequence after the last "
-                                        "layer (what baselines/fastkv/_wiring.py does by default; same rows, same order)") if work.defer \
-        else "layer by layer (FASTKV_DEFER=0)"
+    out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
+                                 "sequence after the last layer, the layers in front of it in pairs (a layer waits for one peer: 128 MiB of "
+                                 "K/V held one layer longer); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
 
     if not a.no_extras:
         # instrumented replay of the same steps: per-kernel HIP-event durations on the launch stream
@@ -568,8 +573,8 @@ def main():
                 ms_all = (time.perf_counter() - t0) / a.steps * 1e3
                 work.defer_max_len = 4096
                 out["deferred_all_layers"] = {"ms_per_step": round(ms_all, 4), "tokens_per_s": round(CFG["S"] / (ms_all * 1e-3), 1),
-                                              "note": "FASTKV_DEFER_MAX_LEN=32768: every layer but the TSP layer deferred (+2 GB of K/V "
-                                                      "held until the forward pass ends); not the default"}
+                                              "note": "FASTKV_DEFER_MAX_LEN=32768: every layer but the TSP layer waits for the end of the "
+                                                      "forward pass (+2 GB of K/V held); not the default"}
             # the same step with the K/V rows in ascending position (FASTKV_KV_ORDER=index; attention does not depend on the row
             # order): the 16 post-TSP layers keep every candidate and become single copy launches
             for c in work.clusters:

@@ -104,79 +104,87 @@ class FastKVCluster:
 
 
 class DeferredCompression:
-    """Compression of several layers in ONE launch sequence at the end of the forward pass.
+    """Compression of several layers in ONE launch sequence instead of one sequence per layer.
 
     The reference compresses layer by layer inside the attention forward (llama_model.py:136-142), but nothing reads a
-    layer's compressed cache before decode -- only the TSP layer's index is needed while the prompt is still in flight.  The
-    layers behind the TSP layer see 2048 tokens each: their launches are all latency (16.5 + 8.2 us per layer for 8 MiB of
-    traffic).  An attention module hands such a layer's q / k / v over with `add`; `flush` groups the collected layers by
-    geometry and runs `ops.update_kv_entries` (device-side pointer tables: no stacking copies) per group -- 16 post-TSP layers
-    in 114 us instead of 407 us -- and returns (layer_idx, k_compressed, v_compressed) in layer order for the cache.
-    `max_len` bounds which layers are taken: 4096 by default (the layers behind the TSP layer).  With FASTKV_DEFER_MAX_LEN at
-    the prompt length the layers in front of the TSP layer are deferred too and run two per launch sequence at 32k (135 -> 122
-    us per pair) -- at the price of keeping their full K/V alive until the end of the forward pass (2 GB at 32k).
+    layer's compressed cache before decode -- only the TSP layer's index is needed while the prompt is still in flight.  An
+    attention module hands a layer's q / k / v over with `add`; layers of one geometry are then compressed together through
+    `ops.update_kv_entries` (device-side pointer tables: no stacking copies).  Two regimes:
+      * short layers (<= `max_len` tokens: the layers behind the TSP layer, whose launches are all latency -- 16.5 + 8.2 us per
+        layer for 8 MiB of traffic) wait for `flush` at the end of the forward pass: 16 post-TSP layers in 114 us instead of 407;
+      * long layers wait for ONE peer only (`hold_long`, default 2: what the fused scoring kernel holds resident at 32k): the pair
+        runs as soon as the second layer arrives -- 135 -> 122 us per pair at 32k -- so that no more than one layer's full K/V
+        (128 MiB at 32k) is kept alive beyond its own attention.  `hold_long = 0` with `max_len` at the prompt length defers
+        every layer to the end (two per launch sequence all the same, but 2 GB of K/V held at 32k).
+    `add` returns None when the layer keeps everything (utils.py:89-91: the caller caches K/V as they are), else the list of
+    (layer_idx, k_compressed, v_compressed) that became ready with this call (usually empty); `flush` returns the rest.
     Same rows, same order as the per-layer calls (tests/test_wiring_gpu.py)."""
 
     _max_entries = {}                                              # geometry -> entries per launch sequence (process-wide)
 
-    def __init__(self, max_len: int = 4096):
+    def __init__(self, max_len: int = 4096, hold_long: int = 2):
         self.max_len = max_len
-        self.items = []
+        self.hold_long = hold_long
+        self.groups = {}
 
     def eligible(self, cluster, key_states, query_states) -> bool:
         # (an instance whose update_kv was wrapped -- a spy, an adapter -- expects to be called: not deferred)
         return (type(cluster) is FastKVCluster and "update_kv" not in vars(cluster) and not cluster.tsp_layer
                 and key_states.is_cuda and key_states.dtype == torch.float16
-                and query_states.dtype == torch.float16 and key_states.shape[0] == 1 and key_states.shape[2] <= self.max_len)
+                and query_states.dtype == torch.float16 and key_states.shape[0] == 1
+                and (key_states.shape[2] <= self.max_len or self.hold_long >= 2))
 
-    def add(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None) -> bool:
-        """True: taken (the cache entry comes from `flush`).  False: the layer keeps everything (utils.py:89-91) -- the caller
-        caches key_states / value_states as they are.  `out_factory` as in FastKVCluster.update_kv: the compacted rows are
-        written straight into the views it returns (a layer's cache slab)."""
+    def add(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None):
         plan = cluster.plan(query_states.shape[2])
         if plan.early_out:
-            return False
+            return None
         outs = None
         if out_factory is not None:
             B, Hkv, _, D = key_states.shape
             outs = out_factory(B, Hkv, plan.capacity, D, key_states.dtype, key_states.device)
-        self.items.append((layer_idx, (cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order),
-                           query_states, key_states, value_states, outs))
-        return True
+        q, k, v = query_states, key_states, value_states
+        key = ((cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order), tuple(q.shape), q.stride(),
+               tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
+        pending = self.groups.setdefault(key, [])
+        pending.append((layer_idx, q, k, v, outs))
+        if k.shape[2] > self.max_len:
+            # a long layer: run as soon as a launch sequence is full (or at once if this geometry only ever runs alone)
+            if len(pending) >= max(1, min(self.hold_long, self._max_entries.get(key, self.hold_long))):
+                return self._run(key)
+        return []
 
     def flush(self):
-        groups = {}
-        for it in self.items:
-            _, params, q, k, v, outs = it
-            key = (params, tuple(q.shape), q.stride(), tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
-            groups.setdefault(key, []).append(it)
-        self.items = []
         done = []
-        for key, its in groups.items():
-            window, ksize, pooling, cap, order = key[0]
-            # as many entries per launch sequence as the fused scoring kernel holds resident for this geometry (found by halving,
-            # remembered per geometry): all 16 post-TSP layers at once, two 32k layers, one entry at a time off the fused path
-            pos = 0
-            while pos < len(its):
-                n = min(self._max_entries.get(key, len(its)), len(its) - pos)
-                if torch.cuda.is_current_stream_capturing():
-                    n = 1                                        # (the entries call stages its address tables through the host)
-                chunk = its[pos:pos + n]
-                qs, ks, vs = [i[2] for i in chunk], [i[3] for i in chunk], [i[4] for i in chunk]
-                outs = None if chunk[0][5] is None else ([i[5][0] for i in chunk], [i[5][1] for i in chunk])
-                if n >= 2:
-                    try:
-                        k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order, outs=outs)
-                    except (FastKVNativeError, AssertionError):  # more than fits, off the fused path, or a misaligned view
-                        self._max_entries[key] = n // 2 if n > 3 else n - 1
-                        continue
-                else:
-                    k_outs, v_outs, _ = ops.update_kv(qs[0], ks[0], vs[0], window, ksize, pooling, cap, 0, order,
-                                                      out=None if outs is None else (outs[0][0], outs[1][0]))
-                    k_outs, v_outs = [k_outs], [v_outs]
-                done += [(i[0], ko, vo) for i, ko, vo in zip(chunk, k_outs, v_outs)]
-                pos += n
+        for key in list(self.groups):
+            done += self._run(key)
         return sorted(done, key=lambda t: t[0])
+
+    def _run(self, key):
+        its = self.groups.pop(key, [])
+        window, ksize, pooling, cap, order = key[0]
+        done, pos = [], 0
+        # as many entries per launch sequence as the fused scoring kernel holds resident for this geometry (found by shrinking,
+        # remembered per geometry): all 16 post-TSP layers at once, two 32k layers, one entry at a time off the fused path
+        while pos < len(its):
+            n = min(self._max_entries.get(key, len(its)), len(its) - pos)
+            if torch.cuda.is_current_stream_capturing():
+                n = 1                                            # (the entries call stages its address tables through the host)
+            chunk = its[pos:pos + n]
+            qs, ks, vs = [i[1] for i in chunk], [i[2] for i in chunk], [i[3] for i in chunk]
+            outs = None if chunk[0][4] is None else ([i[4][0] for i in chunk], [i[4][1] for i in chunk])
+            if n >= 2:
+                try:
+                    k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order, outs=outs)
+                except (FastKVNativeError, AssertionError):      # more than fits, off the fused path, or a misaligned view
+                    self._max_entries[key] = n // 2 if n > 3 else n - 1
+                    continue
+            else:
+                k_outs, v_outs, _ = ops.update_kv(qs[0], ks[0], vs[0], window, ksize, pooling, cap, 0, order,
+                                                  out=None if outs is None else (outs[0][0], outs[1][0]))
+                k_outs, v_outs = [k_outs], [v_outs]
+            done += [(i[0], ko, vo) for i, ko, vo in zip(chunk, k_outs, v_outs)]
+            pos += n
+        return done
 
 
 def init_fastkv(self):

@@ -118,18 +118,18 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     from benchmark import prefill
     from fastkv_amd import ops
 
-    def run(defer, slab="0"):
+    def run(defer, slab="0", tsp_idx="0", S=3000):
         monkeypatch.setenv("FASTKV_DEFER", defer)
         monkeypatch.setenv("FASTKV_SLAB_CACHE", slab)
         a = prefill.parse_args(["--model_path", "llama3-8b", "--num_layers", "6", "--device", "cuda", "--save_txt", "", "--method",
-                                "fastkv", "--max_capacity_prompts", "512", "--tsp_len", "1024", "--tsp_idx", "0", "--pooling", "maxpool"])
+                                "fastkv", "--max_capacity_prompts", "512", "--tsp_len", "1024", "--tsp_idx", tsp_idx, "--pooling", "maxpool"])
         a.save_txt = False
-        a.context_lengths = [3000]
+        a.context_lengths = [S]
         replace_llama("fastkv")
         torch.manual_seed(11)
         model = prefill.build_model(a, "cuda")
         set_model(model, a)
-        ids = torch.randint(0, 1000, (1, 3000), generator=torch.Generator().manual_seed(12)).cuda()
+        ids = torch.randint(0, 1000, (1, S), generator=torch.Generator().manual_seed(12)).cuda()
         with torch.no_grad():
             out = model(ids, attention_mask=torch.ones_like(ids))
             nxt = out.logits[:, -1].argmax(-1, keepdim=True)
@@ -148,9 +148,19 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     assert torch.equal(l1, l0) and torch.equal(d1, d0) and len(c1) == len(c0) == 6
     for (k1, v1), (k0, v0) in zip(c1, c0):
         assert torch.equal(k1, k0) and torch.equal(v1, v0)
+    # long layers in front of the TSP layer wait for ONE peer: layers 0 and 1 of a 5000-token prompt run as a pair when layer 1
+    # arrives, layer 2 alone at the end (its peer would be the TSP layer), layers 4 and 5 behind the TSP layer together
+    del calls[:]
+    lp, dp, cp = run("1", tsp_idx="3", S=5000)
+    assert calls == [2, 2]
+    lq, dq, cq = run("0", tsp_idx="3", S=5000)
+    assert calls == [2, 2] and torch.equal(lp, lq) and torch.equal(dp, dq)
+    for (k1, v1), (k0, v0) in zip(cp, cq):
+        assert torch.equal(k1, k0) and torch.equal(v1, v0)
+    del calls[:]
     # ... and over the slab cache: the deferred launch writes every layer's rows straight into that layer's slab
     ls, ds, cs = run("1", slab="1")
-    assert calls == [5, 5]
+    assert calls == [5]
     assert torch.equal(ls, l0) and len(cs) == 6
     for (k1, v1), (k0, v0) in zip(cs, c0):
         assert torch.equal(k1[:, :, :k0.shape[2]], k0) and torch.equal(v1[:, :, :v0.shape[2]], v0)
