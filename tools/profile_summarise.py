@@ -48,9 +48,18 @@ def kib(counter, prefix):
 
 fused = any(k.startswith("fk::score_fused") for k in pmc.get("FETCH_SIZE", {}))
 dom = "fk::score_fused" if fused else "fk::score_logits"
-lf, lw = kib("FETCH_SIZE", dom), kib("WRITE_SIZE", dom)
-cf, cw = kib("FETCH_SIZE", "fk::compact_kv"), kib("WRITE_SIZE", "fk::compact_kv")
-json.dump({
+# one 32k layer per launch: score_fused_kernel<128, 2, 2, 1>; two (the deferred schedule's pairs): <128, 4, 2, 1>
+one = "fk::score_fused_kernel<128, 2, 2, 1> grid=131072" if fused else dom
+lf, lw = kib("FETCH_SIZE", one), kib("WRITE_SIZE", one)
+pair = {}
+if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1>") for k in pmc.get("FETCH_SIZE", {})):
+    pf, pw = kib("FETCH_SIZE", "fk::score_fused_kernel<128, 4, 2, 1>"), kib("WRITE_SIZE", "fk::score_fused_kernel<128, 4, 2, 1>")
+    pair = {"score_fused_pair_hbm_bytes_per_launch": int((2 * pf + pw) * 1024), "score_fused_pair_fetch_kib_raw": pf,
+            "score_fused_pair_write_kib": pw,
+            "pair_note": "two 32k layers per launch (score_fused_kernel<128,4,2,1>): algorithmic 134.35 MB; four tiles per wave do not fit the "
+                         "256 registers of a wave at two waves per SIMD (236 B of scratch per lane): the spills are the extra writes and reads"}
+cf, cw = kib("FETCH_SIZE", "fk::compact_kv_kernel<16> grid=524288"), kib("WRITE_SIZE", "fk::compact_kv_kernel<16> grid=524288")
+json.dump({**pair, **{
     "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
               "--no-extras`, medians over launches; counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide 16-B/lane "
               "reads, guides/MI355X_MICROARCH.md HBM section; the compact kernel calibrates it: 2*FETCH = its 8.39 MB of row reads)",
@@ -60,6 +69,6 @@ json.dump({
     "compact_kv_fetch_kib_raw": cf, "compact_kv_write_kib": cw,
     "note": "dominant kernel: 2*FETCH = K once + Q window (algorithmic 67.17 MB) + hand-off records; WRITE = the fp16 window-row "
             "sums hs (score_fused) or the fp16 logits (score_logits)",
-}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+}}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_fk_kernels_by_grid.csv")).read())
 print(open(os.path.join(P, "traffic.json")).read())
