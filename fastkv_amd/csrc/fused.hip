@@ -201,7 +201,12 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][NW];
-    float ev[PER][2][NW];
+    // The exponentials of phase B are kept for phase C -- except with four tiles per wave (two 32k layers per launch): 128 more
+    // registers do not fit next to the packed logits, and recomputing them (the same function of the same operands: the same
+    // bits) costs less than spilling them.
+    constexpr bool KEEP_E = PER < 4;
+    float ev[KEEP_E ? PER : 1][2][NW];
+    bool gm_finite_c = true;                                     // (phase B's wave-uniform choice of the exponential, for phase C)
     uint32_t tile_nan = 0;                                       // bit t: tile t's contraction held a NaN (wave-uniform)
 
     // ================================================================ phase A of stream s: logits of its tiles, row maxima,
@@ -360,6 +365,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
         for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; gm_ok = gm_ok && __builtin_fabsf(gm[i]) < INFINITY; }
         const bool gm_finite = __all(gm_ok);                         // wave-uniform: +-inf or NaN row maxima send every tile the general way
+        gm_finite_c = gm_finite;
 #pragma unroll
         for (int lt = 0; lt < PS; ++lt) {
             constexpr int t0 = s * PS;
@@ -376,8 +382,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     const int rB = NB == 2 ? i : (i + 8) & 15;
                     const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
                     const f32x2 e = det_expf2_clamped(x - (f32x2){gm[i], gm[rB]});
-                    ev[t][0][i] = e.x;
-                    ev[t][1][i] = e.y;
+                    if (KEEP_E) { ev[KEEP_E ? t : 0][0][i] = e.x; ev[KEEP_E ? t : 0][1][i] = e.y; }
                     uint32_t h0, l0, h1, l1;
                     exp_to_fix2(e, h0, l0, h1, l1);
                     if (NB == 2) {
@@ -395,8 +400,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     const int rB = NB == 2 ? i : (i + 8) & 15;
                     const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
                     const f32x2 e = det_expf2(x - (f32x2){gm[i], gm[rB]});
-                    ev[t][0][i] = e.x;
-                    ev[t][1][i] = e.y;
+                    if (KEEP_E) { ev[KEEP_E ? t : 0][0][i] = e.x; ev[KEEP_E ? t : 0][1][i] = e.y; }
                     uint32_t h0, l0, h1, l1;
                     exp_to_fix2(e, h0, l0, h1, l1);
                     const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
@@ -504,9 +508,13 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         constexpr int s = decltype(sc)::value;
         float(*tile)[TW] = tile_of(s);
         uint32_t *s_hist = hist_of(s);
-        float ri[16];
+        float ri[16], gmc[KEEP_E ? 1 : 16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) ri[i] = s_ri[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
+        if (!KEEP_E) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gmc[KEEP_E ? 0 : i] = s_gm[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
+        }
         FKF_STAMP(29);
         if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
@@ -522,7 +530,18 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
-                    const f32x2 pr = (f32x2){ev[t][0][wd], ev[t][1][wd]} * (f32x2){ri[wd], ri[rB]};
+                    f32x2 ee;
+                    if (KEEP_E) {
+                        ee = (f32x2){ev[KEEP_E ? t : 0][0][wd], ev[KEEP_E ? t : 0][1][wd]};
+                    } else {
+                        // phase B's exponential again: the same function (clamped for full tiles of finite logits under finite row
+                        // maxima, general otherwise) of the same operands
+                        const f32x2 x = {h2f((uint16_t)(lg[t][wd] & 0xffffu)), h2f((uint16_t)(lg[t][wd] >> 16))};
+                        const f32x2 dx = x - (f32x2){gmc[KEEP_E ? 0 : wd], gmc[KEEP_E ? 0 : rB]};
+                        const bool fast = tile_wt(t) * TK + TK <= S && !((tile_nan >> t) & 1u) && gm_finite_c;
+                        ee = fast ? det_expf2_clamped(dx) : det_expf2(dx);
+                    }
+                    const f32x2 pr = ee * (f32x2){ri[wd], ri[rB]};
                     const uint32_t ph = f2h2(pr.x, pr.y);                                 // utils.py:103 -> fp16
                     p[u] = (f32x2){h2f((uint16_t)(ph & 0xffffu)), h2f((uint16_t)(ph >> 16))};
                 }
