@@ -378,9 +378,26 @@ def decode_step_attention(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Ten
 _ptr_ring = {}
 
 
+_ptr_cache = {}
+
+
 def _device_ptr_table(rows, device: torch.device) -> torch.Tensor:
-    """int64 [len(rows), n] on `device` from lists of addresses: staged through a small ring of pinned host buffers (the copy
-    is asynchronous on the current stream; a buffer is reused only after the copy that read it has completed)."""
+    """int64 [len(rows), n] on `device` from lists of addresses.  A table only holds addresses, so a table built once for a
+    set of addresses is good for ever: tables are cached by their content (a caching allocator hands a model the same blocks
+    prompt after prompt -- no copy at all in the steady state).  A miss is staged through a small ring of pinned host buffers
+    (asynchronous copy on the current stream; a buffer is reused only after the copy that read it has completed)."""
+    key = (device.index, _stream(), tuple(map(tuple, rows)))
+    hit = _ptr_cache.get(key)
+    if hit is not None:
+        return hit
+    tab = _stage_ptr_table(rows, device)
+    if len(_ptr_cache) >= 256:
+        _ptr_cache.clear()
+    _ptr_cache[key] = tab
+    return tab
+
+
+def _stage_ptr_table(rows, device: torch.device) -> torch.Tensor:
     if torch.cuda.is_current_stream_capturing():
         # a replay would re-read the pinned staging buffer, which other calls have rewritten since
         raise RuntimeError("fastkv_amd.update_kv_entries cannot be captured in a HIP graph (its address tables are staged through "
