@@ -494,8 +494,8 @@ def main():
                       "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
            "ttft_hotpath_ms": round(ms_per_step, 4)}
     out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
-                                 "sequence after the last layer, the layers in front of it in pairs (a layer waits for one peer: 128 MiB of "
-                                 "K/V held one layer longer); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
+                                 "sequence after the last layer, the layers in front of it in pairs (a layer waits for one peer: its q / k / v, "
+                                 "400 MiB, held one layer longer); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
 
     if not a.no_extras:
         # instrumented replay of the same steps: per-kernel HIP-event durations on the launch stream

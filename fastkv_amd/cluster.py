@@ -113,8 +113,8 @@ class DeferredCompression:
       * short layers (<= `max_len` tokens: the layers behind the TSP layer, whose launches are all latency -- 16.5 + 8.2 us per
         layer for 8 MiB of traffic) wait for `flush` at the end of the forward pass: 16 post-TSP layers in 114 us instead of 407;
       * long layers wait for ONE peer only (`hold_long`, default 2: what the fused scoring kernel holds resident at 32k): the pair
-        runs as soon as the second layer arrives -- 135 -> 122 us per pair at 32k -- so that no more than one layer's full K/V
-        (128 MiB at 32k) is kept alive beyond its own attention.  `hold_long = 0` with `max_len` at the prompt length defers
+        runs as soon as the second layer arrives -- 135 -> 122 us per pair at 32k -- so that no more than one layer's full q / k / v
+        (400 MiB at 32k, the query tensor included) is kept alive beyond its own attention.  `hold_long = 0` with `max_len` at the prompt length defers
         every layer to the end (two per launch sequence all the same, but 2 GB of K/V held at 32k).
     `add` returns None when the layer keeps everything (utils.py:89-91: the caller caches K/V as they are), else the list of
     (layer_idx, k_compressed, v_compressed) that became ready with this call (usually empty); `flush` returns the rest.
