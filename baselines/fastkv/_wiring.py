@@ -138,13 +138,23 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                         # full current K/V either way
                         self.tsp_idx = None
                         k_c = v_c = None
-                        ready = fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states,
-                                                 out_factory=slab.prefill_views if isinstance(slab, SlabLayer) else None)
-                        if ready is None:
-                            k_c, v_c = key_states, value_states
+                        of = slab.prefill_views if isinstance(slab, SlabLayer) else None
+                        if self.kv_cluster.tsp_layer:              # needed at once; takes a waiting peer along
+                            res = fastkv_defer.add_tsp_layer(self.layer_idx, self.kv_cluster, key_states, query_states, value_states,
+                                                             out_factory=of)
+                            if res is None:
+                                k_c, v_c = key_states, value_states
+                            else:
+                                k_c, v_c, self.tsp_idx, ready = res
+                                for idx, kr, vr in ready:
+                                    past_key_values.update(kr, vr, idx)
                         else:
-                            for idx, kr, vr in ready:              # (a launch sequence became full: this layer and its peer)
-                                past_key_values.update(kr, vr, idx)
+                            ready = fastkv_defer.add(self.layer_idx, self.kv_cluster, key_states, query_states, value_states, out_factory=of)
+                            if ready is None:
+                                k_c, v_c = key_states, value_states
+                            else:
+                                for idx, kr, vr in ready:          # (a launch sequence became full: this layer and its peer)
+                                    past_key_values.update(kr, vr, idx)
                     elif isinstance(slab, SlabLayer) and key_states.is_cuda and getattr(self.kv_cluster, "supports_out_factory", False):
                         # the compaction writes straight into the layer's cache slab; `update` then only adopts the rows
                         k_c, v_c, self.tsp_idx = self.kv_cluster.update_kv(key_states, query_states, value_states, attention_mask,

@@ -97,13 +97,26 @@ class HotPathPrefill:
         defer = DeferredCompression(max_len=self.defer_max_len, hold_long=self.defer_hold) if self.defer else None
         for i, (q, k, v) in enumerate(self.layers_in):
             cl = self.clusters[i]
-            if defer is not None and defer.eligible(cl, k, q):
+            if defer is not None and defer.eligible(cl, k, q) and not cl.tsp_layer:
                 ready = defer.add(i, cl, k, q, v)
                 if ready is None:
                     cache[i] = (k, v)
                 else:
                     for j, ko, vo in ready:
                         cache[j] = (ko, vo)
+                continue
+            if defer is not None and defer.eligible(cl, k, q) and cl.tsp_layer:
+                res = defer.add_tsp_layer(i, cl, k, q, v)                    # runs now, with the waiting layer 14 as its peer
+                if res is None:
+                    cache[i] = (k, v)
+                    continue
+                ko, vo, tsp, ready = res
+                cache[i] = (ko, vo)
+                for j, kr, vr in ready:
+                    cache[j] = (kr, vr)
+                if tsp is not None:
+                    hidden = ops.gather_rows(self.hidden, tsp)               # llama_model.py:255-257
+                    _pos = torch.gather(self.position_ids, 1, tsp)           # llama_model.py:254 (16 KiB)
                 continue
             ko, vo, tsp = cl.update_kv(k, q, v, None, G, i)
             cache[i] = (ko, vo)

@@ -129,12 +129,44 @@ class DeferredCompression:
 
     def eligible(self, cluster, key_states, query_states) -> bool:
         # (an instance whose update_kv was wrapped -- a spy, an adapter -- expects to be called: not deferred)
-        return (type(cluster) is FastKVCluster and "update_kv" not in vars(cluster) and not cluster.tsp_layer
+        return (type(cluster) is FastKVCluster and "update_kv" not in vars(cluster)
                 and key_states.is_cuda and key_states.dtype == torch.float16
                 and query_states.dtype == torch.float16 and key_states.shape[0] == 1
                 and (key_states.shape[2] <= self.max_len or self.hold_long >= 2))
 
+    def add_tsp_layer(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None):
+        """The TSP layer cannot wait (its index is needed at once), but it can take a WAITING peer of its geometry along: the
+        pair runs now, with the TSP selection computed for both entries and the peer's discarded.  Returns
+        (k_compressed, v_compressed, tsp_idx, ready) -- `ready` = the peer's (layer_idx, k, v), if there was one -- or None when
+        the layer keeps everything (utils.py:89-91)."""
+        plan = cluster.plan(query_states.shape[2])
+        if plan.early_out:
+            return None
+        outs = None
+        if out_factory is not None:
+            B, Hkv, _, D = key_states.shape
+            outs = out_factory(B, Hkv, plan.capacity, D, key_states.dtype, key_states.device)
+        q, k, v = query_states, key_states, value_states
+        key = ((cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order), tuple(q.shape), q.stride(),
+               tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
+        peers = self.groups.get(key, [])
+        if plan.tsp_len and len(peers) == 1 and self._max_entries.get(key, 2) >= 2 and not torch.cuda.is_current_stream_capturing():
+            peer = peers[0]
+            try:
+                o = None if outs is None else ([peer[4][0], outs[0]], [peer[4][1], outs[1]])
+                k_outs, v_outs, tsp = ops.update_kv_entries([peer[1], q], [peer[2], k], [peer[3], v], cluster.window_size,
+                                                            cluster.kernel_size, cluster.pooling, plan.capacity, plan.tsp_len,
+                                                            cluster.kv_order, outs=o)
+                self.groups.pop(key)
+                return k_outs[1], v_outs[1], tsp[1:2], [(peer[0], k_outs[0], v_outs[0])]
+            except (FastKVNativeError, AssertionError):
+                pass
+        ko, vo, tsp = ops.update_kv(q, k, v, cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, plan.tsp_len,
+                                    cluster.kv_order, out=outs)
+        return ko, vo, tsp, []
+
     def add(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None):
+        assert not cluster.tsp_layer, "the TSP layer goes through add_tsp_layer"
         plan = cluster.plan(query_states.shape[2])
         if plan.early_out:
             return None

@@ -149,12 +149,12 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     for (k1, v1), (k0, v0) in zip(c1, c0):
         assert torch.equal(k1, k0) and torch.equal(v1, v0)
     # long layers in front of the TSP layer wait for ONE peer: layers 0 and 1 of a 5000-token prompt run as a pair when layer 1
-    # arrives, layer 2 alone at the end (its peer would be the TSP layer), layers 4 and 5 behind the TSP layer together
+    # arrives, layer 2 waits and is taken along by the TSP layer (3), layers 4 and 5 behind the TSP layer run together at the end
     del calls[:]
     lp, dp, cp = run("1", tsp_idx="3", S=5000)
-    assert calls == [2, 2]
+    assert calls == [2, 2, 2]
     lq, dq, cq = run("0", tsp_idx="3", S=5000)
-    assert calls == [2, 2] and torch.equal(lp, lq) and torch.equal(dp, dq)
+    assert calls == [2, 2, 2] and torch.equal(lp, lq) and torch.equal(dp, dq)
     for (k1, v1), (k0, v0) in zip(cp, cq):
         assert torch.equal(k1, k0) and torch.equal(v1, v0)
     del calls[:]
