@@ -15,8 +15,8 @@ G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(G, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)      # (a tag that was run again: the newest files)
+    return f[-1] if f else None
 
 
 shutil.copy(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_bench.json"))
