@@ -1,0 +1,96 @@
+"""Host logic of fastkv_amd.cluster.DeferredCompression on the CPU: which layers run together, when, and what happens when a
+launch sequence refuses more entries than it can hold.  The device calls are replaced by recorders (the product has no CPU
+path; the kernels themselves are checked on the GPU: tests/test_hip_parity.py, tests/test_wiring_gpu.py)."""
+import pytest
+import torch
+
+from fastkv_amd import cluster as C
+from fastkv_amd._lib import FastKVNativeError
+
+
+class Recorder:
+    def __init__(self, max_entries):
+        self.max_entries, self.calls = max_entries, []
+
+    def entries(self, qs, ks, vs, window, ksize, pooling, cap, tsp_len=0, order="score", outs=None, return_indices=False):
+        if len(qs) > self.max_entries:
+            raise FastKVNativeError("unsupported configuration")
+        self.calls.append(("entries", len(qs), tsp_len))
+        n = len(qs)
+        ko = [torch.full((1, 2, cap, 4), float(k[0, 0, 0, 0])) for k in ks]
+        tsp = torch.arange(n * tsp_len).view(n, tsp_len) if tsp_len else None
+        return ko, [t.clone() for t in ko], tsp
+
+    def single(self, q, k, v, window, ksize, pooling, cap, tsp_len=0, order="score", out=None, **kw):
+        self.calls.append(("single", 1, tsp_len))
+        ko = torch.full((1, 2, cap, 4), float(k[0, 0, 0, 0]))
+        return ko, ko.clone(), (torch.arange(tsp_len)[None] if tsp_len else None)
+
+
+def _layer(i, S):
+    k = torch.full((1, 2, S, 4), float(i), dtype=torch.float16)
+    return torch.zeros(1, 8, S, 4, dtype=torch.float16), k, k.clone()
+
+
+@pytest.fixture
+def rec(monkeypatch):
+    r = Recorder(max_entries=2)
+    monkeypatch.setattr(C.ops, "update_kv_entries", r.entries)
+    monkeypatch.setattr(C.ops, "update_kv", r.single)
+    monkeypatch.setattr(C.DeferredCompression, "_max_entries", {})
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    return r
+
+
+def _cluster(tsp_layer=False, cap=16, tsp_length=64):
+    c = C.FastKVCluster()
+    c.max_capacity_prompt, c.tsp_layer, c.tsp_length, c.window_size, c.kernel_size = cap, tsp_layer, tsp_length, 8, 7
+    return c
+
+
+def test_long_layers_pair_up_and_the_tsp_layer_takes_its_peer_along(rec):
+    d = C.DeferredCompression(max_len=100, hold_long=2)
+    done = {}
+    for i in range(5):                                             # layers 0..4 long, layer 5 = TSP layer
+        q, k, v = _layer(i, 1000)
+        ready = d.add(i, _cluster(), k, q, v)
+        for j, ko, vo in ready:
+            done[j] = float(ko[0, 0, 0, 0])
+    assert rec.calls == [("entries", 2, 0), ("entries", 2, 0)] and sorted(done) == [0, 1, 2, 3]     # layer 4 waits
+    q, k, v = _layer(5, 1000)
+    ko, vo, tsp, ready = d.add_tsp_layer(5, _cluster(tsp_layer=True), k, q, v)
+    assert rec.calls[-1] == ("entries", 2, 64) and [r[0] for r in ready] == [4]
+    assert float(ko[0, 0, 0, 0]) == 5.0 and float(ready[0][1][0, 0, 0, 0]) == 4.0                  # own rows / the peer's rows
+    assert tsp.shape == (1, 64) and int(tsp[0, 0]) == 64                                             # the TSP layer's row of the pair
+    assert d.flush() == []
+    for j, val in done.items():
+        assert val == float(j)
+
+
+def test_short_layers_wait_for_the_end_and_shrink_to_what_fits(rec):
+    rec.max_entries = 3
+    d = C.DeferredCompression(max_len=4096, hold_long=2)
+    for i in range(7):
+        q, k, v = _layer(i, 200)
+        assert d.add(i, _cluster(), k, q, v) == []
+    out = d.flush()
+    assert [o[0] for o in out] == list(range(7)) and all(float(o[1][0, 0, 0, 0]) == float(o[0]) for o in out)
+    assert rec.calls == [("entries", 3, 0), ("entries", 3, 0), ("single", 1, 0)]                      # 7 refused, 3 fits: 3 + 3 + 1
+    # the limit is remembered per geometry: the next prompt asks for 3 at once
+    rec.calls.clear()
+    for i in range(3):
+        q, k, v = _layer(i, 200)
+        d.add(i, _cluster(), k, q, v)
+    d.flush()
+    assert rec.calls == [("entries", 3, 0)]
+
+
+def test_layers_that_keep_everything_are_not_taken(rec):
+    d = C.DeferredCompression()
+    q, k, v = _layer(0, 10)
+    assert d.add(0, _cluster(cap=512), k, q, v) is None and d.add_tsp_layer(1, _cluster(True, cap=512), k, q, v) is None
+    assert rec.calls == [] and d.flush() == []
+    # a TSP layer without a waiting peer runs alone, at once
+    q, k, v = _layer(2, 1000)
+    ko, vo, tsp, ready = d.add_tsp_layer(2, _cluster(tsp_layer=True), k, q, v)
+    assert rec.calls == [("single", 1, 64)] and ready == [] and tsp.shape == (1, 64)
