@@ -15,6 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 dev = torch.device("cuda:0")
 t0 = time.time()
 fails = 0
+n_entries_runs = n_entries_refused = 0
 main_stream = torch.cuda.current_stream()
 side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 for it in range(N):
@@ -70,6 +71,30 @@ for it in range(N):
     torch.cuda.synchronize()
     torch.cuda.set_stream(main_stream)
     ops.set_score_engine("auto")
+    if fusedish and B == 1 and rng.random() < 0.25:
+        # the same geometry as several SEPARATELY ALLOCATED entries in one launch sequence (fastkv_update_kv_ptrs_f16); refused
+        # (nothing launched) when that many do not fit the fused kernel's residency
+        ne = rng.choice([2, 2, 3, 5, 16])
+        ins = [(q, k, v)] + [make_qkv(9000 + it + 100000 * j, B, Hkv * G, Hkv, S, D, W, peaked=peaked) for j in range(1, ne)]
+        if S * ne * Hkv * D < 60e6:
+            try:
+                dq, dk, dv = ([t[j].transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in ins] for j in range(3))
+                ge = ops.update_kv_entries(dq, dk, dv, W, ks, pooling, cap, tsp_len, order, return_indices=True)
+                torch.cuda.synchronize()
+                n_entries_runs += 1
+                for j, (qj, kj, vj) in enumerate(ins):
+                    wj = want if j == 0 else O.update_kv(qj, kj, vj, W, ks, pooling, cap, tsp_len, order)
+                    okj = torch.equal(ge[0][j].cpu().view(torch.int16), wj[0].view(torch.int16)) and torch.equal(ge[3][j:j + 1].cpu(), wj[2]) and \
+                        torch.equal(ge[1][j].cpu().view(torch.int16), wj[1].view(torch.int16)) and \
+                        ((ge[2] is None and wj[3] is None) or torch.equal(ge[2][j:j + 1].cpu(), wj[3]))
+                    if not okj:
+                        fails += 1
+                        print("MISMATCH (entries)", tag, dict(entries=ne, entry=j), flush=True)
+                        break
+            except ops.FastKVNativeError if hasattr(ops, "FastKVNativeError") else Exception as e:
+                if "unsupported" not in str(e).lower():
+                    raise
+                n_entries_refused += 1
     if pre and not (torch.equal(c_only.cpu().view(torch.int16), want[4].view(torch.int16))):
         print("MISMATCH (scores-only entry point)", dict(it=it, engine=engine), flush=True)
         fails += 1
@@ -86,5 +111,5 @@ for it in range(N):
         gsc, wsc = got[4].cpu().view(torch.int16), want[4].view(torch.int16)
         for ix in (gsc != wsc).nonzero()[:16].tolist():
             print("   at", ix, "gpu %04x oracle %04x" % (int(gsc[tuple(ix)]) & 0xffff, int(wsc[tuple(ix)]) & 0xffff), flush=True)
-print(f"{N} cases, {fails} mismatches, {time.time() - t0:.0f} s")
+print(f"{N} cases, {fails} mismatches, {time.time() - t0:.0f} s (entries calls: {n_entries_runs} run, {n_entries_refused} refused)")
 sys.exit(1 if fails else 0)
