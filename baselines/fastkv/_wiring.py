@@ -85,7 +85,8 @@ def _static_layer(layer, x, position_embeddings, past_key_values):
     k = qkv[..., nq:nq + nk].view(B, 1, nk // D, D).transpose(1, 2)
     v = qkv[..., nq + nk:].view(B, 1, nk // D, D).transpose(1, 2)
     cos, sin = position_embeddings
-    a = ops.decode_step_attention(q, k, v, cos, sin, slab.kslab, slab.vslab, slab.len_dev, attn.scaling)
+    a = ops.decode_step_attention(q, k, v, cos, sin, slab.kslab, slab.vslab, slab.len_dev, attn.scaling, counters=slab.step_counters,
+                                  workspace=slab.decode_ws)
     slab.host_step()
     attn.tsp_idx = None
     h1 = ops.decode_gemv(a, [attn.o_proj.weight], residual=x)
@@ -173,7 +174,7 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                         # static decode over the slab: append + GQA attention through the HIP decode kernels, the length is a
                         # device-side counter -> no shape changes, the step is graph-capturable (fastkv_amd/cache.py)
                         ops.decode_append(slab.kslab, slab.vslab, key_states, value_states, slab.len_dev)
-                        attn_output = ops.decode_attention(query_states, slab.kslab, slab.vslab, slab.len_dev, self.scaling)
+                        attn_output = ops.decode_attention(query_states, slab.kslab, slab.vslab, slab.len_dev, self.scaling, workspace=slab.decode_ws)
                         slab.host_step()
                         return self.o_proj(attn_output.view(*input_shape, -1)), None
                     key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)
@@ -310,6 +311,14 @@ def make_model_forward(modeling, mask_fn_for):
         if defer is not None:
             for idx, k_c, v_c in defer.flush():                   # (layer order: the cache grows by appending)
                 past_key_values.update(k_c, v_c, idx)
+        if inputs_embeds.is_cuda and inputs_embeds.shape[1] > 1:
+            # Once per prefill: has a launch of this process given up a bounded in-kernel wait (include/fastkv_hip.h,
+            # "Residency")?  A host-only read of pinned memory, no synchronisation: it reports what has run by now -- the
+            # harnesses ask again behind their synchronisation point (benchmark/prefill.py, e2e.py), and any later operator call
+            # reports the rest.  The caches of this forward pass are invalid then: raise, never hand them to decode.
+            if os.environ.get("FASTKV_CHECK_SYNC", "0") == "1":   # debugging aid: wait for this stream, then the report is complete
+                torch.cuda.current_stream().synchronize()
+            ops.raise_if_aborted("prefill")
         hidden_states = _norm(self.norm, hidden_states, _static_step(past_key_values, hidden_states))
         hidden_states = hidden_states[:, -1:, :]                  # only the last token feeds lm_head
         if sp is not None and not sp.reduced:

@@ -439,6 +439,63 @@ def spawn_leg(name, idx, steps, rank, timeout_s=240):
     return {"status": "ok (no report on this rank)"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher around it (no RANK in the environment): start the N ranks the way the
+    contract's own command does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- as a CHILD process, pass its output through and exit with its code.  This
+    process makes no HIP call before or after (a process that has initialised the GPU must not be replaced or forked from),
+    so nothing is exec'ed: the launcher is an ordinary subprocess.  The legs' rendezvous ports are MASTER_PORT + 101.. (spawn_leg)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or 0) or _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                                        # ranks print nothing but rank 0's ONE JSON line on stdout
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but printed no contract line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def rehearse(a, rank, world) -> int:
+    """What tests/test_bench_contract.py runs on a box without a GPU: the launcher, the rendezvous and the one-line protocol of
+    an N-rank run, with nothing measured (value null, "rehearsal": true -- not a bench line)."""
+    seen, backend = 1, "none"
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("BENCH_BACKEND", "gloo")
+        dist.init_process_group(backend)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        assert int(t.item()) == world * (world + 1) // 2
+        seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "prefill_hotpath_tokens_per_s", "value": None, "rehearsal": True, "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ranks_seen": seen, "backend": backend}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,12 +506,19 @@ def main():
     ap.add_argument("--leg", choices=LEGS, default=None, help="internal: run ONE multi-GPU leg in this (child) process")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented replay / roofline-shape / CPU legs")
     ap.add_argument("--no-ttft", action="store_true", help="skip the whole-model TTFT leg (random-init Llama-3-8B, fastkv vs fullkv)")
+    ap.add_argument("--rehearse", action="store_true", help="launcher rehearsal (tests): the ranks rendezvous, exchange one all-reduce and "
+                    "rank 0 prints a line with value null -- no GPU work, nothing measured")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ and not a.leg:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU and never will)
+        return self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if a.rehearse:
+        return rehearse(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback for the product path)"
     if a.leg:
         return leg_child_main(a)
@@ -505,7 +569,9 @@ def main():
            "config": {"workload": "FastKV hot path (score+select+compact, 32 layers + TSP gather) of one Llama-3-8B prefill, "
                                   "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
                       "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
-           "ttft_hotpath_ms": round(ms_per_step, 4)}
+           "ttft_hotpath_ms": round(ms_per_step, 4),
+           "ranks_seen": dist.get_world_size() if dist is not None else 1,
+           "backend": (dist.get_backend() if dist is not None else "none")}
     out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
                                  "sequence after the last layer, the layers in front of it in pairs (a layer waits for one peer: its q / k / v, "
                                  "400 MiB, held one layer longer); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
@@ -676,4 +742,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -31,6 +31,7 @@ def graph_decode(model, pkv, tok, steps, timed):
     this stream and is a real, counted step), then ONE capture of the step and `steps - 1` replays.  Returns (ms, tokens)."""
     dev = tok.device
     pkv.enable_static_decode(steps + 8)
+    pkv.reserve_steps(steps)                                      # replays advance device-side lengths only: room for all of them, checked now
     tok_buf = tok.clone()
     # positions restart at the compressed length (reference e2e.py:82-90 passes no position_ids); kept on the device
     pos_buf = torch.full((tok.shape[0], 1), pkv.get_seq_length(), dtype=torch.int64, device=dev)
@@ -94,6 +95,7 @@ def main(model, args):
             out = fn()
             e.record()
             torch.cuda.synchronize()
+            P._raise_if_aborted()                                 # an abandoned launch / an overrun slab is an error of the run
             return s.elapsed_time(e), out
         t0 = time.perf_counter()
         out = fn()

@@ -69,6 +69,15 @@ def build_model(args, device):
     return model.eval()
 
 
+def _raise_if_aborted():
+    """After a synchronisation: did any launch of the run give up a bounded in-kernel wait (FASTKV_EABORTED)?  fullkv arms and
+    CPU runs never load the library, so only ask when it is loaded."""
+    import sys
+    lib = sys.modules.get("fastkv_amd._lib")
+    if lib is not None and lib._lib is not None:
+        lib.raise_if_aborted("benchmark")
+
+
 def main(model, args):
     from baselines.monkeypatch import set_model
     dev = next(model.parameters()).device
@@ -95,6 +104,7 @@ def main(model, args):
         if use_events:
             end.record()
             torch.cuda.synchronize()
+            _raise_if_aborted()                               # everything of this run has completed: an abandoned launch is an error
             return start.elapsed_time(end) / 1000.0, out
         return time.perf_counter() - t0, out
 

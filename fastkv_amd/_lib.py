@@ -10,8 +10,18 @@ import os
 from . import _build
 
 
+# return codes of the C ABI (include/fastkv_hip.h)
+FASTKV_OK, FASTKV_EINVAL, FASTKV_EWORKSPACE, FASTKV_ELAUNCH, FASTKV_EUNSUPPORTED, FASTKV_EABORTED, FASTKV_EOVERFLOW = 0, -1, -2, -3, -4, -5, -6
+
+
 class FastKVNativeError(RuntimeError):
-    pass
+    """`code` = the C ABI's return code (None when the library itself could not be loaded).  Callers may fall back to another
+    path on FASTKV_EUNSUPPORTED only; FASTKV_EABORTED / FASTKV_ELAUNCH mean a launch of this process went wrong and must
+    reach the user (fastkv_amd/cluster.py: DeferredCompression)."""
+
+    def __init__(self, msg: str, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 class Problem(ctypes.Structure):
@@ -135,4 +145,13 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().fastkv_strerror(rc).decode()
-        raise FastKVNativeError(f"fastkv_amd.{what}: {msg} (code {rc})")
+        raise FastKVNativeError(f"fastkv_amd.{what}: {msg} (code {rc})", code=rc)
+
+
+def raise_if_aborted(what: str = "last_status") -> None:
+    """Host-only read of the library's asynchronous-error word (fastkv_last_status): raises FastKVNativeError(FASTKV_EABORTED /
+    FASTKV_EOVERFLOW) if a launch of this process that has ALREADY RUN gave up a bounded in-kernel wait or overran a decode slab
+    since the last report.  Costs a load of pinned memory: no synchronisation.  Call it behind a synchronisation point to learn
+    about everything enqueued before it (benchmark/prefill.py, benchmark/e2e.py); the wiring also calls it un-synchronised at the
+    end of every prefill, which reports what has completed by then."""
+    check(load().fastkv_last_status(), what)

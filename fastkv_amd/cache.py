@@ -26,6 +26,8 @@ class SlabLayer(DynamicLayer):
         self.len = 0
         self.static_decode = False
         self.len_dev = None
+        self.step_counters = None
+        self.decode_ws = None
 
     def _alloc(self, B, H, rows, D, dtype, device):
         self.kslab = torch.empty(B, H, rows, D, dtype=dtype, device=device)
@@ -81,15 +83,34 @@ class SlabLayer(DynamicLayer):
         return self.len
 
     # ---- static decode: the length lives on the device, the kernels advance it
-    def enable_static_decode(self, extra_rows: int):
+    def enable_static_decode(self, extra_rows: int, shared=None):
+        """`shared` = (arrival counters, slice-record workspace) of the cache this layer belongs to (the layers of one cache run
+        one after the other, so they share them); a stand-alone layer gets its own."""
         assert self.kslab is not None and self.kslab.is_cuda, "static decode needs a prefilled slab on the GPU"
         if self.len + extra_rows > self.kslab.shape[2]:
             self._grow(self.len + extra_rows)
         self.len_dev = torch.tensor([self.len], dtype=torch.int32, device=self.kslab.device)
         self.static_decode = True
+        # What the step kernels keep between launches is allocated (and zeroed) NOW, eagerly, and owned by the cache -- never
+        # for the first time inside a graph capture, where the allocation would live in that graph's private pool, its zero-fill
+        # would be replayed with every step, and a later capture would find a tensor of a pool that may be gone (ADVICE r02).
+        from . import ops
+        if shared is None:
+            B, Hkv, _, D = self.kslab.shape
+            shared = (ops.new_step_counters(self.kslab.device), ops.new_decode_workspace(self.kslab.device, B, Hkv * 8, D))
+        self.step_counters, self.decode_ws = shared
+
+    def rows_left(self) -> int:
+        """Steps the slab still has room for (host mirror of the length; graph replays do not advance it -- see reserve_steps)."""
+        return self.kslab.shape[2] - self.len
 
     def host_step(self):
         """Host mirror of one decode step (the device-side length is advanced by the attention kernel)."""
+        if self.len >= self.kslab.shape[2]:
+            # the kernel clamps (the step's row overwrites the last cached row) and reports FASTKV_EOVERFLOW through
+            # fastkv_last_status; an eager caller learns it here, before the launch's results are used
+            raise RuntimeError(f"fastkv_amd.cache: static decode ran out of slab rows ({self.kslab.shape[2]}): "
+                               "enable_static_decode(extra_rows) reserved too few")
         self.len += 1
 
     def finish_static_decode(self, true_len=None):
@@ -111,8 +132,24 @@ class FastKVSlabCache(Cache):
         return bool(self.layers) and all(getattr(l, "static_decode", False) for l in self.layers)
 
     def enable_static_decode(self, extra_rows: int):
+        from . import ops
+        first = self.layers[0]
+        B, Hkv, _, D = first.kslab.shape
+        shared = (ops.new_step_counters(first.kslab.device), ops.new_decode_workspace(first.kslab.device, B, Hkv * 8, D))
         for l in self.layers:
-            l.enable_static_decode(extra_rows)
+            l.enable_static_decode(extra_rows, shared if l.kslab.device == first.kslab.device and l.kslab.shape[:2] == first.kslab.shape[:2]
+                                   and l.kslab.shape[3] == D else None)
+
+    def rows_left(self) -> int:
+        return min(l.rows_left() for l in self.layers)
+
+    def reserve_steps(self, steps: int) -> None:
+        """Before replaying a captured step `steps` times: the replays advance only the DEVICE-side lengths, nothing on the host
+        sees a slab fill up -- so the room is checked here, once, for all of them."""
+        left = self.rows_left()
+        if steps > left:
+            raise RuntimeError(f"fastkv_amd.cache: {steps} decode steps planned, the slabs have rows for {left}: "
+                               "call enable_static_decode with more extra_rows")
 
     def finish_static_decode(self):
         for l in self.layers:

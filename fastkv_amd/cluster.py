@@ -15,7 +15,7 @@ from typing import NamedTuple, Optional
 import torch
 
 from . import ops
-from ._lib import FastKVNativeError
+from ._lib import FASTKV_EUNSUPPORTED, FastKVNativeError
 
 
 class Plan(NamedTuple):
@@ -159,8 +159,12 @@ class DeferredCompression:
                                                             cluster.kv_order, outs=o)
                 self.groups.pop(key)
                 return k_outs[1], v_outs[1], tsp[1:2], [(peer[0], k_outs[0], v_outs[0])]
-            except (FastKVNativeError, AssertionError):
-                pass
+            except FastKVNativeError as e:
+                # Only "this pair cannot go through one launch sequence" (nothing was launched) sends the TSP layer on alone; the
+                # peer stays in its group for `flush`.  Anything else -- FASTKV_EABORTED from an EARLIER launch, FASTKV_ELAUNCH --
+                # is not this pair's to absorb: it must reach the caller.
+                if e.code != FASTKV_EUNSUPPORTED:
+                    raise
         ko, vo, tsp = ops.update_kv(q, k, v, cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, plan.tsp_len,
                                     cluster.kv_order, out=outs)
         return ko, vo, tsp, []
@@ -207,7 +211,15 @@ class DeferredCompression:
             if n >= 2:
                 try:
                     k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order, outs=outs)
-                except (FastKVNativeError, AssertionError):      # more than fits, off the fused path, or a misaligned view
+                except FastKVNativeError as e:
+                    # FASTKV_EUNSUPPORTED = more entries than the fused kernel holds resident, a geometry off the fused path or
+                    # entries of different layouts: nothing was launched, retry with fewer (remembered per geometry).  Every other
+                    # code (FASTKV_EABORTED: an earlier launch of this process gave up a wait and ITS outputs are invalid;
+                    # FASTKV_ELAUNCH) is an error of the run, not a property of the geometry: the pending entries go back so that a
+                    # caller who handles the error can flush again, `_max_entries` is left alone, and the error is raised.
+                    if e.code != FASTKV_EUNSUPPORTED:
+                        self.groups.setdefault(key, [])[:0] = its[pos:]
+                        raise
                     self._max_entries[key] = n // 2 if n > 3 else n - 1
                     continue
             else:

@@ -20,7 +20,8 @@ uint32_t *abort_flag_device()
         void *h = nullptr, *d = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return; }
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
-        *reinterpret_cast<volatile uint32_t *>(h) = 0;
+        reinterpret_cast<volatile uint32_t *>(h)[0] = 0;
+        reinterpret_cast<volatile uint32_t *>(h)[1] = 0;
         g_abort_host = reinterpret_cast<uint32_t *>(h);
         g_abort_dev = reinterpret_cast<uint32_t *>(d);
     });
@@ -38,8 +39,10 @@ uint64_t spin_limit_ticks()
 static int take_abort_status()
 {
     if (!g_abort_host) return FASTKV_OK;
-    if (__atomic_load_n(g_abort_host, __ATOMIC_ACQUIRE) == 0u) return FASTKV_OK;
-    return __atomic_exchange_n(g_abort_host, 0u, __ATOMIC_ACQ_REL) ? FASTKV_EABORTED : FASTKV_OK;
+    // word 0: a launch gave up a bounded in-kernel wait; word 1: a decode step ran into a full cache slab (decode.hip)
+    if (__atomic_load_n(g_abort_host, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EABORTED;
+    if (__atomic_load_n(g_abort_host + 1, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 1, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EOVERFLOW;
+    return FASTKV_OK;
 }
 }  // namespace fk
 
@@ -444,6 +447,9 @@ const char *fastkv_strerror(int code)
         return "an earlier fused launch gave up waiting for its co-resident workgroups (another kernel held compute units longer "
                "than FASTKV_SPIN_LIMIT_MS, or two such launches overlapped): the outputs of that call are invalid -- repeat it, "
                "with FASTKV_FUSED=0 if the GPU is shared";
+    case FASTKV_EOVERFLOW:
+        return "an earlier static-decode step ran into a full cache slab (more steps than enable_static_decode reserved rows for): "
+               "the last cached row was overwritten, the tokens from that step on are invalid";
     case FASTKV_EUNSUPPORTED: return "unsupported configuration (head_dim must be 64/128/256, S < 2^24)";
     default: return "unknown error";
     }

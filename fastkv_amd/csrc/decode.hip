@@ -43,6 +43,7 @@ struct StepArgs {
     const uint16_t *cosv, *sinv; int64_t cs_b;                   // [B,1,D]
     uint32_t *counters;                                          // [1 + B*Hkv], zero between launches
     uint16_t *out; int H;                                        // [B,1,H*D]
+    uint32_t *host_flag;                                         // pinned status words of the process (capi.hip); [1] = slab overrun
 };
 
 // rotate-half RoPE of element d of a head row x[0..D): the stock fp16 sequence (see decode_rope_kernel)
@@ -337,6 +338,9 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
         if (__hip_atomic_fetch_add(sa.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
             __hip_atomic_store(sa.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *len_dev = len_old + 1 < rows ? len_old + 1 : rows;
+            // a step into a FULL slab has overwritten the last cached row and the length stays where it is: wrong tokens from
+            // here on.  Reported, not silent: fastkv_last_status() / the next operator call return FASTKV_EOVERFLOW.
+            if (len_old >= rows && sa.host_flag) __hip_atomic_store(sa.host_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
 // grid (H, B), D threads; advances *len_dev (block 0, thread 0) -- every reader of the old length has finished by now
 template <int D>
 __global__ void __launch_bounds__(D) decode_combine_kernel(const float *__restrict__ part, int nsplit, uint16_t *__restrict__ out, int H,
-                                                           int32_t *__restrict__ len_dev, int rows)
+                                                           int32_t *__restrict__ len_dev, int rows, uint32_t *__restrict__ host_flag)
 {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float *rec = part + ((size_t)b * H + h) * nsplit * (D + 2);
@@ -358,7 +362,11 @@ __global__ void __launch_bounds__(D) decode_combine_kernel(const float *__restri
         O += rec[c * (D + 2) + 2 + d] * f;
     }
     out[((size_t)b * H + h) * D + d] = f2h(O / L);
-    if (h == 0 && b == 0 && d == 0 && len_dev) { const int n = *len_dev + 1; *len_dev = n < rows ? n : rows; }
+    if (h == 0 && b == 0 && d == 0 && len_dev) {
+        const int n = *len_dev + 1;
+        *len_dev = n < rows ? n : rows;
+        if (n > rows && host_flag) __hip_atomic_store(host_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // slab overrun (see the step kernel)
+    }
 }
 
 // ---- the step's small operators, one launch each (the stock modules run 7 / 8 / 2 elementwise launches for them) ----
@@ -508,9 +516,9 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
     }
     if (hipGetLastError() != hipSuccess) return FASTKV_ELAUNCH;
     ProfScope ps2_(K_DECODE, st);
-    if (D == 64) hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(H, B), dim3(64), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
-    else if (D == 128) hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(H, B), dim3(128), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
-    else hipLaunchKernelGGL((decode_combine_kernel<256>), dim3(H, B), dim3(256), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows);
+    if (D == 64) hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(H, B), dim3(64), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows, abort_flag_device());
+    else if (D == 128) hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(H, B), dim3(128), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows, abort_flag_device());
+    else hipLaunchKernelGGL((decode_combine_kernel<256>), dim3(H, B), dim3(256), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows, abort_flag_device());
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
@@ -535,7 +543,7 @@ int fastkv_decode_step_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t 
     sa.k_new = (const uint16_t *)k_new; sa.kn_b = kn_strides[0]; sa.kn_h = kn_strides[1];
     sa.v_new = (const uint16_t *)v_new; sa.vn_b = vn_strides[0]; sa.vn_h = vn_strides[1];
     sa.cosv = (const uint16_t *)cosv; sa.sinv = (const uint16_t *)sinv; sa.cs_b = cs_batch_stride;
-    sa.counters = (uint32_t *)counters; sa.out = (uint16_t *)out; sa.H = H;
+    sa.counters = (uint32_t *)counters; sa.out = (uint16_t *)out; sa.H = H; sa.host_flag = abort_flag_device();
     dim3 grid(nsplit, Hkv, B);
     ProfScope ps_(K_DECODE, st);
 #define FK_STEP(DV, GV)                                                                                                                 \

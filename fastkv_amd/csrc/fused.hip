@@ -153,7 +153,13 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // control block (fastkv_workspace_init): a missing initialisation must not turn into a silent wrong answer.  The token
     // of this launch is the epoch left by the previous one + 1 (the compaction kernel bumps it): never a launch argument,
     // which a graph replay would freeze; the granules in memory still carry earlier tokens (or whatever the allocation held).
-    if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) __builtin_trap();
+    if (*reinterpret_cast<const uint64_t *>(ctrl) != CTRL_MAGIC) {
+        // workspace never initialised (fastkv_workspace_init): no hand-off of this launch could be trusted.  Reported like an
+        // abandoned wait -- the process-wide flag in pinned host memory, FASTKV_EABORTED at the next call -- and every workgroup
+        // leaves at once (the condition is the same for all of them); nothing traps, the context stays usable.
+        if (threadIdx.x == 0) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const uint32_t token = handoff_token(ctrl[2]);
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (threadIdx.x == 0) s_abort = 0;
@@ -776,23 +782,25 @@ one_stream:
     // kernel, so that a second thread cannot slip its own launch in between.  Nothing is added while the caller stays on
     // one stream; inside a stream capture the chain is skipped (see include/fastkv_hip.h).
     static std::mutex mtx;
-    static hipStream_t last_stream[16];
+    static hipStream_t last_stream[16];                        // compared only, never passed to HIP again (the caller may have destroyed it)
     static bool have_last[16];
-    static hipEvent_t chain_ev[16];
+    static hipEvent_t chain_ev[16];                            // recorded on the launch's OWN stream, right behind the fused kernel
     std::lock_guard<std::mutex> lk(mtx);
+    int dev = -1;
+    bool chained = false;
     {
-        int dev = 0;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && hipStreamIsCapturing(st, &cs) == hipSuccess &&
             cs == hipStreamCaptureStatusNone) {
-            if (have_last[dev] && last_stream[dev] != st) {
-                if (!chain_ev[dev]) (void)hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming);
-                if (chain_ev[dev] && hipEventRecord(chain_ev[dev], last_stream[dev]) == hipSuccess)
-                    (void)hipStreamWaitEvent(st, chain_ev[dev], 0);
-                (void)hipGetLastError();                         // a destroyed previous stream is not this call's error
+            chained = true;
+            if (!chain_ev[dev] && hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) {
+                chain_ev[dev] = nullptr;
+                (void)hipGetLastError();
+                chained = false;
             }
-            last_stream[dev] = st;
-            have_last[dev] = true;
+            // the previous fused launch of this process ran on another stream: wait for the event recorded behind it
+            if (chained && have_last[dev] && last_stream[dev] != st) (void)hipStreamWaitEvent(st, chain_ev[dev], 0);
+            (void)hipGetLastError();
         }
     }
     ProfScope ps_(K_FUSED, st);
@@ -803,6 +811,10 @@ one_stream:
                              pt ? pt->k : nullptr);
     });
     *err = hipGetLastError();
+    if (chained && *err == hipSuccess) {
+        if (hipEventRecord(chain_ev[dev], st) == hipSuccess) { last_stream[dev] = st; have_last[dev] = true; }
+        else { (void)hipGetLastError(); have_last[dev] = false; }
+    }
     return true;
 }
 

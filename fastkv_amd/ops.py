@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import Problem, check, load
+from ._lib import FASTKV_EUNSUPPORTED, FastKVNativeError, Problem, check, load, raise_if_aborted  # noqa: F401
 
 POOLING = {"avgpool": 0, "maxpool": 1}
 ORDER = {"index": 0, "score": 1}
@@ -104,7 +104,10 @@ def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, ke
                 or ko.dtype != torch.float16 or vo.dtype != torch.float16:
             raise ValueError("fastkv_amd: out must be two [B,Hkv,capacity,D] fp16 views with equal strides and unit head_dim stride")
     ostr = (ctypes.c_int64 * 3)(*ko.stride()[:3])
-    tsp = torch.empty(B, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
+    # zeros, not empty: the ONE output that torch itself consumes as indices (torch.gather on the position ids, llama_model.py:254)
+    # -- an abandoned launch (FASTKV_EABORTED) leaves entries unwritten, and a stale index there would be a device-side assert
+    # in torch instead of a reported error; position 0 is always valid.  16 KiB memset once per prefill.
+    tsp = torch.zeros(B, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
     kv_idx = torch.empty(B, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
     sc = torch.empty(B, Hkv, p.S - window, dtype=torch.float16, device=dev) if return_scores else None
     nbytes = L.fastkv_workspace_bytes(ctypes.byref(p))
@@ -263,7 +266,7 @@ def decode_append(kslab: torch.Tensor, vslab: torch.Tensor, k_new: torch.Tensor,
 
 
 def decode_attention(q: torch.Tensor, kslab: torch.Tensor, vslab: torch.Tensor, len_dev: torch.Tensor, scaling: float,
-                     nsplit: int = 0) -> torch.Tensor:
+                     nsplit: int = 0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GQA attention of q [B,H,1,D] over slab rows 0 .. len_dev[0] (inclusive: the row decode_append just wrote) -> fp16
     [B,1,H*D]; advances len_dev on the device.  Static shapes: capturable in a HIP graph."""
     _require_cuda(q, kslab, vslab, len_dev)
@@ -273,7 +276,8 @@ def decode_attention(q: torch.Tensor, kslab: torch.Tensor, vslab: torch.Tensor, 
     nsplit = nsplit or DECODE_NSPLIT
     L = load()
     out = torch.empty(B, 1, H * D, dtype=torch.float16, device=q.device)
-    ws = _workspace(L.fastkv_decode_workspace_bytes(B, H, D, nsplit), q.device, "decode")
+    need = L.fastkv_decode_workspace_bytes(B, H, D, nsplit)
+    ws = workspace if workspace is not None and workspace.numel() >= need else _workspace(need, q.device, "decode")
     I2, I3 = ctypes.c_int64 * 2, ctypes.c_int64 * 3
     rc = L.fastkv_decode_attention_f16(B, H, Hkv, D, q.data_ptr(), I2(q.stride(0), q.stride(1)), kslab.data_ptr(), vslab.data_ptr(),
                                        I3(*kslab.stride()[:3]), rows, len_dev.data_ptr(), ctypes.c_float(scaling), nsplit,
@@ -346,8 +350,43 @@ def decode_gemv(x: torch.Tensor, weights, norm_weight: Optional[torch.Tensor] = 
 _step_counters = {}
 
 
+def new_step_counters(device: torch.device) -> torch.Tensor:
+    """Arrival counters of the fused step kernel (zero between launches).  A cache slab owns its own set (allocated eagerly by
+    SlabLayer.enable_static_decode -- never for the first time inside a graph capture, where the allocation would live in the
+    graph's private pool and its zero-fill would be replayed with every step), so steps over different caches may run
+    concurrently and a capture only ever records launches."""
+    return torch.zeros(1024, dtype=torch.int32, device=device)
+
+
+def new_decode_workspace(device: torch.device, B: int, H: int, D: int, nsplit: int = 0) -> torch.Tensor:
+    """Slice-record scratch of decode_attention / decode_step_attention for up to H query heads (uninitialised: every record is
+    written before it is read)."""
+    n = load().fastkv_decode_workspace_bytes(B, H, D, nsplit or DECODE_NSPLIT)
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+
+
+def _default_counters(device: torch.device) -> torch.Tensor:
+    # callers without a slab object (tests, tools): one set per (device, stream), allocated outside captures only
+    key = (device.index, _stream())
+    cnt = _step_counters.get(key)
+    if cnt is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fastkv_amd.decode_step_attention: pass `counters` (ops.new_step_counters, allocated before the "
+                               "capture) when the step is captured in a graph")
+        cnt = _step_counters[key] = new_step_counters(device)
+    return cnt
+
+
+def reset_decode_state(*counters: torch.Tensor) -> None:
+    """After a reported error (FASTKV_EABORTED, a killed kernel) arrival counters may be non-zero for good: zero them from the
+    host before the next step (the given ones, and every default set)."""
+    for c in list(counters) + list(_step_counters.values()):
+        c.zero_()
+
+
 def decode_step_attention(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
-                          kslab: torch.Tensor, vslab: torch.Tensor, len_dev: torch.Tensor, scaling: float, nsplit: int = 0) -> torch.Tensor:
+                          kslab: torch.Tensor, vslab: torch.Tensor, len_dev: torch.Tensor, scaling: float, nsplit: int = 0,
+                          counters: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RoPE + append + GQA attention + slice merge of a one-token step in ONE launch: q [B,H,1,D] / k_new, v_new [B,Hkv,1,D] are
     the RAW projections, cos / sin [B,1,D] fp16; returns fp16 [B,1,H*D], the slab gains the row, len_dev is advanced."""
     _require_cuda(q, k_new, v_new, cos, sin, kslab, vslab, len_dev)
@@ -359,11 +398,10 @@ def decode_step_attention(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Ten
     nsplit = nsplit or DECODE_NSPLIT
     L = load()
     out = torch.empty(B, 1, H * D, dtype=torch.float16, device=q.device)
-    ws = _workspace(L.fastkv_decode_workspace_bytes(B, H, D, nsplit), q.device, "decode")
-    key = (q.device.index, _stream())
-    cnt = _step_counters.get(key)
-    if cnt is None:
-        cnt = _step_counters[key] = torch.zeros(1024, dtype=torch.int32, device=q.device)
+    need = L.fastkv_decode_workspace_bytes(B, H, D, nsplit)
+    ws = workspace if workspace is not None and workspace.numel() >= need else _workspace(need, q.device, "decode")
+    cnt = counters if counters is not None else _default_counters(q.device)
+    assert cnt.dtype == torch.int32 and cnt.numel() >= 1 + B * Hkv and cnt.is_cuda
     I2, I3 = ctypes.c_int64 * 2, ctypes.c_int64 * 3
     rc = L.fastkv_decode_step_attention_f16(B, H, Hkv, D, q.data_ptr(), I2(q.stride(0), q.stride(1)), k_new.data_ptr(),
                                             I2(k_new.stride(0), k_new.stride(1)), v_new.data_ptr(), I2(v_new.stride(0), v_new.stride(1)),
@@ -433,11 +471,18 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
     assert n >= 1 and len(ks) == n and len(vs) == n
     q0, k0, v0 = qs[0], ks[0], vs[0]
     _check_qkv(q0, k0, v0)
+
+    def same_layout(ok: bool, what: str):
+        # entries that do not share one geometry / layout / alignment cannot go through one launch sequence: the caller runs them
+        # one by one (the only condition besides the library's own FASTKV_EUNSUPPORTED that DeferredCompression falls back on)
+        if not ok:
+            raise FastKVNativeError(f"fastkv_amd.update_kv_entries: entries differ in {what}", code=FASTKV_EUNSUPPORTED)
+
     for q, k, v in zip(qs, ks, vs):
-        assert q.shape == q0.shape and k.shape == k0.shape and v.shape == v0.shape and q.shape[0] == 1
-        assert q.stride() == q0.stride() and k.stride() == k0.stride() and v.stride() == v0.stride()
-        assert q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16
-        assert (q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0
+        same_layout(q.shape == q0.shape and k.shape == k0.shape and v.shape == v0.shape and q.shape[0] == 1, "shape")
+        same_layout(q.stride() == q0.stride() and k.stride() == k0.stride() and v.stride() == v0.stride(), "strides")
+        same_layout(q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16, "dtype")
+        same_layout((q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0, "16-byte alignment")
     L = load()
     p = _problem(q0, k0, window, kernel_size, pooling, capacity, tsp_len, order)
     p.B = n
@@ -449,12 +494,13 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
     else:
         k_outs, v_outs = outs
         for ko, vo in zip(k_outs, v_outs):
-            assert ko.shape == (1, Hkv, capacity, D) and vo.shape == ko.shape and ko.stride() == k_outs[0].stride() == vo.stride()
-            assert ko.stride(3) == 1 and (ko.data_ptr() | vo.data_ptr()) % 16 == 0
+            same_layout(ko.shape == (1, Hkv, capacity, D) and vo.shape == ko.shape and ko.stride() == k_outs[0].stride() == vo.stride(),
+                        "output shape / strides")
+            same_layout(ko.stride(3) == 1 and (ko.data_ptr() | vo.data_ptr()) % 16 == 0, "output alignment")
     ostr = (ctypes.c_int64 * 3)(*k_outs[0].stride()[:3])
     tab = _device_ptr_table([[t.data_ptr() for t in lst] for lst in (qs, ks, vs, k_outs, v_outs)], dev)
     kv_idx = torch.empty(n, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
-    tsp = torch.empty(n, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
+    tsp = torch.zeros(n, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None        # (see update_kv)
     ws = _workspace(L.fastkv_workspace_bytes(ctypes.byref(p)), dev)
     rc = L.fastkv_update_kv_ptrs_f16(ctypes.byref(p), tab[0].data_ptr(), _strides(q0), tab[1].data_ptr(), _strides(k0), tab[2].data_ptr(),
                                      _strides(v0), tab[3].data_ptr(), tab[4].data_ptr(), ostr,

