@@ -197,6 +197,8 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
             from fastkv_amd.dist import sp_update_kv
             cl = self.kv_cluster
             self.tsp_idx = None
+            if sp.layout(query_states.shape[1], key_states.shape[1]) == "heads":
+                return self._forward_head_parallel(query_states, key_states, value_states, past_key_values, sp, input_shape)
             if past_key_values is not None:
                 early, cap, tsp = sp_model.plan_for(cl, sp.total)
                 if early:                                         # utils.py:89-91: nothing is dropped, the shard's rows are cached
@@ -213,6 +215,35 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                 past_key_values.update(k_c, v_c, self.layer_idx)
             k_cat, v_cat = sp_model.gather_kv(key_states, value_states, sp)
             attn_output = sp_model.sp_attention(query_states, k_cat, v_cat, self.scaling)
+            return self.o_proj(attn_output.reshape(*input_shape, -1).contiguous()), None
+
+        def _forward_head_parallel(self, query_states, key_states, value_states, past_key_values, sp, input_shape):
+            """The same with head-parallel attention (fastkv_amd/sp_model.py, layout "heads"): one all-to-all hands this rank ALL
+            positions of its H/P query heads and Hkv/P KV heads; attention is plain causal attention over the whole prompt for
+            those heads (1/P of the work on every rank); the cache gets update_kv's rows for the local KV heads through the
+            ordinary fused operator (`tp_update_kv`: no collective, the TSP layer adds one all-gather of score rows); a second
+            all-to-all returns the attention output to sequence shards."""
+            from fastkv_amd import sp_model
+            from fastkv_amd.dist import tp_update_kv
+            cl = self.kv_cluster
+            q_f, k_f, v_f = sp_model.heads_exchange(query_states, key_states, value_states, sp)
+            if past_key_values is not None:
+                early, cap, tsp = sp_model.plan_for(cl, sp.total)
+                if early:                                         # utils.py:89-91: nothing is dropped
+                    k_c, v_c = k_f, v_f
+                else:
+                    dt = k_f.dtype
+                    k16, q16, v16 = (t if t.dtype == torch.float16 else t.half() for t in (k_f, q_f, v_f))
+                    k_c, v_c, self.tsp_idx, _ = tp_update_kv(k16, q16, v16, window_size=cl.window_size, kernel_size=cl.kernel_size,
+                                                             pooling=cl.pooling, capacity=cap, tsp_len=tsp,
+                                                             order=getattr(cl, "kv_order", None) or getattr(cl, "order", "score"),
+                                                             group=sp.group, local_ops=sp.tp_ops)
+                    k_c, v_c = k_c.to(dt), v_c.to(dt)
+                if sp.replicate:                                  # (tests: every rank holds all KV heads' rows)
+                    k_c, v_c = sp_model.gather_heads(k_c, sp), sp_model.gather_heads(v_c, sp)
+                past_key_values.update(k_c, v_c, self.layer_idx)
+            attn = sp_model.heads_attention(q_f, k_f, v_f, self.scaling)
+            attn_output = sp_model.heads_return(attn, sp)
             return self.o_proj(attn_output.reshape(*input_shape, -1).contiguous()), None
 
     return FastKVAttention

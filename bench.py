@@ -346,8 +346,9 @@ def run_leg(name, steps, rank, world, dev, dist):
 
 def run_sp_ttft(steps, rank, world, dev, dist):
     """BASELINE.json configs[2] as a WHOLE-MODEL number: TTFT of ONE 131,072-token prompt, random-init Llama-3-8B geometry,
-    sequence-parallel prefill over `world` ranks (fastkv_amd/sp_model.py: K/V all-gather + lower-right causal attention,
-    sequence-sharded update_kv, TSP re-shard at layer 15, replicated layers behind it).  1 warm-up + 2 timed runs."""
+    sequence-parallel prefill over `world` ranks (fastkv_amd/sp_model.py: head-parallel attention between two all-to-alls with the
+    head-local fused update_kv -- or, when the KV heads do not split over the ranks, K/V all-gather + lower-right causal attention
+    + the sequence-sharded update_kv --, TSP re-shard at layer 15, replicated layers behind it).  1 warm-up + 2 timed runs."""
     from baselines.monkeypatch import replace_llama, set_model
     from benchmark import prefill
     from fastkv_amd.sp_model import SPContext, sp_prefill
@@ -372,7 +373,8 @@ def run_sp_ttft(steps, rank, world, dev, dist):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
-            out = sp_prefill(model, ids, SPContext(shard_lengths=lens))
+            ctx = SPContext(shard_lengths=lens)
+            out = sp_prefill(model, ids, ctx)
         torch.cuda.synchronize()
         dist.barrier()
         dt = time.perf_counter() - t0
@@ -385,7 +387,10 @@ def run_sp_ttft(steps, rank, world, dev, dist):
     return {"prompt_tokens": S, "tokens_per_rank": lens[0], "model": "random-init Llama-3-8B geometry, fp16, 32 layers", "ttft_ms": round(ms, 2),
             "tokens_per_s": round(S / (ms * 1e-3), 1), "scaling": "strong", "runs": len(times), "backend": dist.get_backend(),
             "max_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-            "note": "whole-model TTFT (not the hot path alone): attention by K/V all-gather, 5 collectives per layer up to the TSP layer, none behind it"}
+            "layout": ctx.layout(model.config.num_attention_heads, model.config.num_key_value_heads),
+            "note": "whole-model TTFT (not the hot path alone).  layout 'heads': all-to-all to head shards, causal attention over the whole "
+                    "prompt for H/P query heads per rank (1/P of the work each), head-local fused update_kv, all-to-all back: 2 collectives per "
+                    "layer up to the TSP layer (+1 on it), none behind it; 'gather' (KV heads do not split over the ranks): K/V all-gather, 5 per layer"}
 
 
 def leg_child_main(a):

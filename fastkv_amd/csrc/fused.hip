@@ -781,26 +781,33 @@ one_stream:
     // everything submitted there so far) makes the new stream wait.  The lock is held from the chaining to the enqueue of the
     // kernel, so that a second thread cannot slip its own launch in between.  Nothing is added while the caller stays on
     // one stream; inside a stream capture the chain is skipped (see include/fastkv_hip.h).
+    // Why the event is recorded on the PREVIOUS stream at the switch and not behind every launch on its own stream: measured
+    // (round 3, `FASTKV_CHAIN=0` A/B on one box) an event record behind each of the 17 fused launches of a step costs 4-8 % of
+    // the step (1.03-1.08 ms against 0.996 ms): the marker packet keeps the next kernel from being dispatched back to back.
+    // The previous stream's handle is therefore kept.  If the caller has destroyed that stream meanwhile, hipEventRecord
+    // refuses the handle (the runtime checks every stream handle against its table of live streams and returns
+    // hipErrorContextIsDestroyed / hipErrorInvalidHandle; nothing is dereferenced) and the chain is skipped: the destroyed
+    // stream's work was complete, or at least ordered, when it was destroyed.  A NEW stream that re-uses the address merely
+    // contributes a harmless extra dependency.
     static std::mutex mtx;
-    static hipStream_t last_stream[16];                        // compared only, never passed to HIP again (the caller may have destroyed it)
+    static hipStream_t last_stream[16];
     static bool have_last[16];
-    static hipEvent_t chain_ev[16];                            // recorded on the launch's OWN stream, right behind the fused kernel
+    static hipEvent_t chain_ev[16];
     std::lock_guard<std::mutex> lk(mtx);
-    int dev = -1;
-    bool chained = false;
     {
+        static const bool chain_off = []() { const char *e = getenv("FASTKV_CHAIN"); return e && e[0] == '0'; }();   // measurement aid
+        int dev = 0;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && hipStreamIsCapturing(st, &cs) == hipSuccess &&
+        if (!chain_off && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && hipStreamIsCapturing(st, &cs) == hipSuccess &&
             cs == hipStreamCaptureStatusNone) {
-            chained = true;
-            if (!chain_ev[dev] && hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) {
-                chain_ev[dev] = nullptr;
-                (void)hipGetLastError();
-                chained = false;
+            if (have_last[dev] && last_stream[dev] != st) {
+                if (!chain_ev[dev]) (void)hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming);
+                if (chain_ev[dev] && hipEventRecord(chain_ev[dev], last_stream[dev]) == hipSuccess)
+                    (void)hipStreamWaitEvent(st, chain_ev[dev], 0);
+                (void)hipGetLastError();                         // a destroyed previous stream is not this call's error
             }
-            // the previous fused launch of this process ran on another stream: wait for the event recorded behind it
-            if (chained && have_last[dev] && last_stream[dev] != st) (void)hipStreamWaitEvent(st, chain_ev[dev], 0);
-            (void)hipGetLastError();
+            last_stream[dev] = st;
+            have_last[dev] = true;
         }
     }
     ProfScope ps_(K_FUSED, st);
@@ -811,10 +818,6 @@ one_stream:
                              pt ? pt->k : nullptr);
     });
     *err = hipGetLastError();
-    if (chained && *err == hipSuccess) {
-        if (hipEventRecord(chain_ev[dev], st) == hipSuccess) { last_stream[dev] = st; have_last[dev] = true; }
-        else { (void)hipGetLastError(); have_last[dev] = false; }
-    }
     return true;
 }
 

@@ -1,12 +1,15 @@
 """Sequence-parallel prefill of the whole (tiny, CPU) model over 2-3 gloo ranks against the single-process model
 (fastkv_amd/sp_model.py).  The cluster is the oracle-backed stand-in (the product has no CPU path); what is
-under test is the sharded wiring: K/V all-gather + lower-right causal attention, the sequence-sharded operator inside the
-attention module, the TSP re-shard (every rank contributes the surviving rows it owns), the replicated layers behind it, and
-the last-token broadcast when no TSP reduction happens.
+under test is the sharded wiring in both layouts -- "heads" (two ranks: all-to-all to head shards, plain causal attention over
+the whole prompt for the local heads, the head-local operator `tp_update_kv`, all-to-all back; 2 all-to-alls per sharded layer
+asserted) and "gather" (three ranks, or forced: K/V all-gather + lower-right causal attention, the sequence-sharded operator)
+-- the TSP re-shard (every rank contributes the surviving rows it owns), the replicated layers behind it, and the last-token
+broadcast when no TSP reduction happens.
 
-Tolerance: the sharded attention sums in another order than the single-process SDPA call (fp32 model: ~1e-6); the selection
-itself is exact arithmetic on fp16 inputs, so index sets agree unless a last-bit difference of the fp32 projections crosses
-an fp16 rounding boundary AND a selection threshold -- the prompts below do not."""
+Tolerance: head-parallel attention is the single-process SDPA call restricted to a rank's heads: logits within 2e-5 of the
+single-process fp32 model; the all-gather layout sums in another order (2e-4).  The selection itself is exact arithmetic on
+fp16 inputs, so index sets agree unless a last-bit difference of the fp32 projections crosses an fp16 rounding boundary AND a
+selection threshold -- the prompts below do not."""
 import os
 import socket
 import sys
@@ -63,11 +66,24 @@ def _worker(rank, world, port, case, q_out):
         ref_tsp = [l.self_attn.tsp_idx for l in ref_model.model.layers]
         model = build()
         lo, hi = sum(lens[:rank]), sum(lens[:rank + 1])
-        ctx = SPContext(shard_lengths=lens, local_ops=OracleLocalOps(), replicate=True)
+        from fastkv_amd import sp_model
+        from sp_oracle_ops import OracleTPOps
+        ctx = SPContext(shard_lengths=lens, local_ops=OracleLocalOps(), tp_ops=OracleTPOps(), replicate=True, mode=case.get("mode", "auto"))
+        cfg = model.config
+        layout = ctx.layout(cfg.num_attention_heads, cfg.num_key_value_heads)
+        a2a0 = sp_model.COLLECTIVES["all_to_all"]
         with torch.no_grad():
             out = sp_prefill(model, ids[:, lo:hi], ctx)
         msg = []
-        if not torch.allclose(out.logits, ref.logits, atol=2e-4, rtol=1e-4):
+        if layout != case["layout"]:
+            msg.append(f"layout {layout}, expected {case['layout']}")
+        n_sharded = len(model.model.layers) if case.get("early_out") else case["tsp_idx"] + 1
+        if layout == "heads" and sp_model.COLLECTIVES["all_to_all"] - a2a0 != 2 * n_sharded:
+            msg.append(f"{sp_model.COLLECTIVES['all_to_all'] - a2a0} all-to-alls for {n_sharded} sharded layers (2 per layer expected)")
+        # head-parallel attention is the single-process SDPA call restricted to a rank's heads (heads are independent): logits
+        # agree to the last bits of the fp32 model; the all-gather layout sums in another order
+        tol = dict(atol=2e-5, rtol=1e-5) if layout == "heads" else dict(atol=2e-4, rtol=1e-4)
+        if not torch.allclose(out.logits, ref.logits, **tol):
             msg.append(f"logits differ by {float((out.logits - ref.logits).abs().max()):.3e}")
         for i, layer in enumerate(model.model.layers):
             t, rt = layer.self_attn.tsp_idx, ref_tsp[i]
@@ -75,8 +91,9 @@ def _worker(rank, world, port, case, q_out):
                 msg.append(f"tsp_idx of layer {i} differs")
             kc, rk = out.past_key_values.layers[i].keys, ref.past_key_values.layers[i].keys
             vc, rv = out.past_key_values.layers[i].values, ref.past_key_values.layers[i].values
-            if case.get("early_out"):
+            if case.get("early_out") and layout == "gather":
                 rk, rv = rk[:, :, lo:hi], rv[:, :, lo:hi]           # nothing dropped, nothing re-sharded: every rank caches its shard's rows
+            # (layout "heads" with `replicate`: all heads of the whole prompt on every rank, as in the single-process cache)
             if kc.shape != rk.shape:
                 msg.append(f"cache of layer {i}: shape {tuple(kc.shape)} vs {tuple(rk.shape)}")
             elif i <= case["tsp_idx"] or case.get("early_out"):
@@ -101,12 +118,18 @@ def _worker(rank, world, port, case, q_out):
 
 
 CASES = [
-    # layer 0 sharded, layer 1 = TSP layer (sharded, re-shard behind it), layers 2-3 replicated on every rank
-    dict(lens=[100, 120, 80], cap=64, tsp_len=96, tsp_idx=1, pooling="avgpool"),
-    # TSP at layer 0, maxpool, two ragged shards
-    dict(lens=[210, 90], cap=48, tsp_len=80, tsp_idx=0, pooling="maxpool"),
+    # three ranks: the tiny model's 2 KV heads do not split -> the all-gather layout.  Layer 0 sharded, layer 1 = TSP layer
+    # (sharded, re-shard behind it), layers 2-3 replicated on every rank
+    dict(lens=[100, 120, 80], cap=64, tsp_len=96, tsp_idx=1, pooling="avgpool", layout="gather"),
+    # two ranks: head-parallel attention (one KV head + four query heads per rank).  TSP at layer 0, maxpool, ragged shards
+    dict(lens=[210, 90], cap=48, tsp_len=80, tsp_idx=0, pooling="maxpool", layout="heads"),
+    # head-parallel, TSP at layer 1 (two sharded layers), very ragged
+    dict(lens=[40, 260], cap=64, tsp_len=96, tsp_idx=1, pooling="avgpool", layout="heads"),
+    # the all-gather layout on two ranks, forced (what P that does not divide the KV heads gets)
+    dict(lens=[210, 90], cap=48, tsp_len=80, tsp_idx=0, pooling="maxpool", mode="gather", layout="gather"),
     # budgets above the prompt: early-out in every layer, no TSP reduction -> the last rank's last token is broadcast
-    dict(lens=[64, 64], cap=512, tsp_len=2048, tsp_idx=1, pooling="avgpool", early_out=True),
+    dict(lens=[64, 64], cap=512, tsp_len=2048, tsp_idx=1, pooling="avgpool", early_out=True, layout="heads"),
+    dict(lens=[64, 64], cap=512, tsp_len=2048, tsp_idx=1, pooling="avgpool", early_out=True, mode="gather", layout="gather"),
 ]
 
 
