@@ -242,11 +242,14 @@ template <typename T, typename Op> __device__ __forceinline__ T halfwave_reduce1
 // The taps are read into registers first (KMAX independent LDS reads) and combined afterwards in tap order: a rolled
 // "read, add, read, add" loop is a chain of LDS round trips, which two waves per SIMD cannot hide (measured in the fused
 // score kernel: 5.4 us for 12 pools per thread).
-template <int KMAX> __device__ __forceinline__ float pool_taps_n(const float *st, int t, int pad, int ksize, bool avg)
+// T = float, or uint16_t holding fp16 bits (the pooled values ARE fp16 values: h2f is exact)
+__device__ __forceinline__ float pool_elem(float x) { return x; }
+__device__ __forceinline__ float pool_elem(uint16_t x) { return h2f(x); }
+template <int KMAX, typename T> __device__ __forceinline__ float pool_taps_n(const T *st, int t, int pad, int ksize, bool avg)
 {
     float v[KMAX];
 #pragma unroll
-    for (int o = 0; o < KMAX; ++o) v[o] = st[t - pad + (o < ksize ? o : ksize - 1)];
+    for (int o = 0; o < KMAX; ++o) v[o] = pool_elem(st[t - pad + (o < ksize ? o : ksize - 1)]);
     float pv;
     if (avg) {
         pv = 0.0f;
@@ -260,18 +263,18 @@ template <int KMAX> __device__ __forceinline__ float pool_taps_n(const float *st
     }
     return pv;
 }
-__device__ __forceinline__ float pool_taps(const float *st, int t, int pad, int ksize, bool avg)
+template <typename T> __device__ __forceinline__ float pool_taps(const T *st, int t, int pad, int ksize, bool avg)
 {
     if (ksize <= 7) return pool_taps_n<7>(st, t, pad, ksize, avg);
     if (ksize <= 15) return pool_taps_n<15>(st, t, pad, ksize, avg);
     float pv;
     if (avg) {
         pv = 0.0f;
-        for (int o = -pad; o <= pad; ++o) pv = pv + st[t + o];
+        for (int o = -pad; o <= pad; ++o) pv = pv + pool_elem(st[t + o]);
         pv = pv / (float)ksize;
     } else {
         pv = -INFINITY;
-        for (int o = -pad; o <= pad; ++o) { const float xv = st[t + o]; if (xv > pv || xv != xv) pv = xv; }
+        for (int o = -pad; o <= pad; ++o) { const float xv = pool_elem(st[t + o]); if (xv > pv || xv != xv) pv = xv; }
     }
     return pv;
 }

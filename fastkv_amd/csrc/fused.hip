@@ -90,9 +90,24 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     static_assert(PER % NS == 0, "tiles split evenly over the streams");
     constexpr int W = 8, G = 4, NPH = D / DH, TK = 32 * NB, NW = 8 * NB, PS = PER / NS;
     constexpr int SLAB_BYTES = 4 * 64 * ROWB, AS_FLOATS = (D / 2) * 64;
-    // one block of LDS, carved twice: phase A = the waves' K slabs + the fp32 query operand of every stream; phases C/D (all
-    // of phase A is over by then, on every stream) = the window-row-sum tiles and the key histograms of the streams
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SLAB_BYTES + NS * AS_FLOATS * 4];
+    // Phase B's exponentials are needed again in phase C.  Up to two tiles per wave keep them in registers (64 of them); with
+    // four tiles per wave (two 32k layers per launch) the other two tiles park theirs in LDS -- the K slabs and the query
+    // operand are dead by then -- as one float4 per lane and word pair (conflict-free ds_write_b128 / ds_read_b128).  Round 2
+    // recomputed them instead (128 more registers do not fit): 13.2 us of phase C against 3.9 us (per-wave stamps, r03).
+    constexpr int E_REGS = PER < 4 ? PER : 2, E_LDS = PER - E_REGS;
+    constexpr int E_BYTES = 4 * E_LDS * 64 * 2 * NW * 4;          // 64 KiB (32 KiB with 32-key tiles) per workgroup when PER == 4
+    // the window-row sums of phases C / D are fp16 values: kept as fp16 bits when the parked exponentials need the room
+    using tile_t = std::conditional_t<(E_LDS > 0), uint16_t, float>;
+    constexpr int TWG_ = 4 * PS * TK, TW_ = TWG_ + 64;            // 31 halo columns on either side; rows stay 8-B / 16-B aligned
+    constexpr int HIST_BYTES = HIST12 * 4;
+    // phases C / D: [parked exponentials | histogram (inside the exponentials' area once they are consumed, behind them when
+    // there are none)] [window-row-sum tiles of the streams]
+    constexpr int CD_HEAD = E_BYTES >= HIST_BYTES ? E_BYTES : (E_BYTES + NS * HIST_BYTES);
+    constexpr int CD_BYTES = CD_HEAD + NS * G * TW_ * (int)sizeof(tile_t);
+    constexpr int A_BYTES = SLAB_BYTES + NS * AS_FLOATS * 4;
+    // one block of LDS, carved twice: phase A = the waves' K slabs + the fp32 query operand of every stream; phases B-D (all
+    // of phase A is over by then, on every stream) = parked exponentials, the window-row-sum tiles, the key histograms
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES > CD_BYTES ? A_BYTES : CD_BYTES];
     __shared__ float s_pf[NS][4][32];                          // per-wave row maxima of a stream (phase A -> publish)
     __shared__ uint64_t s_pu[NS][4][32];                       // per-wave fixed-point row sums (phase B -> publish)
     __shared__ uint32_t s_pb[NS][4][32];
@@ -207,12 +222,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][NW];
-    // The exponentials of phase B are kept for phase C -- except with four tiles per wave (two 32k layers per launch): 128 more
-    // registers do not fit next to the packed logits, and recomputing them (the same function of the same operands: the same
-    // bits) costs less than spilling them.
-    constexpr bool KEEP_E = PER < 4;
-    float ev[KEEP_E ? PER : 1][2][NW];
-    bool gm_finite_c = true;                                     // (phase B's wave-uniform choice of the exponential, for phase C)
+    float ev[E_REGS][2][NW];
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ *ebuf = reinterpret_cast<f32x4_ *>(smem) + (size_t)w * E_LDS * (NW / 2) * 64 + lane;   // [tile][word pair][lane] of this wave
     uint32_t tile_nan = 0;                                       // bit t: tile t's contraction held a NaN (wave-uniform)
 
     // ================================================================ phase A of stream s: logits of its tiles, row maxima,
@@ -371,7 +383,12 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
         for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; gm_ok = gm_ok && __builtin_fabsf(gm[i]) < INFINITY; }
         const bool gm_finite = __all(gm_ok);                         // wave-uniform: +-inf or NaN row maxima send every tile the general way
-        gm_finite_c = gm_finite;
+        f32x2 epair = {0.0f, 0.0f};                                  // the even word's exponentials, until the odd word's join them
+        auto keep = [&](int t, int i, f32x2 e) {                     // t, i: compile-time after unrolling
+            if (t < E_REGS) { ev[t < E_REGS ? t : 0][0][i] = e.x; ev[t < E_REGS ? t : 0][1][i] = e.y; }
+            else if (i & 1) ebuf[((t - E_REGS) * (NW / 2) + (i >> 1)) * 64] = (f32x4_){epair.x, epair.y, e.x, e.y};
+            else epair = e;
+        };
 #pragma unroll
         for (int lt = 0; lt < PS; ++lt) {
             constexpr int t0 = s * PS;
@@ -388,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     const int rB = NB == 2 ? i : (i + 8) & 15;
                     const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
                     const f32x2 e = det_expf2_clamped(x - (f32x2){gm[i], gm[rB]});
-                    if (KEEP_E) { ev[KEEP_E ? t : 0][0][i] = e.x; ev[KEEP_E ? t : 0][1][i] = e.y; }
+                    keep(t, i, e);
                     uint32_t h0, l0, h1, l1;
                     exp_to_fix2(e, h0, l0, h1, l1);
                     if (NB == 2) {
@@ -406,7 +423,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                     const int rB = NB == 2 ? i : (i + 8) & 15;
                     const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
                     const f32x2 e = det_expf2(x - (f32x2){gm[i], gm[rB]});
-                    if (KEEP_E) { ev[KEEP_E ? t : 0][0][i] = e.x; ev[KEEP_E ? t : 0][1][i] = e.y; }
+                    keep(t, i, e);
                     uint32_t h0, l0, h1, l1;
                     exp_to_fix2(e, h0, l0, h1, l1);
                     const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
@@ -501,28 +518,27 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // utils.py:104): the lower half's partial sum crosses to the upper half, which finishes it and owns the result.
     // The workgroup owns the contiguous positions [lo, lo + TWG) of each stream's head: the window-row sums hs go to the
     // stream's LDS tile, column pad + local position; candidates past n hold the pooling pad value (utils.py:106,108).
-    constexpr int TWG = 4 * PS * TK, PADMAX = 31, TW = TWG + 2 * PADMAX;
-    static_assert(NS * (G * TW * sizeof(float) + HIST12 * sizeof(uint32_t)) <= sizeof(smem), "phases C/D do not fit the phase-A LDS");
+    constexpr int TWG = TWG_, PADMAX = 31, TW = TW_;
+    static_assert(E_LDS == 0 || NS == 1, "parked exponentials: one stream only");
+    static_assert(CD_BYTES <= (int)sizeof(smem) && sizeof(smem) + 6656 <= 80 * 1024, "two workgroups per CU share 160 KiB of LDS");
     const int pad = ksize / 2, lo = blk * TWG;
     const bool avg = pooling == FASTKV_POOL_AVG;
     const float padv = avg ? 0.0f : -INFINITY;
     const bool want_hist = all_idx == nullptr;
-    auto tile_of = [&](int s) { return reinterpret_cast<float(*)[TW]>(smem + (size_t)s * G * TW * sizeof(float)); };
-    auto hist_of = [&](int s) { return reinterpret_cast<uint32_t *>(smem + NS * G * TW * sizeof(float) + (size_t)s * HIST12 * sizeof(uint32_t)); };
+    auto tile_of = [&](int s) { return reinterpret_cast<tile_t(*)[TW]>(smem + CD_HEAD + (size_t)s * G * TW * sizeof(tile_t)); };
+    auto hist_of = [&](int s) { return reinterpret_cast<uint32_t *>(smem + (E_BYTES >= HIST_BYTES ? 0 : E_BYTES) + (size_t)s * HIST_BYTES); };
+    // a tile element: an fp16-valued number (or the pooling pad value: 0 / -inf), stored as float or as its fp16 bits
+    auto tl_put = [](tile_t &dst, float v) { if constexpr (std::is_same<tile_t, float>::value) dst = v; else dst = f2h(v); };
+    auto tl_get = [](const tile_t &src) -> float { if constexpr (std::is_same<tile_t, float>::value) return src; else return h2f(src); };
 
     auto phaseC = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        float(*tile)[TW] = tile_of(s);
+        tile_t(*tile)[TW] = tile_of(s);
         uint32_t *s_hist = hist_of(s);
-        float ri[16], gmc[KEEP_E ? 1 : 16];
+        float ri[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) ri[i] = s_ri[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
-        if (!KEEP_E) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) gmc[KEEP_E ? 0 : i] = s_gm[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
-        }
         FKF_STAMP(29);
-        if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
 #pragma unroll
         for (int lt = 0; lt < PS; ++lt) {
             constexpr int t0 = s * PS;
@@ -533,20 +549,17 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 // one packed pair per step: every operation below is per component what the scalar chain does.  NB == 2: the two
                 // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
                 f32x2 p[4];
+                f32x4_ parked[2];                                 // this step's four words of a tile whose exponentials wait in LDS
+                if (t >= E_REGS) {
+                    parked[0] = ebuf[((t - E_REGS) * (NW / 2) + 2 * i4) * 64];
+                    parked[1] = ebuf[((t - E_REGS) * (NW / 2) + 2 * i4 + 1) * 64];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
                     f32x2 ee;
-                    if (KEEP_E) {
-                        ee = (f32x2){ev[KEEP_E ? t : 0][0][wd], ev[KEEP_E ? t : 0][1][wd]};
-                    } else {
-                        // phase B's exponential again: the same function (clamped for full tiles of finite logits under finite row
-                        // maxima, general otherwise) of the same operands
-                        const f32x2 x = {h2f((uint16_t)(lg[t][wd] & 0xffffu)), h2f((uint16_t)(lg[t][wd] >> 16))};
-                        const f32x2 dx = x - (f32x2){gmc[KEEP_E ? 0 : wd], gmc[KEEP_E ? 0 : rB]};
-                        const bool fast = tile_wt(t) * TK + TK <= S && !((tile_nan >> t) & 1u) && gm_finite_c;
-                        ee = fast ? det_expf2_clamped(dx) : det_expf2(dx);
-                    }
+                    if (t < E_REGS) ee = (f32x2){ev[t < E_REGS ? t : 0][0][wd], ev[t < E_REGS ? t : 0][1][wd]};
+                    else ee = (u & 1) ? (f32x2){parked[u >> 1].z, parked[u >> 1].w} : (f32x2){parked[u >> 1].x, parked[u >> 1].y};
                     const f32x2 pr = ee * (f32x2){ri[wd], ri[rB]};
                     const uint32_t ph = f2h2(pr.x, pr.y);                                 // utils.py:103 -> fp16
                     p[u] = (f32x2){h2f((uint16_t)(ph & 0xffffu)), h2f((uint16_t)(ph >> 16))};
@@ -557,24 +570,27 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
                 if (hi) {
                     if (NB == 2) {
-                        tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
-                        tile[i4][PADMAX + lp + 32] = lo + lp + 32 < n ? h2f(f2h(c.y)) : padv;
+                        tl_put(tile[i4][PADMAX + lp], lo + lp < n ? h2f(f2h(c.x)) : padv);
+                        tl_put(tile[i4][PADMAX + lp + 32], lo + lp + 32 < n ? h2f(f2h(c.y)) : padv);
                     } else {
-                        tile[i4][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.x)) : padv;
-                        tile[(i4 + 2) & 3][PADMAX + lp] = lo + lp < n ? h2f(f2h(c.y)) : padv;
+                        tl_put(tile[i4][PADMAX + lp], lo + lp < n ? h2f(f2h(c.x)) : padv);
+                        tl_put(tile[(i4 + 2) & 3][PADMAX + lp], lo + lp < n ? h2f(f2h(c.y)) : padv);
                     }
                 }
             }
         }
         FKF_STAMP(30);
         __syncthreads();
+        // (the histogram may lie where the parked exponentials were: cleared only now that every wave has consumed them; phase D,
+        // its first user, starts behind the barrier of read_halo)
+        if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
         // halo: pooling reaches `pad` positions into the neighbouring workgroups of the head.  Every workgroup publishes its
         // first and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the flag)
         uint64_t *eg = edges + ((size_t)bgv_s[s] * nblk + blk) * (2 * G * PADMAX);
         const int tt = threadIdx.x, per_side = G * pad;
         if (tt < 2 * per_side) {
             const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
-            const float v = tile[i4][PADMAX + (side ? TWG - pad + e : e)];
+            const float v = tl_get(tile[i4][PADMAX + (side ? TWG - pad + e : e)]);
             __hip_atomic_store(eg + (side * G + i4) * PADMAX + e, ((uint64_t)token << 32) | f32_bits(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -583,7 +599,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // the neighbours' halo granules of stream s into the pad columns of its tile; no neighbour = pooling padding
     auto read_halo = [&](auto sc) -> bool {
         constexpr int s = decltype(sc)::value;
-        float(*tile)[TW] = tile_of(s);
+        tile_t(*tile)[TW] = tile_of(s);
         const int tt = threadIdx.x, per_side = G * pad;
         if (tt < 2 * per_side) {
             const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
@@ -599,7 +615,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 }
                 hv = bits_f32((uint32_t)x);
             }
-            tile[i4][side ? PADMAX + TWG + e : PADMAX - pad + e] = hv;
+            tl_put(tile[i4][side ? PADMAX + TWG + e : PADMAX - pad + e], hv);
         }
         __syncthreads();
         return !s_abort;
@@ -609,7 +625,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // utils.py:105-112)
     auto phaseD = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        float(*tile)[TW] = tile_of(s);
+        tile_t(*tile)[TW] = tile_of(s);
         uint32_t *s_hist = hist_of(s);
         const int bg = bg_s[s], bgv = bgv_s[s], vh = vh_s[s];
         uint32_t *hist_row = zero_area + (size_t)bg * HIST12;
@@ -655,6 +671,125 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         }
     };
 
+    // Phase D for the usual kernel sizes (3 / 5 / 7): FOUR consecutive positions per thread.  The 12-element window
+    // [lp - 3, lp + 9) of a head's row serves all four (3 aligned 8-B / 16-B LDS reads instead of 28 scalar ones per position),
+    // the four scores leave in one 8-byte store.  Per position the same operations in the same order as the scalar loop above.
+    auto phaseD_vec = [&](auto sc, auto padc) {
+        constexpr int s = decltype(sc)::value, PAD = decltype(padc)::value, KS = 2 * PAD + 1;
+        static_assert(PAD >= 1 && PAD <= 3 && PADMAX % 4 == 3 && TW % 4 == 0, "aligned 12-element windows");
+        tile_t(*tile)[TW] = tile_of(s);
+        uint32_t *s_hist = hist_of(s);
+        const int bg = bg_s[s], bgv = bgv_s[s], vh = vh_s[s];
+        uint32_t *hist_row = zero_area + (size_t)bg * HIST12;
+        uint64_t *chain_in = chain + ((size_t)(bgv - 1) * nblk + blk) * TWG;
+        uint64_t *chain_out = chain + ((size_t)bgv * nblk + blk) * TWG;
+        const bool last_vh = vh == VH - 1;
+#pragma unroll
+        for (int u = 0; u * 1024 < TWG; ++u) {
+            const int lp = (u * 256 + (int)threadIdx.x) * 4, j = lo + lp;
+            const bool any = lp < TWG && j < n;
+            float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (any && vh > 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (j + e < n) {
+                        uint64_t x;
+                        while ((uint32_t)((x = __hip_atomic_load(chain_in + lp + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != token) {
+                            __builtin_amdgcn_s_sleep(4);
+                            if (spin_failed(sp)) break;
+                        }
+                        gs[e] = bits_f32((uint32_t)x);
+                    }
+                }
+            }
+            if (any) {
+                float pv[G][4];
+#pragma unroll
+                for (int i4 = 0; i4 < G; ++i4) {
+                    float wv[12];
+                    const tile_t *row = &tile[i4][PADMAX - 3 + lp];
+                    if constexpr (std::is_same<tile_t, float>::value) {
+#pragma unroll
+                        for (int v4 = 0; v4 < 3; ++v4) {
+                            const float4 x = *reinterpret_cast<const float4 *>(row + 4 * v4);
+                            wv[4 * v4] = x.x; wv[4 * v4 + 1] = x.y; wv[4 * v4 + 2] = x.z; wv[4 * v4 + 3] = x.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int v4 = 0; v4 < 3; ++v4) {
+                            const uint2 x = *reinterpret_cast<const uint2 *>(row + 4 * v4);
+                            wv[4 * v4] = h2f((uint16_t)(x.x & 0xffffu)); wv[4 * v4 + 1] = h2f((uint16_t)(x.x >> 16));
+                            wv[4 * v4 + 2] = h2f((uint16_t)(x.y & 0xffffu)); wv[4 * v4 + 3] = h2f((uint16_t)(x.y >> 16));
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float p;
+                        if (avg) {
+                            p = 0.0f;
+#pragma unroll
+                            for (int o = 0; o < KS; ++o) p = p + wv[e + 3 - PAD + o];
+                            p = p / (float)KS;
+                        } else {
+                            p = -INFINITY;
+#pragma unroll
+                            for (int o = 0; o < KS; ++o) { const float xv = wv[e + 3 - PAD + o]; if (xv > p || xv != xv) p = xv; }
+                        }
+                        pv[i4][e] = p;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int i4 = 0; i4 < G; ++i4) gs[e] = gs[e] + h2f(f2h(pv[i4][e]));
+                    if (!last_vh && j + e < n)
+                        __hip_atomic_store(chain_out + lp + e, granule(token, f32_bits(gs[e])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            uint16_t c16[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c16[e] = f2h_score(gs[e]);
+            if (any && last_vh) {
+                uint16_t *cp = c_out + (size_t)bg * c_row_stride + j;
+                if (j + 3 < n && (reinterpret_cast<uintptr_t>(cp) & 7) == 0) {
+                    *reinterpret_cast<uint2 *>(cp) = make_uint2((uint32_t)c16[0] | ((uint32_t)c16[1] << 16), (uint32_t)c16[2] | ((uint32_t)c16[3] << 16));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (j + e < n) cp[e] = c16[e];
+                }
+                if (all_idx) {                                   // capacity == S: identity selection + keys (see score_finalize)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (j + e < n) all_idx[(size_t)bg * n + j + e] = (int64_t)(j + e);
+                    if (all_keys) {
+                        uint16_t *kp = all_keys + (size_t)bg * all_key_stride + j;
+                        if (j + 3 < n && (reinterpret_cast<uintptr_t>(kp) & 7) == 0) {
+                            *reinterpret_cast<uint2 *>(kp) = make_uint2(mono16(c16[0]) | (mono16(c16[1]) << 16), mono16(c16[2]) | (mono16(c16[3]) << 16));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (j + e < n) kp[e] = (uint16_t)mono16(c16[e]);
+                        }
+                    }
+                }
+            }
+            if (want_hist && last_vh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hist12_add(s_hist, mono16(c16[e]) >> 4, any && j + e < n, lane);
+            }
+        }
+        FKF_STAMP(31);
+        if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
+        if (want_hist && last_vh) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
+        }
+    };
+    auto phaseD_any = [&](auto sc) {
+        if (ksize == 7) phaseD_vec(sc, std::integral_constant<int, 3>{});
+        else if (ksize == 5) phaseD_vec(sc, std::integral_constant<int, 2>{});
+        else if (ksize == 3) phaseD_vec(sc, std::integral_constant<int, 1>{});
+        else phaseD(sc);
+    };
+
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NS - 1>;            // (== S0 when NS == 1: the second calls below are compiled out)
     phaseA(S0{});
@@ -675,9 +810,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     FKF_STAMP(10);
     if (!read_halo(S0{})) return;
     FKF_STAMP(11);
-    phaseD(S0{});
+    phaseD_any(S0{});
     FKF_STAMP(12);
-    if (NS == 2) { if (!read_halo(S1{})) return; FKF_STAMP(13); phaseD(S1{}); }
+    if (NS == 2) { if (!read_halo(S1{})) return; FKF_STAMP(13); phaseD_any(S1{}); }
     FKF_STAMP(14);
 }
 

@@ -836,3 +836,36 @@ def test_operator_over_separately_allocated_entries(dev):
     with pytest.raises(Exception) as ei:
         ops.update_kv_entries(qs, kks, vs, 4, 7, "maxpool", 128, 0, "score")
     assert "unsupported" in str(ei.value).lower() or "-3" in str(ei.value) or "UNSUPPORTED" in str(ei.value)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=2, H=32, Hkv=8, S=32768, D=128, ks=7, pooling="avgpool", cap=2048, tsp=2048),     # two 32k layers of Llama-3-8B per launch
+    dict(B=1, H=32, Hkv=8, S=60001, D=64, ks=5, pooling="maxpool", cap=3000, tsp=0),          # one long ragged prompt, head_dim 64
+    dict(B=4, H=8, Hkv=2, S=40000, D=256, ks=7, pooling="avgpool", cap=700, tsp=900),         # head_dim 256, a batch
+])
+def test_four_tiles_per_wave_bit_exact(shape, dev):
+    """score_fused_kernel<D,4,NB,1>: a wave owns four tiles; the exponentials of two of them wait for phase C in LDS (the other two
+    in registers), the window-row sums are kept as fp16 bits.  Scores, indices, rows and the TSP index equal the oracle's, also with
+    non-finite values in K and in a window row of Q (the general softmax path of such tiles)."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    s = shape
+    q, k, v = make_qkv(8100 + s["B"], s["B"], s["H"], s["Hkv"], s["S"], s["D"], 8)
+    for special in (False, True):
+        if special:
+            k, q = k.clone(), q.clone()
+            k[0, 0, 1000, 5] = float("inf")
+            k[-1, 1, s["S"] - 3000, 1] = float("nan")
+            k[0, -1, 64:90] *= 1e-5
+            q[-1, 3, s["S"] - 2, 7] = float("inf")
+        qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+        for order in ("score", "index"):
+            want = O.update_kv(q, k, v, 8, s["ks"], s["pooling"], s["cap"], s["tsp"], order, return_scores=True)
+            got = ops.update_kv(qd, kd, vd, 8, s["ks"], s["pooling"], s["cap"], s["tsp"], order, return_indices=True, return_scores=True)
+            torch.cuda.synchronize()
+            assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), (special, order)
+            assert torch.equal(got[3].cpu(), want[2]), (special, order)
+            assert torch.equal(got[0].cpu().view(torch.int16), want[0].view(torch.int16)), (special, order)
+            assert torch.equal(got[1].cpu().view(torch.int16), want[1].view(torch.int16)), (special, order)
+            if s["tsp"]:
+                assert torch.equal(got[2].cpu(), want[3]), (special, order)
