@@ -42,6 +42,9 @@ def replace_llama(method):
         modeling_llama.LlamaAttention = _stock_of(modeling_llama, "LlamaAttention")
         modeling_llama.LlamaDecoderLayer.forward = _stock["llama_layer_forward"]
         modeling_llama.LlamaModel.forward = make_model_forward_general(_stock["llama_model_forward"])
+    # every compressing method decodes at the TRUE positions (monkeypatch.py:55-56); the full-KV arm keeps the stock preparation
+    LlamaForCausalLM.prepare_inputs_for_generation = (prepare_inputs_for_generation_llama if method != "fullkv"
+                                                      else _STOCK_PREPARE["llama"])
 
 
 def replace_mistral(method):
@@ -60,6 +63,8 @@ def replace_mistral(method):
         modeling_mistral.MistralAttention = _stock_of(modeling_mistral, "MistralAttention")
         modeling_mistral.MistralDecoderLayer.forward = _stock["mistral_layer_forward"]
         modeling_mistral.MistralModel.forward = make_model_forward_general(_stock["mistral_model_forward"])
+    MistralForCausalLM.prepare_inputs_for_generation = (prepare_inputs_for_generation_mistral if method != "fullkv"
+                                                        else _STOCK_PREPARE["mistral"])      # monkeypatch.py:101-102
 
 
 def set_model(model, args):
@@ -81,8 +86,8 @@ def set_model(model, args):
 # The reference overrides `prepare_inputs_for_generation` of transformers 4.45 so that, after a COMPRESSED prefill, decode
 # steps get their true positions (attention-mask cumsum, `:280-288`) instead of positions derived from the shorter cache.
 # The installed transformers (5.x) already derives `position_ids` from the attention mask inside `generate()`; these two
-# functions keep the reference's names importable and enforce exactly that rule on top of the stock implementation, so a
-# caller that installs them (as the reference's `replace_llama` / `replace_mistral` do) gets the same behaviour on both.
+# functions keep the reference's names and enforce exactly that rule on top of the stock implementation; `replace_llama` /
+# `replace_mistral` install them for every compressing method, as the reference does (`:55-56`, `:101-102`).
 def _prepare_inputs_true_positions(stock):
     def prepare(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, position_ids=None, **kwargs):
         model_inputs = stock(self, input_ids, past_key_values=past_key_values, attention_mask=attention_mask,
@@ -100,5 +105,6 @@ def _prepare_inputs_true_positions(stock):
 import torch  # noqa: E402  (only the two functions below need it)
 from transformers import LlamaForCausalLM, MistralForCausalLM  # noqa: E402
 
-prepare_inputs_for_generation_llama = _prepare_inputs_true_positions(LlamaForCausalLM.prepare_inputs_for_generation)
-prepare_inputs_for_generation_mistral = _prepare_inputs_true_positions(MistralForCausalLM.prepare_inputs_for_generation)
+_STOCK_PREPARE = {"llama": LlamaForCausalLM.prepare_inputs_for_generation, "mistral": MistralForCausalLM.prepare_inputs_for_generation}
+prepare_inputs_for_generation_llama = _prepare_inputs_true_positions(_STOCK_PREPARE["llama"])
+prepare_inputs_for_generation_mistral = _prepare_inputs_true_positions(_STOCK_PREPARE["mistral"])

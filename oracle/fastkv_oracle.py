@@ -28,7 +28,16 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    """Compile the C restatement with gcc (seconds).  Returns the path of the .so."""
+    """Compile the C restatement with gcc (seconds).  Returns the path of the .so.
+    FASTKV_ORACLE_SANITIZE=1 (tests/test_oracle_golden.py::test_oracle_under_address_and_ub_sanitizers): the same source with
+    -fsanitize=address,undefined into its own file -- to be loaded by a process started with the sanitizer runtime preloaded."""
+    if os.environ.get("FASTKV_ORACLE_SANITIZE", "0") == "1":
+        san = os.path.join(_HERE, "libfastkv_oracle_asan.so")
+        if force or not os.path.exists(san) or os.path.getmtime(san) < os.path.getmtime(_SRC):
+            flags = [f for f in CFLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                                                         "-fno-sanitize-recover=undefined"]
+            subprocess.check_call(["gcc", *flags, "-o", san, _SRC, "-lm"])
+        return san
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
         subprocess.check_call(["gcc", *CFLAGS, "-o", _LIB, _SRC, "-lm"])
     return _LIB

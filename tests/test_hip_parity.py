@@ -869,3 +869,23 @@ def test_four_tiles_per_wave_bit_exact(shape, dev):
             assert torch.equal(got[1].cpu().view(torch.int16), want[1].view(torch.int16)), (special, order)
             if s["tsp"]:
                 assert torch.equal(got[2].cpu(), want[3]), (special, order)
+
+
+def test_debug_bounds_build_runs_the_randomised_shapes(dev, tmp_path):
+    """The index-bounds debug build SURVEY.md 5 plans in place of a GPU sanitizer: the whole library compiled with
+    -DFK_DEBUG_BOUNDS into a temporary directory (every gather -- compact_kv, gather_rows -- then TRAPS on an index outside
+    [0, S) instead of clamping it) and the randomised-shapes case + the entries / keep-all cases run against it in a child
+    process: no index the selection hands to a gather is ever out of range."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FASTKV_BUILD_DIR=str(tmp_path / "dbg_lib"), FASTKV_CXXFLAGS="-DFK_DEBUG_BOUNDS")
+    code = ("import sys, pytest, fastkv_amd._build as b; assert b.LIBDIR.endswith('dbg_lib'); "
+            "from fastkv_amd._lib import load; load(); assert b.os.path.exists(b.LIB); "
+            "sys.exit(pytest.main(['tests/test_hip_parity.py', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', "
+            "'randomised_shapes or separately_allocated or keep_all_layers']))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    objs = os.listdir(tmp_path / "dbg_lib" / "obj")
+    assert any(o.endswith(".flags") and "-DFK_DEBUG_BOUNDS" in open(tmp_path / "dbg_lib" / "obj" / o).read() for o in objs)

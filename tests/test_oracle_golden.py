@@ -260,3 +260,27 @@ def test_gemfilter_rule_matches_reference_standard_dis_index():
                 vk = float(ref[b, r][want[b, r][-1]])
                 rs = set(ridx[b, r].tolist())
                 assert set(torch.nonzero(ref[b, r].float() > vk).flatten().tolist()) <= rs <= set(torch.nonzero(ref[b, r].float() >= vk).flatten().tolist())
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """SURVEY.md 5 (race detection / sanitizers: no GPU twin of compute-sanitizer exists, and GPU AddressSanitizer is not available
+    on this pool): the CPU restatement built with -fsanitize=address,undefined replays the small goldens -- tiny_*, the ragged
+    MHA / head_dim 64 case, k == n -- plus the tie-rule, NaN and gather tests in a child process with the sanitizer runtime
+    preloaded.  Any out-of-bounds access, misaligned load, signed overflow or shift error in oracle/fastkv_oracle.c ends the child
+    with a report."""
+    import os
+    import subprocess
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan next to this gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FASTKV_ORACLE_SANITIZE="1", LD_PRELOAD=asan, OMP_NUM_THREADS="2",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98")
+    sel = "(test_oracle_matches_reference_golden and (tiny or ragged_mha_d64 or k_eq_n)) or tie_rule or nan_scores or gather_rows"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_oracle_golden.py"), "-x", "-q", "-k", sel,
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out, out[-3000:]
+    assert r.returncode == 0 and " passed" in r.stdout, out[-3000:]
+    assert os.path.exists(os.path.join(root, "oracle", "libfastkv_oracle_asan.so"))          # (the child really loaded the sanitized build)

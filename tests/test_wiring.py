@@ -233,17 +233,20 @@ def test_eager_attention_stays_causal_after_the_tsp_layer():
 def test_generate_decodes_at_true_positions_after_a_compressed_prefill(install_override):
     """`model.generate()` on top of a compressed prefill: decode steps must run at the prompt's TRUE positions (200, 201, ...),
     not at positions derived from the 40-row cache -- what the reference's prepare_inputs_for_generation override provides on
-    transformers 4.45 (/root/reference/baselines/monkeypatch.py:280-288).  The installed transformers does it by itself;
-    with the reference-named override installed the result is the same."""
+    transformers 4.45 (/root/reference/baselines/monkeypatch.py:280-288) and what `replace_llama("fastkv")` installs here too
+    (`:55-56`).  The installed transformers derives the positions by itself as well: same result with the stock preparation;
+    `replace_llama("fullkv")` puts the stock one back."""
     from transformers import LlamaForCausalLM
     from baselines import monkeypatch as MP
     from benchmark import prefill
     a = _args(method="fastkv", max_capacity_prompts=40, tsp_len=80, tsp_idx=0)
     a.context_lengths = [200]
     MP.replace_llama("fastkv")
+    # replace_llama installs the override for every compressing method, as the reference does (monkeypatch.py:55-56) ...
+    assert LlamaForCausalLM.prepare_inputs_for_generation is MP.prepare_inputs_for_generation_llama
     stock = LlamaForCausalLM.prepare_inputs_for_generation
-    if install_override:
-        LlamaForCausalLM.prepare_inputs_for_generation = MP.prepare_inputs_for_generation_llama      # as monkeypatch.py:55-56
+    if not install_override:                                       # ... and the stock preparation gives the same positions here
+        LlamaForCausalLM.prepare_inputs_for_generation = MP._STOCK_PREPARE["llama"]
     try:
         torch.manual_seed(17)
         model = prefill.build_model(a, "cpu")
@@ -267,3 +270,6 @@ def test_generate_decodes_at_true_positions_after_a_compressed_prefill(install_o
         assert seen == [(199, 0), (200, 40), (201, 41), (202, 42)]
     finally:
         LlamaForCausalLM.prepare_inputs_for_generation = stock
+    MP.replace_llama("fullkv")
+    assert LlamaForCausalLM.prepare_inputs_for_generation is MP._STOCK_PREPARE["llama"]
+    MP.replace_llama("fastkv")
