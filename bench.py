@@ -140,35 +140,45 @@ def profile_read(lib):
 
 def compact_roofline_shape(lib, dev, steps):
     """Same row geometry as the 32k config (256-B rows at 2 KiB pitch, 2040+8 rows per head) but 32 'layers' in one
-    launch: 2 x 2 GiB sources, 539 MB of algorithmic traffic, nothing served from the 256 MiB Infinity Cache.
+    launch: 2 x 2 GiB sources, 541 MB of algorithmic traffic, nothing served from the 256 MiB Infinity Cache.
     Both row orders: `index` (rows in ascending position: a pure gather) and `score` (the reference's order, utils.py:113,
     what the product's default path produces: with this shape's 256 heads the winners' slots come from one grouping pass per
     head, `rank_group_kernel`, launched inside the same timed bracket as the copy; a single layer's 8 heads are ranked by
-    comparison counting inside the copy kernel instead -- `compact.per_layer_avg_us`)."""
+    comparison counting inside the copy kernel instead -- `compact.per_layer_avg_us`).
+    THREE disjoint source sets are rotated (12 GiB in all) and every call's kernel bracket (HIP events on the launch stream) is
+    read on its own: the line carries min / median / max over the calls, so that a call-to-call spread is visible."""
+    import statistics
     from fastkv_amd import ops
     B, Hkv, S, D, W, cap = 32, CFG["Hkv"], CFG["S"], CFG["D"], CFG["window"], CFG["budget"]
-    k = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
-    v = torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)
+    sets = [(torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2),
+             torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)) for _ in range(3)]
     sc = torch.rand(B * Hkv, S - W, device=dev).half()
     idx = ops.select(sc, cap - W, "index").view(B, Hkv, cap - W).contiguous()     # realistic per-head index sets
     sc3 = sc.view(B, Hkv, S - W)
     nbytes = 2 * (2 * B * Hkv * cap * D * 2) + B * Hkv * (cap - W) * 8
-    res = {"shape": f"B={B} (32 layers stacked), Hkv={Hkv}, S={S}, D={D}, cap={cap}", "bytes": nbytes}
+    res = {"shape": f"B={B} (32 layers stacked), Hkv={Hkv}, S={S}, D={D}, cap={cap}", "bytes": nbytes, "source_sets_rotated": len(sets)}
+    reps = max(4, steps // 2)
     for order, kw in (("index", {}), ("score", {"scores": sc3})):
-        for _ in range(2):
+        for k, v in sets:
             ops.compact(k, v, idx, W, **kw)
         torch.cuda.synchronize()
-        profile_read(lib)
-        lib.fastkv_profile_enable(1)
-        for _ in range(steps):
-            ops.compact(k, v, idx, W, **kw)
-        torch.cuda.synchronize()
-        lib.fastkv_profile_enable(0)
-        cnt, ms = profile_read(lib)["compact_kv"]
-        us = ms / cnt * 1e3
-        res[order] = {"avg_us": round(us, 2), "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1),
-                      "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
-    del k, v
+        us = []
+        for _ in range(reps):
+            for k, v in sets:
+                profile_read(lib)
+                lib.fastkv_profile_enable(1)
+                ops.compact(k, v, idx, W, **kw)
+                torch.cuda.synchronize()
+                lib.fastkv_profile_enable(0)
+                cnt, ms = profile_read(lib)["compact_kv"]                    # (score order: the grouping pass + the copy, one bracket)
+                us.append(ms / cnt * 1e3)
+        us.sort()
+        med = statistics.median(us)
+        res[order] = {"avg_us": round(med, 2), "min_us": round(us[0], 2), "median_us": round(med, 2), "max_us": round(us[-1], 2), "calls": len(us),
+                      "achieved_GBps": round(nbytes / (med * 1e-6) / 1e9, 1), "frac_of_8TBps": round(nbytes / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                      "frac_of_8TBps_best": round(nbytes / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                      "frac_of_8TBps_worst": round(nbytes / (us[-1] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+    del sets
     return res
 
 

@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # FASTKV_BUILD_DIR: build (and load) the library somewhere else than in-tree -- for instrumented builds that must not replace
-# the product's .so (tests/test_hip_parity.py::test_debug_bounds_build_runs_the_randomised_shapes: -DFK_DEBUG_BOUNDS in a temp dir)
+# the product's .so (e.g. FASTKV_CXXFLAGS=-DFK_STAMP, -DFK_DEBUG_BOUNDS)
 LIBDIR = os.environ.get("FASTKV_BUILD_DIR") or os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfastkv_hip.so")
 SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "sp.hip", "decode.hip", "gemv.hip", "capi.hip", "debug.hip", "prof.hip"]

@@ -11,7 +11,7 @@ from . import _build
 
 
 # return codes of the C ABI (include/fastkv_hip.h)
-FASTKV_OK, FASTKV_EINVAL, FASTKV_EWORKSPACE, FASTKV_ELAUNCH, FASTKV_EUNSUPPORTED, FASTKV_EABORTED, FASTKV_EOVERFLOW = 0, -1, -2, -3, -4, -5, -6
+FASTKV_OK, FASTKV_EINVAL, FASTKV_EWORKSPACE, FASTKV_ELAUNCH, FASTKV_EUNSUPPORTED, FASTKV_EABORTED, FASTKV_EOVERFLOW, FASTKV_EBOUNDS = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class FastKVNativeError(RuntimeError):

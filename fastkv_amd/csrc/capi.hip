@@ -22,6 +22,7 @@ uint32_t *abort_flag_device()
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
         reinterpret_cast<volatile uint32_t *>(h)[0] = 0;
         reinterpret_cast<volatile uint32_t *>(h)[1] = 0;
+        reinterpret_cast<volatile uint32_t *>(h)[2] = 0;
         g_abort_host = reinterpret_cast<uint32_t *>(h);
         g_abort_dev = reinterpret_cast<uint32_t *>(d);
     });
@@ -42,6 +43,8 @@ static int take_abort_status()
     // word 0: a launch gave up a bounded in-kernel wait; word 1: a decode step ran into a full cache slab (decode.hip)
     if (__atomic_load_n(g_abort_host, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EABORTED;
     if (__atomic_load_n(g_abort_host + 1, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 1, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EOVERFLOW;
+    // word 2 (FASTKV_DEBUG_BOUNDS=1 only): a gather was handed an index outside [0, S) (compact.hip)
+    if (__atomic_load_n(g_abort_host + 2, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 2, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EBOUNDS;
     return FASTKV_OK;
 }
 }  // namespace fk
@@ -450,6 +453,8 @@ const char *fastkv_strerror(int code)
     case FASTKV_EOVERFLOW:
         return "an earlier static-decode step ran into a full cache slab (more steps than enable_static_decode reserved rows for): "
                "the last cached row was overwritten, the tokens from that step on are invalid";
+    case FASTKV_EBOUNDS:
+        return "index-bounds debug mode (FASTKV_DEBUG_BOUNDS=1): an earlier gather was handed a row index outside [0, S) (it read a clamped row)";
     case FASTKV_EUNSUPPORTED: return "unsupported configuration (head_dim must be 64/128/256, S < 2^24)";
     default: return "unknown error";
     }

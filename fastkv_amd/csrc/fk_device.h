@@ -204,6 +204,16 @@ __device__ __forceinline__ f32x2 scale_div2(f32x2 x, float c, float rc)
     return q1;
 }
 
+// scale_div2 for FINITE x whose zero sign does not matter: the plain Newton pair, nothing selected.  x = +-inf would give NaN
+// (the caller sends such tiles through scale_div2); x = -0 gives +0 where the division gives -0 -- indistinguishable for a
+// softmax LOGIT: exp(x - max) and max itself treat the two zeros alike (fused.hip, phase A).
+__device__ __forceinline__ f32x2 scale_div2_finite(f32x2 x, float c, float rc)
+{
+    const f32x2 q0 = x * splat2(rc);
+    const f32x2 r = fma2(-q0, splat2(c), x);
+    return fma2(r, splat2(rc), q0);
+}
+
 // Reduction of 16 per-lane values over the 32 lanes of a half wave in 16 exchanges instead of 80: every step halves the
 // number of values a lane carries (it keeps the half selected by one bit of its lane id and sends the other half to the
 // partner).  Returns the fully reduced value of index halfwave_red_index(lane); lanes 2t and 2t+1 hold the same one.

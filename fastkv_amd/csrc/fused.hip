@@ -274,9 +274,25 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 if (redo_tile_if_nan<NPH, NB>(acc0, acc1, kb_s[s], ks_s, key0, S, lane, my, As + s * AS_FLOATS + lane, n31, sh))
                     tile_nan |= 1u << t;
                 const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
-                if (key0 + TK <= n) {
-                    // tile entirely among the candidates: no window mask, every column counts; the running maxima stay
-                    // packed fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf)
+                // largest magnitude among the tile's fp32 results (NaN-free here unless redo_tile_if_nan said so): below 65520 no
+                // logit rounds to an fp16 infinity, and the division needs no special cases (scale_div2_finite)
+                float amax = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(acc0[i]), NB == 2 ? __builtin_fabsf(acc1[i]) : 0.0f));
+                const bool tame = __all(amax < 65520.0f) && !((tile_nan >> t) & 1u);                            // wave-uniform
+                if (key0 + TK <= n && tame) {
+                    // tile entirely among the candidates, every logit finite: no window mask, every column counts; the running
+                    // maxima stay packed fp16 pairs (v_pk_max_f16: maxNum, ignores NaN like fmaxf)
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[(i + 8) & 15]);             // matmul -> fp16
+                        const f32x2 scv = scale_div2_finite((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);   // utils.py:94
+                        const uint32_t wd = f2h2(scv.x, scv.y);
+                        mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
+                                                                                          __builtin_bit_cast(h16x2, wd)));
+                        lg[t][i] = wd;
+                    }
+                } else if (key0 + TK <= n) {
 #pragma unroll
                     for (int i = 0; i < NW; ++i) {
                         const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[(i + 8) & 15]);             // matmul -> fp16

@@ -57,4 +57,32 @@ __device__ __forceinline__ uint32_t rank_partial(const uint16_t *__restrict__ ke
     return (acc & 0xffffu) + (acc >> 16);
 }
 
+// The same count over a key list in LDS that is ZERO PADDED TO A MULTIPLE OF 8 * 4 * nsub keys (the copy kernel pads it): no
+// vector needs a bounds test, and the vector that holds p is counted with the side threshold like every other one and corrected
+// afterwards by its owner -- 14 instead of ~20 instructions per vector (the counting is the copy launch's vector-ALU bill: k^2
+// packed compares per head, 4.7 us of issue time per 32k layer).  kp >= 1.
+__device__ __forceinline__ uint32_t rank_partial_padded(const uint16_t *__restrict__ keys, int kpad, int p, uint32_t kp, int sub, int nsub)
+{
+    const int nvp = kpad >> 3, pv = p >> 3, pe = p & 7;
+    const uint32_t t_hi = kp * 0x00010001u, t_lo = (kp - 1u) * 0x00010001u;
+    uint32_t acc = 0;
+    for (int v0 = sub; v0 < nvp; v0 += 4 * nsub) {
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint4 *>(keys + (v0 + u * nsub) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t ts = (v0 + u * nsub) < pv ? t_lo : t_hi;       // vector pv itself: t_hi, corrected below
+            acc += pk_gt(x[u].x, ts) + pk_gt(x[u].y, ts) + pk_gt(x[u].z, ts) + pk_gt(x[u].w, ts);
+        }
+    }
+    uint32_t cnt = (acc & 0xffffu) + (acc >> 16);
+    if ((pv % nsub) == sub) {
+        // elements of vector pv in front of p count when key >= kp, not only when key > kp: add those equal to kp
+        const uint16_t *kv = keys + pv * 8;
+        for (int e = 0; e < pe; ++e) cnt += kv[e] == kp;
+    }
+    return cnt;
+}
+
 }  // namespace fk

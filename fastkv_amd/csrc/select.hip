@@ -422,6 +422,36 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
                            __HIP_MEMORY_SCOPE_AGENT);
     // ---------------- phase 2: totals over the row and over the chunks before this one
     const int ng = nchunks * 17;
+    if (ng <= 4 * SPL_THREADS) {
+        // (rows of up to 60 chunks -- 122,880 positions: every prompt of the reference's drivers) the granules a thread polls stay
+        // in its registers: the pass that finds every tag current IS the read -- one memory round trip less than poll, then read
+        for (;;) {
+            bool ok = true;
+            uint64_t gr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + u * SPL_THREADS, ic = i < ng ? i : 0, cc = ic / 17, f = ic - cc * 17;
+                gr[u] = __hip_atomic_load(&tab[cc * SPL_LINE + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (uint32_t)(gr[u] >> 32) == token;
+            }
+            if (__syncthreads_and(ok)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + u * SPL_THREADS, cc = i / 17, f = i - cc * 17;
+                    const uint32_t v = (uint32_t)gr[u];
+                    if (i < ng && v) {
+                        atomicAdd(&sh.tot[f], v);
+                        if (cc < chunk) atomicAdd(&sh.pre[f], v);
+                    }
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+            if (tid == 0 && spin_failed(sp)) s_abort = 1;                // chunks of this row never arrived: give up, loudly (host flag)
+            __syncthreads();
+            if (s_abort) return;
+        }
+    } else {
     for (;;) {                                                           // until every chunk's granules carry this call's token
         bool ok = true;
         for (int i = tid; i < ng; i += SPL_THREADS) {
@@ -441,6 +471,7 @@ __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_
             atomicAdd(&sh.tot[f], v);
             if (cc < chunk) atomicAdd(&sh.pre[f], v);
         }
+    }
     }
     }
     __syncthreads();

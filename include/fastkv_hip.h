@@ -35,6 +35,8 @@ extern "C" {
 #define FASTKV_EUNSUPPORTED (-4)
 #define FASTKV_EABORTED (-5)   /* an EARLIER fused launch gave up a bounded in-kernel wait; see fastkv_workspace_init */
 #define FASTKV_EOVERFLOW (-6)  /* an EARLIER static-decode step found its cache slab full (reported like FASTKV_EABORTED) */
+#define FASTKV_EBOUNDS (-7)    /* FASTKV_DEBUG_BOUNDS=1 only: an EARLIER gather was handed a row index outside [0, S) (it read a
+                                  clamped row, as always; reported like FASTKV_EABORTED) */
 
 #define FASTKV_POOL_AVG 0 /* F.avg_pool1d(k, padding=k//2, stride=1)   utils.py:105-106 */
 #define FASTKV_POOL_MAX 1 /* F.max_pool1d(k, padding=k//2, stride=1)   utils.py:107-108 */

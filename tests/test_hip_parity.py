@@ -871,21 +871,29 @@ def test_four_tiles_per_wave_bit_exact(shape, dev):
                 assert torch.equal(got[2].cpu(), want[3]), (special, order)
 
 
-def test_debug_bounds_build_runs_the_randomised_shapes(dev, tmp_path):
-    """The index-bounds debug build SURVEY.md 5 plans in place of a GPU sanitizer: the whole library compiled with
-    -DFK_DEBUG_BOUNDS into a temporary directory (every gather -- compact_kv, gather_rows -- then TRAPS on an index outside
-    [0, S) instead of clamping it) and the randomised-shapes case + the entries / keep-all cases run against it in a child
-    process: no index the selection hands to a gather is ever out of range."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FASTKV_BUILD_DIR=str(tmp_path / "dbg_lib"), FASTKV_CXXFLAGS="-DFK_DEBUG_BOUNDS")
-    code = ("import sys, pytest, fastkv_amd._build as b; assert b.LIBDIR.endswith('dbg_lib'); "
-            "from fastkv_amd._lib import load; load(); assert b.os.path.exists(b.LIB); "
-            "sys.exit(pytest.main(['tests/test_hip_parity.py', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', "
-            "'randomised_shapes or separately_allocated or keep_all_layers']))")
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    objs = os.listdir(tmp_path / "dbg_lib" / "obj")
-    assert any(o.endswith(".flags") and "-DFK_DEBUG_BOUNDS" in open(tmp_path / "dbg_lib" / "obj" / o).read() for o in objs)
+def test_index_bounds_debug_mode(dev):
+    """The index-bounds debug mode SURVEY.md 5 plans in place of a GPU sanitizer (FASTKV_DEBUG_BOUNDS=1, or a build with
+    -DFK_DEBUG_BOUNDS): every gather -- compact_kv, gather_rows -- REPORTS an index outside [0, S) (FASTKV_EBOUNDS from
+    fastkv_last_status) besides clamping it.  The randomised-shapes case, the entries / keep-all cases and the slab-cache wiring run
+    in that mode in a child process: no index the selection hands to a gather is ever out of range; a deliberately bad index is
+    reported in that mode and silently clamped in the product mode."""
+    code = """
+import sys, pytest, torch
+rc = pytest.main(['tests/test_hip_parity.py', 'tests/test_wiring_gpu.py', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k',
+                  'test_randomised_shapes_bit_exact or test_operator_over_separately_allocated_entries or test_keep_all_layers_bit_exact or test_slab_cache_in_place'])
+from fastkv_amd import ops
+from fastkv_amd._lib import load
+torch.cuda.synchronize()
+st = load().fastkv_last_status()
+print('status after the cases:', st)
+x = torch.arange(64 * 128, dtype=torch.float16, device='cuda').view(1, 64, 128)
+y = ops.gather_rows(x, torch.tensor([[3, 64]], device='cuda'))         # 64 is out of range: reads the clamped row 63
+torch.cuda.synchronize()
+print('status after the bad index:', load().fastkv_last_status(), 'clamped:', bool(torch.equal(y[0, 1], x[0, 63])))
+sys.exit(int(rc) or (0 if st == 0 else 9))
+"""
+    r = _child(code, {"FASTKV_DEBUG_BOUNDS": "1"})
+    assert r.returncode == 0 and " passed" in r.stdout and "status after the cases: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "status after the bad index: -7 clamped: True" in r.stdout, r.stdout[-500:]
+    r = _child(code.replace("rc = pytest.main", "rc = 0 and pytest.main"), {"FASTKV_DEBUG_BOUNDS": "0"})       # product mode: clamped, not reported
+    assert r.returncode == 0 and "status after the bad index: 0 clamped: True" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
