@@ -131,7 +131,7 @@ class DeferredCompression:
         # (an instance whose update_kv was wrapped -- a spy, an adapter -- expects to be called: not deferred)
         return (type(cluster) is FastKVCluster and "update_kv" not in vars(cluster)
                 and key_states.is_cuda and key_states.dtype == torch.float16
-                and query_states.dtype == torch.float16 and key_states.shape[0] == 1
+                and query_states.dtype == torch.float16
                 and (key_states.shape[2] <= self.max_len or self.hold_long >= 2))
 
     def add_tsp_layer(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None):
@@ -158,7 +158,8 @@ class DeferredCompression:
                                                             cluster.kernel_size, cluster.pooling, plan.capacity, plan.tsp_len,
                                                             cluster.kv_order, outs=o)
                 self.groups.pop(key)
-                return k_outs[1], v_outs[1], tsp[1:2], [(peer[0], k_outs[0], v_outs[0])]
+                Bq = q.shape[0]                                   # (rows i*Bq .. of the index tensor belong to entry i)
+                return k_outs[1], v_outs[1], tsp[Bq:2 * Bq], [(peer[0], k_outs[0], v_outs[0])]
             except FastKVNativeError as e:
                 # Only "this pair cannot go through one launch sequence" (nothing was launched) sends the TSP layer on alone; the
                 # peer stays in its group for `flush`.  Anything else -- FASTKV_EABORTED from an EARLIER launch, FASTKV_ELAUNCH --

@@ -90,65 +90,7 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
         const uint16_t *kr = keys + (size_t)bg * kal;
         const int pc = rc < kk ? rc : kk - 1;
         uint32_t rk;
-        if (keys_in_lds == 4) {
-            // The head's winners grouped by key range ONCE per workgroup (a counting sort in LDS: 256 bins between the head's
-            // smallest and largest key), then a row is counted against the members of ITS bin only: ~k/256 compares per row
-            // instead of k.  (The plain counting below costs k^2 packed compares per head -- 9 us of vector-ALU issue time per
-            // 32k layer, PMC SQ_INSTS_VALU 5.6 M per launch -- and was what bounded the copy launch in score order.)  A head
-            // whose keys are all equal degenerates to one bin = the old cost.
-            constexpr int NBIN = 256;
-            uint32_t *b_cnt = reinterpret_cast<uint32_t *>(s_keys + ((kal + 7) & ~7));          // [NBIN] members per bin
-            uint32_t *b_start = b_cnt + NBIN, *b_cur = b_start + NBIN;                         // [NBIN] winners in higher bins; scatter cursors
-            uint32_t *grp = b_cur + NBIN;                                                     // [kal] composites grouped by bin
-            uint32_t *red = grp + kal;                                                        // [16] cross-wave scratch
-            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-            uint32_t mn = 0xffffu, mx = 0;
-            for (int i = threadIdx.x * 8; i < kal; i += 256 * 8) {
-                const uint4 v8 = *reinterpret_cast<const uint4 *>(kr + i);
-                *reinterpret_cast<uint4 *>(s_keys + i) = v8;
-                const uint32_t wds[4] = {v8.x, v8.y, v8.z, v8.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t x = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                    if (i + e < kk) { mn = min(mn, x); mx = max(mx, x); }
-                }
-            }
-            b_cnt[threadIdx.x] = 0;
-            b_cur[threadIdx.x] = 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
-            if (lane == 0) { red[w] = mn; red[4 + w] = mx; }
-            __syncthreads();
-            mn = min(min(red[0], red[1]), min(red[2], red[3]));
-            mx = max(max(red[4], red[5]), max(red[6], red[7]));
-            int sh = 0;
-            while (((mx - mn) >> sh) >= (uint32_t)NBIN) ++sh;
-            for (int i = threadIdx.x; i < kk; i += 256) atomicAdd(&b_cnt[(s_keys[i] - mn) >> sh], 1u);
-            __syncthreads();
-            {
-                // suffix sums: thread t owns bin t; start[t] = number of winners in bins above t
-                const uint32_t c = b_cnt[threadIdx.x];
-                uint32_t v = c;                                                              // -> sum over this and the higher lanes of the wave
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = (uint32_t)__shfl_down((int)v, o, 64); if (lane + o < 64) v += nb; }
-                if (lane == 0) red[8 + w] = v;
-                __syncthreads();
-                uint32_t higher = 0;
-                for (int i = w + 1; i < 4; ++i) higher += red[8 + i];
-                b_start[threadIdx.x] = v - c + higher;
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < kk; i += 256) {
-                const uint32_t key = s_keys[i], bin = (key - mn) >> sh;
-                grp[b_start[bin] + atomicAdd(&b_cur[bin], 1u)] = (key << 16) | (uint32_t)(65535 - i);
-            }
-            __syncthreads();
-            const uint32_t kp = s_keys[pc], bin = (kp - mn) >> sh, me = (kp << 16) | (uint32_t)(65535 - pc);
-            const uint32_t lo = b_start[bin], nm = b_cnt[bin];
-            uint32_t c = 0;
-            for (uint32_t u = sub; u < nm; u += LPR) c += grp[lo + u] > me ? 1u : 0u;           // larger key, or the same key at an earlier position
-            rk = c + (sub == 0 ? lo : 0u);
-        } else if (keys_in_lds) {                             // one 16-B load per thread instead of kal/8/LPR dependent L2 trips
+        if (keys_in_lds) {                                    // one 16-B load per thread instead of kal/8/LPR dependent L2 trips
             const int kpad = (kal + 32 * LPR - 1) / (32 * LPR) * (32 * LPR);     // whole steps of rank_partial_padded; zeros never count
             for (int i = threadIdx.x * 8; i < kpad; i += 256 * 8)
                 *reinterpret_cast<uint4 *>(s_keys + i) = i < kal ? *reinterpret_cast<const uint4 *>(kr + i) : make_uint4(0u, 0u, 0u, 0u);
@@ -258,12 +200,7 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
     ProfScope ps_(K_COMPACT, st);
     const size_t kal = ((size_t)(p.capacity - p.window) + 7) & ~(size_t)7;
     int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                      // 32 KiB of LDS at most
-    // FASTKV_COMPACT_BUCKETS (measurement switch): 0 = comparison counting / the grouping pass as in round 2; 1 = winners grouped
-    // inside every copy workgroup when there are few heads, the grouping pass in front of the copy for 64 heads or more; 2 = grouped
-    // inside the copy workgroups always
-    static const int bucket_mode = []() { const char *e = getenv("FASTKV_COMPACT_BUCKETS"); return e ? atoi(e) : 1; }();
-    const bool in_wg = bucket_mode >= 1 && kal <= 8192 && kal >= 256;
-    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 2688 && !(in_wg && bucket_mode >= 2)) {           // (its LDS: 48 KiB of bins + 6 bytes per winner <= 64 KiB)
+    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 2688) {           // (its LDS: 48 KiB of bins + 6 bytes per winner <= 64 KiB)
         // many heads: every head's key list becomes its slot list (workspace memory of this call)
         const int kk_ = p.capacity - p.window;
         const size_t lds = (size_t)3 * RG_BINS * 4 + kal * 4 + kal * 2;
@@ -271,11 +208,7 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
         keys_in_lds = 2;
     }
     const size_t kpad = (kal + 32 * (size_t)lpr - 1) / (32 * (size_t)lpr) * (32 * (size_t)lpr);   // (rank_partial_padded reads whole steps)
-    // score order: the winners are grouped by key range inside every copy workgroup.  LDS: keys + 3 x 256 bin words + one word per
-    // winner + scratch
-    if (keys_in_lds == 1 && in_wg) keys_in_lds = 4;
-    const size_t dyn = keys_in_lds == 1 ? kpad * sizeof(uint16_t)
-                     : keys_in_lds == 4 ? ((kal + 7) & ~(size_t)7) * sizeof(uint16_t) + (3 * 256 + kal + 16) * sizeof(uint32_t) : 0;
+    const size_t dyn = keys_in_lds == 1 ? kpad * sizeof(uint16_t) : 0;
 #define FK_COMPACT(LPRV)                                                                                                   \
     hipLaunchKernelGGL((compact_kv_kernel<LPRV>), grid, dim3(256), dyn, st, (const uint16_t *)k, ks[0], ks[1], ks[2],       \
                        (const uint16_t *)v, vs[0], vs[1], vs[2], idx, keys, idx_sorted_out, p.Hkv, p.S, p.window,           \

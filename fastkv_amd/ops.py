@@ -463,14 +463,16 @@ def _stage_ptr_table(rows, device: torch.device) -> torch.Tensor:
 def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, capacity: int, tsp_len: int = 0, order: str = "score",
                       outs=None, return_indices: bool = False):
     """`update_kv` over SEPARATELY ALLOCATED entries in one launch sequence (fastkv_update_kv_ptrs_f16): qs / ks / vs are lists
-    of [1,H,S,D] / [1,Hkv,S,D] fp16 tensors of ONE geometry and ONE memory layout (e.g. the layers of a model whose compression
-    was deferred to the end of the forward pass).  Returns (k_outs, v_outs, tsp_idx [n,tsp_len] | None[, kv_idx [n,Hkv,cap-W]]);
-    `outs` = (list of k buffers, list of v buffers), [1,Hkv,cap,D] views of one stride pattern, to write into.
+    of [Bq,H,S,D] / [Bq,Hkv,S,D] fp16 tensors of ONE geometry and ONE memory layout (e.g. the layers of a model whose compression
+    was deferred to the end of the forward pass; every batch row of every tensor becomes one entry of the library call).
+    Returns (k_outs, v_outs, tsp_idx [n*Bq,tsp_len] | None[, kv_idx [n*Bq,Hkv,cap-W]]), rows i*Bq .. (i+1)*Bq-1 belonging to tensor i;
+    `outs` = (list of k buffers, list of v buffers), [Bq,Hkv,cap,D] views of one stride pattern, to write into.
     Raises FastKVNativeError(FASTKV_EUNSUPPORTED) for geometries off the fused scoring path: call `update_kv` per entry then."""
     n = len(qs)
     assert n >= 1 and len(ks) == n and len(vs) == n
     q0, k0, v0 = qs[0], ks[0], vs[0]
     _check_qkv(q0, k0, v0)
+    Bq = q0.shape[0]
 
     def same_layout(ok: bool, what: str):
         # entries that do not share one geometry / layout / alignment cannot go through one launch sequence: the caller runs them
@@ -479,28 +481,35 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
             raise FastKVNativeError(f"fastkv_amd.update_kv_entries: entries differ in {what}", code=FASTKV_EUNSUPPORTED)
 
     for q, k, v in zip(qs, ks, vs):
-        same_layout(q.shape == q0.shape and k.shape == k0.shape and v.shape == v0.shape and q.shape[0] == 1, "shape")
+        same_layout(q.shape == q0.shape and k.shape == k0.shape and v.shape == v0.shape, "shape")
         same_layout(q.stride() == q0.stride() and k.stride() == k0.stride() and v.stride() == v0.stride(), "strides")
         same_layout(q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16, "dtype")
         same_layout((q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0, "16-byte alignment")
     L = load()
     p = _problem(q0, k0, window, kernel_size, pooling, capacity, tsp_len, order)
-    p.B = n
+    p.B = n * Bq
     Hkv, D, dev = p.Hkv, p.D, q0.device
     if outs is None:
-        kb = torch.empty(n, Hkv, capacity, D, dtype=torch.float16, device=dev)
+        kb = torch.empty(n, Bq, Hkv, capacity, D, dtype=torch.float16, device=dev)
         vb = torch.empty_like(kb)
-        k_outs, v_outs = [kb[i:i + 1] for i in range(n)], [vb[i:i + 1] for i in range(n)]
+        k_outs, v_outs = [kb[i] for i in range(n)], [vb[i] for i in range(n)]
     else:
         k_outs, v_outs = outs
         for ko, vo in zip(k_outs, v_outs):
-            same_layout(ko.shape == (1, Hkv, capacity, D) and vo.shape == ko.shape and ko.stride() == k_outs[0].stride() == vo.stride(),
+            same_layout(ko.shape == (Bq, Hkv, capacity, D) and vo.shape == ko.shape and ko.stride() == k_outs[0].stride() == vo.stride(),
                         "output shape / strides")
             same_layout(ko.stride(3) == 1 and (ko.data_ptr() | vo.data_ptr()) % 16 == 0, "output alignment")
     ostr = (ctypes.c_int64 * 3)(*k_outs[0].stride()[:3])
-    tab = _device_ptr_table([[t.data_ptr() for t in lst] for lst in (qs, ks, vs, k_outs, v_outs)], dev)
-    kv_idx = torch.empty(n, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
-    tsp = torch.zeros(n, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None        # (see update_kv)
+    if Bq > 1:
+        for t in (q0, k0, v0, k_outs[0]):
+            same_layout((t.stride(0) * 2) % 16 == 0, "16-byte alignment of the batch rows")
+
+    def rows_of(lst):                                              # one address per batch row of every tensor
+        return [t.data_ptr() + b * t.stride(0) * 2 for t in lst for b in range(Bq)]
+
+    tab = _device_ptr_table([rows_of(lst) for lst in (qs, ks, vs, k_outs, v_outs)], dev)
+    kv_idx = torch.empty(n * Bq, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
+    tsp = torch.zeros(n * Bq, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None        # (see update_kv)
     ws = _workspace(L.fastkv_workspace_bytes(ctypes.byref(p)), dev)
     rc = L.fastkv_update_kv_ptrs_f16(ctypes.byref(p), tab[0].data_ptr(), _strides(q0), tab[1].data_ptr(), _strides(k0), tab[2].data_ptr(),
                                      _strides(v0), tab[3].data_ptr(), tab[4].data_ptr(), ostr,

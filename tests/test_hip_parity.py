@@ -819,6 +819,17 @@ def test_operator_over_separately_allocated_entries(dev):
             assert (got[2] is None and want[3] is None) or torch.equal(got[2][i:i + 1].cpu(), want[3]), (n, i)
         if slab:
             assert all(float(s_[:, :, :, cap:].abs().max()) == 0.0 for s_ in slabs)         # nothing written past the views
+    # entries with a batch dimension: every batch row of every tensor is an entry of the library call (deferred compression of a
+    # batched prompt); rows i*B .. (i+1)*B-1 of the index tensors belong to tensor i
+    ins = [make_qkv(650 + i, 2, 32, 8, 2048, 128, 8) for i in range(3)]
+    qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
+    got = ops.update_kv_entries(qs, kks, vs, 8, 7, "maxpool", 300, 600, "score", return_indices=True)
+    torch.cuda.synchronize()
+    for i, (q, k, v) in enumerate(ins):
+        want = O.update_kv(q, k, v, 8, 7, "maxpool", 300, 600, "score")
+        assert got[0][i].shape == (2, 8, 300, 128)
+        assert torch.equal(got[0][i].cpu(), want[0]) and torch.equal(got[1][i].cpu(), want[1]), i
+        assert torch.equal(got[3][2 * i:2 * i + 2].cpu(), want[2]) and torch.equal(got[2][2 * i:2 * i + 2].cpu(), want[3]), i
     # two 32k layers per launch sequence (four tiles per wave) is what the residency limit allows; three are refused
     from fastkv_amd._lib import FastKVNativeError
     ins = [make_qkv(700 + i, 1, 32, 8, 32768, 128, 8) for i in range(3)]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces the round's measurement artefacts under gpurun_out/ (copy the summaries into profiles/):
 #   bench JSON line, rocprofv3 --kernel-trace --stats of the same command, FETCH_SIZE / WRITE_SIZE PMC passes.
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/${tag}_bench.json 2> $R/gpurun_out/${tag}_bench.err

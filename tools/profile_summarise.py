@@ -56,8 +56,8 @@ if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1>") for k in pmc.get("FE
     pf, pw = kib("FETCH_SIZE", "fk::score_fused_kernel<128, 4, 2, 1>"), kib("WRITE_SIZE", "fk::score_fused_kernel<128, 4, 2, 1>")
     pair = {"score_fused_pair_hbm_bytes_per_launch": int((2 * pf + pw) * 1024), "score_fused_pair_fetch_kib_raw": pf,
             "score_fused_pair_write_kib": pw,
-            "pair_note": "two 32k layers per launch (score_fused_kernel<128,4,2,1>): algorithmic 134.35 MB; four tiles per wave do not fit the "
-                         "256 registers of a wave at two waves per SIMD (236 B of scratch per lane): the spills are the extra writes and reads"}
+            "pair_note": "two 32k layers per launch (score_fused_kernel<128,4,2,1>): algorithmic 134.35 MB; no scratch traffic to speak of "
+                         "(12 B per lane: four values parked across phase B); the exponentials of two of a wave's four tiles wait for phase C in LDS"}
 cf, cw = kib("FETCH_SIZE", "fk::compact_kv_kernel<16> grid=524288"), kib("WRITE_SIZE", "fk::compact_kv_kernel<16> grid=524288")
 json.dump({**pair, **{
     "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
