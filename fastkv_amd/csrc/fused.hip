@@ -1,4 +1,4 @@
-// Fused window scoring for the common geometries (window W == 8, G = 4, 8, 12, ... query heads per KV head, rows short
+// Fused window scoring for the common geometries (window W == 8, G = 1-3 or 4, 8, 12, ... query heads per KV head, rows short
 // enough that a wave keeps the logits of all its tiles in registers): ONE launch replaces score_logits + row_stats + score_finalize
 // (/root/reference/baselines/fastkv/utils.py:93-112).  The 16 MiB of logits of the 32k shape never leave the registers
 // and the window-row sums never leave LDS; what reaches memory is the score tensor c[b,g,j] (0.5 MiB) and its histogram.
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab)
+                                                             const uint64_t *__restrict__ k_tab, int HV)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
@@ -156,9 +156,12 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         for (int u = 0; u < QV; ++u) {
             const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
             const int i = rowl / W, r = rowl - i * W;
-            qv[s][u] = *reinterpret_cast<const uint4 *>((q_tab ? reinterpret_cast<const uint16_t *>(q_tab[b]) : q + b * qs_b) +
-                                                       (int64_t)((g_s[s] * VH + vh_s[s]) * G + i) * qs_h +
-                                                       (int64_t)(n + r) * qs_s + ch * 8);
+            // HV < 4 (models with 1-3 query heads per KV head; then VH == 1): the block's rows of the missing heads are zero
+            // queries -- their logits, maxima and sums are computed and never used (phases C / D stop at HV heads)
+            const int qh = g_s[s] * (HV < G ? HV : G * VH) + vh_s[s] * G + i;
+            qv[s][u] = i < HV ? *reinterpret_cast<const uint4 *>((q_tab ? reinterpret_cast<const uint16_t *>(q_tab[b]) : q + b * qs_b) +
+                                                                 (int64_t)qh * qs_h + (int64_t)(n + r) * qs_s + ch * 8)
+                              : make_uint4(0u, 0u, 0u, 0u);
         }
     KStage sA, sB;
     k_fetch<NB>(sA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
@@ -586,11 +589,13 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
                 if (hi) {
                     if (NB == 2) {
-                        tl_put(tile[i4][PADMAX + lp], lo + lp < n ? h2f(f2h(c.x)) : padv);
-                        tl_put(tile[i4][PADMAX + lp + 32], lo + lp + 32 < n ? h2f(f2h(c.y)) : padv);
+                        if (i4 < HV) {
+                            tl_put(tile[i4][PADMAX + lp], lo + lp < n ? h2f(f2h(c.x)) : padv);
+                            tl_put(tile[i4][PADMAX + lp + 32], lo + lp + 32 < n ? h2f(f2h(c.y)) : padv);
+                        }
                     } else {
-                        tl_put(tile[i4][PADMAX + lp], lo + lp < n ? h2f(f2h(c.x)) : padv);
-                        tl_put(tile[(i4 + 2) & 3][PADMAX + lp], lo + lp < n ? h2f(f2h(c.y)) : padv);
+                        if (i4 < HV) tl_put(tile[i4][PADMAX + lp], lo + lp < n ? h2f(f2h(c.x)) : padv);
+                        if (((i4 + 2) & 3) < HV) tl_put(tile[(i4 + 2) & 3][PADMAX + lp], lo + lp < n ? h2f(f2h(c.y)) : padv);
                     }
                 }
             }
@@ -604,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         // first and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the flag)
         uint64_t *eg = edges + ((size_t)bgv_s[s] * nblk + blk) * (2 * G * PADMAX);
         const int tt = threadIdx.x, per_side = G * pad;
-        if (tt < 2 * per_side) {
+        if (tt < 2 * per_side && (tt % per_side) / pad < HV) {
             const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
             const float v = tl_get(tile[i4][PADMAX + (side ? TWG - pad + e : e)]);
             __hip_atomic_store(eg + (side * G + i4) * PADMAX + e, ((uint64_t)token << 32) | f32_bits(v), __ATOMIC_RELAXED,
@@ -617,7 +622,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         constexpr int s = decltype(sc)::value;
         tile_t(*tile)[TW] = tile_of(s);
         const int tt = threadIdx.x, per_side = G * pad;
-        if (tt < 2 * per_side) {
+        if (tt < 2 * per_side && (tt % per_side) / pad < HV) {
             const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
             // side 0 of this thread = the LEFT halo of this workgroup = the right edge (side 1) of workgroup blk - 1, and vice versa
             const int nb = side ? blk + 1 : blk - 1;
@@ -664,9 +669,9 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             if (is_out) {
                 float pv[G];
 #pragma unroll
-                for (int i4 = 0; i4 < G; ++i4) pv[i4] = pool_taps(tile[i4], PADMAX + lp, pad, ksize, avg);
+                for (int i4 = 0; i4 < G; ++i4) pv[i4] = i4 < HV ? pool_taps(tile[i4], PADMAX + lp, pad, ksize, avg) : 0.0f;
 #pragma unroll
-                for (int i4 = 0; i4 < G; ++i4) gsum = gsum + h2f(f2h(pv[i4]));
+                for (int i4 = 0; i4 < G; ++i4) if (i4 < HV) gsum = gsum + h2f(f2h(pv[i4]));
                 if (!last_vh) __hip_atomic_store(chain_out + lp, granule(token, f32_bits(gsum)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const uint16_t c16 = f2h_score(gsum);
@@ -722,6 +727,11 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                 float pv[G][4];
 #pragma unroll
                 for (int i4 = 0; i4 < G; ++i4) {
+                    if (i4 >= HV) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[i4][e] = 0.0f;
+                        continue;
+                    }
                     float wv[12];
                     const tile_t *row = &tile[i4][PADMAX - 3 + lp];
                     if constexpr (std::is_same<tile_t, float>::value) {
@@ -757,7 +767,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                    for (int i4 = 0; i4 < G; ++i4) gs[e] = gs[e] + h2f(f2h(pv[i4][e]));
+                    for (int i4 = 0; i4 < G; ++i4) if (i4 < HV) gs[e] = gs[e] + h2f(f2h(pv[i4][e]));
                     if (!last_vh && j + e < n)
                         __hip_atomic_store(chain_out + lp + e, granule(token, f32_bits(gs[e])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -883,8 +893,12 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
     // FASTKV_FUSED_STREAMS=2: the two-heads-per-workgroup experiment (measured slower, see the kernel's comment); default 1
     static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
-    const int G = p.H / p.Hkv, VH = G / 4;                     // virtual heads of 4 query heads per KV head
-    if (disabled || L.engine != ENGINE_MFMA || p.window != 8 || G % 4 != 0 || VH > 8 || p.kernel > 63) return false;
+    // virtual heads of 4 query heads per KV head; a group of 1-3 query heads (MHA, G = 2 models, the per-query-head rule's
+    // views) is ONE block whose missing heads are zero queries: a quarter to three quarters of the block's matrix work is
+    // spent on rows nobody reads, and the launch still beats the three staged kernels with their logits round trip
+    const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4, HV = G < 4 ? G : 4;
+    const bool engine_ok = G < 4 ? (p.reserved & 3) != ENGINE_VALU : L.engine == ENGINE_MFMA;     // (tests force engines through `reserved`)
+    if (disabled || !engine_ok || p.window != 8 || (G >= 4 && G % 4 != 0) || VH > 8 || p.kernel > 63) return false;
     uint32_t *host_flag = abort_flag_device();
     if (!host_flag) return false;                                // no way to report an abandoned launch: staged path
     const int UH = p.Hkv * VH;                                   // units (kv head, virtual head) per batch row
@@ -966,7 +980,7 @@ one_stream:
         decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                              p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                              c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                             pt ? pt->k : nullptr);
+                             pt ? pt->k : nullptr, HV);
     });
     *err = hipGetLastError();
     return true;

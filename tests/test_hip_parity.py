@@ -908,3 +908,44 @@ sys.exit(int(rc) or (0 if st == 0 else 9))
     assert "status after the bad index: -7 clamped: True" in r.stdout, r.stdout[-500:]
     r = _child(code.replace("rc = pytest.main", "rc = 0 and pytest.main"), {"FASTKV_DEBUG_BOUNDS": "0"})       # product mode: clamped, not reported
     assert r.returncode == 0 and "status after the bad index: 0 clamped: True" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=1, H=16, Hkv=8, S=32768, D=128, ks=7, pooling="maxpool", cap=2048, tsp=2048),      # G = 2 (Llama-3.2-1B-like grouping)
+    dict(B=1, H=4, Hkv=4, S=777, D=64, ks=7, pooling="avgpool", cap=100, tsp=300),             # MHA, ragged, head_dim 64
+    dict(B=2, H=6, Hkv=2, S=3000, D=128, ks=5, pooling="avgpool", cap=300, tsp=0),             # G = 3
+    dict(B=1, H=8, Hkv=8, S=2048, D=128, ks=7, pooling="maxpool", cap=2048, tsp=0),            # MHA, every candidate kept
+])
+def test_small_groups_take_the_fused_kernel(shape, dev):
+    """1-3 query heads per KV head (MHA, G = 2 models, the per-query-head rule's views): ONE zero-padded 32-row block per KV head on
+    the fused scoring kernel (round 2: the staged three-kernel path with its logits round trip).  Scores, indices, rows and the TSP
+    index equal the oracle's; the library's profiler confirms which kernel ran."""
+    import ctypes
+    from fastkv_amd import ops
+    from fastkv_amd._lib import load
+    from oracle import fastkv_oracle as O
+    s = shape
+    L = load()
+    q, k, v = make_qkv(9100 + s["H"], s["B"], s["H"], s["Hkv"], s["S"], s["D"], 8)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+
+    def read():
+        n = L.fastkv_profile_kernels()
+        cnt, ms = (ctypes.c_int64 * n)(), (ctypes.c_double * n)()
+        assert L.fastkv_profile_read(cnt, ms) == 0
+        return {L.fastkv_profile_kernel_name(i).decode(): int(cnt[i]) for i in range(n)}
+
+    for order in ("score", "index"):
+        want = O.update_kv(q, k, v, 8, s["ks"], s["pooling"], s["cap"], s["tsp"], order, return_scores=True)
+        read()
+        L.fastkv_profile_enable(1)
+        got = ops.update_kv(qd, kd, vd, 8, s["ks"], s["pooling"], s["cap"], s["tsp"], order, return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        L.fastkv_profile_enable(0)
+        ran = read()
+        assert ran["score_fused"] == 1 and ran["score_logits"] == 0 and ran["row_stats"] == 0, ran
+        assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), order
+        assert torch.equal(got[3].cpu(), want[2]), order
+        assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1]), order
+        if s["tsp"]:
+            assert torch.equal(got[2].cpu(), want[3]), order
