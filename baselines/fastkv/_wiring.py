@@ -28,6 +28,18 @@ def _static_step(past_key_values, hidden_states) -> bool:
         and hidden_states.dtype == torch.float16
 
 
+def _window_allows_static(config, past_key_values) -> bool:
+    """The HIP decode attention attends over ALL rows of the slab (no mask: one new token sees the whole cache).  A model with a
+    sliding window (Mistral v0.1: `config.sliding_window`) limits attention to the last `window` positions in the eager path
+    (mistral_model.py passes the window to the mask builder and the attention call): the two agree only while the slabs cannot
+    hold more rows than the window.  Otherwise static decode is refused up front instead of diverging silently."""
+    win = getattr(config, "sliding_window", None)
+    if win is None:
+        return True
+    layers = getattr(past_key_values, "layers", None) or []
+    return all(getattr(l, "kslab", None) is None or l.kslab.shape[2] <= win for l in layers)
+
+
 def _norm(module, hidden_states, static):
     if static and hasattr(module, "variance_epsilon") and module.weight.dtype == torch.float16:
         return ops.decode_rmsnorm(hidden_states, module.weight, module.variance_epsilon)
@@ -51,7 +63,10 @@ def _gemv_ok(*linears) -> bool:
 
 def _static_layer_ok(layer, hidden_states, position_embeddings, past_key_values) -> bool:
     """Whole-layer fast path of a one-token step (see `_static_layer`): stock Llama / Mistral module shapes, fp16, no biases,
-    batch 1 or 2 (the input rows of the widest projection live in LDS), the layer's cache a slab in static-decode mode."""
+    batch 1 or 2 (the input rows of the widest projection live in LDS), the layer's cache a slab in static-decode mode.
+    Batch 2 shares ONE device-side length per layer (SlabLayer.len_dev): both rows hold the same number of cached tokens -- true by
+    construction for the unpadded, equal-length prompts this wiring supports (as the reference: SURVEY 3.2) after a compression to
+    one budget."""
     if os.environ.get("FASTKV_DECODE_GEMV", "1") == "0" or hidden_states.shape[0] not in (1, 2):
         return False
     attn, mlp = layer.self_attn, layer.mlp
@@ -298,6 +313,10 @@ def make_model_forward(modeling, mask_fn_for):
         if sp is not None and position_ids is None:
             position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + sp.pos0).unsqueeze(0)
             position_ids = position_ids.expand(inputs_embeds.shape[0], -1)
+        if getattr(past_key_values, "static_decode", False) and not _window_allows_static(self.config, past_key_values):
+            raise ValueError(f"static decode attends over the whole cache slab, but this model has sliding_window = "
+                             f"{self.config.sliding_window} and the slabs hold more rows than that: decode eagerly "
+                             "(cache.finish_static_decode()) or size the slabs within the window")
         if position_ids is None:
             if getattr(past_key_values, "static_decode", False):
                 raise ValueError("static decode (graph-capturable) needs position_ids as a device tensor: a host-side position "

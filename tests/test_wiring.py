@@ -273,3 +273,16 @@ def test_generate_decodes_at_true_positions_after_a_compressed_prefill(install_o
     MP.replace_llama("fullkv")
     assert LlamaForCausalLM.prepare_inputs_for_generation is MP._STOCK_PREPARE["llama"]
     MP.replace_llama("fastkv")
+
+
+def test_static_decode_is_refused_when_a_sliding_window_is_smaller_than_the_slab():
+    """the HIP decode attention attends over the whole slab; a model with `sliding_window` set limits attention in the
+    eager path.  Static decode is therefore only allowed while the slabs cannot hold more rows than the window."""
+    import types
+    from baselines.fastkv._wiring import _window_allows_static
+    slab = lambda rows: types.SimpleNamespace(kslab=torch.empty(1, 2, rows, 4))
+    cache = types.SimpleNamespace(layers=[slab(300), slab(200), types.SimpleNamespace(kslab=None)])
+    assert _window_allows_static(types.SimpleNamespace(sliding_window=None), cache)
+    assert _window_allows_static(types.SimpleNamespace(sliding_window=4096), cache)
+    assert not _window_allows_static(types.SimpleNamespace(sliding_window=256), cache)
+    assert _window_allows_static(types.SimpleNamespace(), cache)              # (Llama configs have no such attribute)
