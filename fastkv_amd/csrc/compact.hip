@@ -265,8 +265,21 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *_
     const unsigned char *sp = src + b * sbs + s * srs;
     unsigned char *dp = dst + (b * rows_out + r) * row_bytes;
     const int64_t pieces = row_bytes >> 4;
-    for (int64_t pc = sub; pc < pieces; pc += lpr)
-        *reinterpret_cast<uint4 *>(dp + pc * 16) = *reinterpret_cast<const uint4 *>(sp + pc * 16);
+    // four pieces of a thread in flight before the first store (8 KiB hidden-state rows: both of a thread's pieces -- a "load, store,
+    // load, store" loop pays a memory round trip per piece)
+    for (int64_t pc = sub; pc < pieces; pc += 4 * (int64_t)lpr) {
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = pc + u * (int64_t)lpr;
+            x[u] = *reinterpret_cast<const uint4 *>(sp + (q < pieces ? q : pc) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = pc + u * (int64_t)lpr;
+            if (q < pieces) *reinterpret_cast<uint4 *>(dp + q * 16) = x[u];
+        }
+    }
 }
 
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,

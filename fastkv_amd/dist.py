@@ -279,10 +279,10 @@ class HipTPOps:
         from . import ops
         self.ops = ops
 
-    def update_kv_local(self, q, k, v, window, kernel_size, pooling, capacity, order):
-        ko, vo, _, kv_idx, c = self.ops.update_kv(q, k, v, window, kernel_size, pooling, capacity, 0, order, return_indices=True,
-                                                   return_scores=True)
-        return ko, vo, kv_idx, c
+    def update_kv_local(self, q, k, v, window, kernel_size, pooling, capacity, order, want_scores=True):
+        out = self.ops.update_kv(q, k, v, window, kernel_size, pooling, capacity, 0, order, return_indices=True,
+                                 return_scores=want_scores)                # (the score rows only leave the workspace on the TSP layer)
+        return out[0], out[1], out[3], (out[4] if want_scores else None)
 
     def head_sum(self, c_all):
         return self.ops.head_sum(c_all)
@@ -306,7 +306,11 @@ def tp_update_kv(key_states: torch.Tensor, query_states: torch.Tensor, value_sta
     B, Hkv_l, S, D = key_states.shape
     W = window_size
     assert W < capacity <= S and (tsp_len == 0 or W < tsp_len < S)
-    ko, vo, kv_idx, c = lo.update_kv_local(query_states, key_states, value_states, W, kernel_size, pooling, capacity, order)
+    try:
+        ko, vo, kv_idx, c = lo.update_kv_local(query_states, key_states, value_states, W, kernel_size, pooling, capacity, order,
+                                               want_scores=bool(tsp_len))
+    except TypeError:                                             # (a LocalOps stand-in without the keyword: tests)
+        ko, vo, kv_idx, c = lo.update_kv_local(query_states, key_states, value_states, W, kernel_size, pooling, capacity, order)
     tsp = None
     if tsp_len:
         P = dist.get_world_size(group)
