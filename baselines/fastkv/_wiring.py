@@ -342,7 +342,7 @@ def make_model_forward(modeling, mask_fn_for):
                 and os.environ.get("FASTKV_DEFER", "1") != "0":
             from fastkv_amd.cluster import DeferredCompression
             defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")),
-                                        hold_long=int(os.environ.get("FASTKV_DEFER_HOLD", "2")))
+                                        hold_long=int(os.environ.get("FASTKV_DEFER_HOLD", "8")))
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:
             hidden_states = decoder_layer(hidden_states, attention_mask=causal_mask, position_embeddings=position_embeddings,
                                           position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,

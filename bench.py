@@ -7,8 +7,9 @@ TSP layer 15, budget 2048, window 8, kernel 7, maxpool, fp16):
     layers 0..15   update_kv at S=32768 (score -> select -> compact), layer 15 also produces the TSP index
     TSP propagation  hidden [1,32768,4096] -> [1,2048,4096] row gather (llama_model.py:252-259)
     layers 16..31  update_kv at S=2048 (k == n permutation case) -- handed to DeferredCompression and run as ONE launch sequence
-                   after the last layer, as baselines/fastkv/_wiring.py does by default (`layer_by_layer` in the line: the
-                   32 sequential calls of the reference's schedule, FASTKV_DEFER=0)
+                   after the last layer, as baselines/fastkv/_wiring.py does by default; layers 0..15 likewise in groups of 8
+                   (`layer_by_layer` in the line: the 32 sequential calls of the reference's schedule, FASTKV_DEFER=0;
+                   `hold_2`: the round-2 schedule, pairs)
 on synthetic fp16 Q/K/V (seeded torch.randn on the device, one distinct tensor set per layer so nothing is
 cache-resident across layers), inputs already in HBM.  `value` = prompt tokens / hot-path time, summed over ranks.
 N>1: every rank runs its own prompt (independent prompts shard with no exchange) -> weak scaling.
@@ -82,7 +83,7 @@ class HotPathPrefill:
         self.clusters = [l.self_attn.kv_cluster for l in layers]
         self.defer = os.environ.get("FASTKV_DEFER", "1") != "0"
         self.defer_max_len = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096"))
-        self.defer_hold = int(os.environ.get("FASTKV_DEFER_HOLD", "2"))
+        self.defer_hold = int(os.environ.get("FASTKV_DEFER_HOLD", "8"))
 
     def step(self):
         """The calls the patched model makes during one prefill (baselines/fastkv/_wiring.py), without the model around them:
@@ -588,8 +589,9 @@ def main():
            "ranks_seen": dist.get_world_size() if dist is not None else 1,
            "backend": (dist.get_backend() if dist is not None else "none")}
     out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
-                                 "sequence after the last layer, the layers in front of it in pairs (a layer waits for one peer: its q / k / v, "
-                                 "400 MiB, held one layer longer); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
+                                 f"sequence after the last layer, the layers in front of it in groups of {work.defer_hold} (FASTKV_DEFER_HOLD: a layer waits "
+                                 "for its peers, q / k / v held meanwhile: 400 MiB per waiting layer; the library scores a group two layers per "
+                                 "fused launch and selects / copies it with one launch each); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
 
     if not a.no_extras:
         # instrumented replay of the same steps: per-kernel HIP-event durations on the launch stream
@@ -686,6 +688,19 @@ def main():
                 work.defer = True
                 out["layer_by_layer"] = {"ms_per_step": round(ms_seq, 4), "tokens_per_s": round(CFG["S"] / (ms_seq * 1e-3), 1),
                                          "note": "32 sequential update_kv calls (FASTKV_DEFER=0): the call pattern of the reference"}
+                # the round-2 default: long layers in pairs (one more layer's q / k / v held instead of seven)
+                hold0, work.defer_hold = work.defer_hold, 2
+                for _ in range(2):
+                    work.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    work.step()
+                torch.cuda.synchronize()
+                ms_h2 = (time.perf_counter() - t0) / a.steps * 1e3
+                work.defer_hold = hold0
+                out["hold_2"] = {"ms_per_step": round(ms_h2, 4), "tokens_per_s": round(CFG["S"] / (ms_h2 * 1e-3), 1),
+                                 "note": "FASTKV_DEFER_HOLD=2: the layers in front of the TSP layer in pairs (round 2's schedule)"}
                 # ... and with the 15 layers in front of the TSP layer deferred as well (FASTKV_DEFER_MAX_LEN = prompt length: two
                 # 32k layers per launch sequence; their full K/V stay alive until the end of the forward pass)
                 work.defer_max_len = CFG["S"]

@@ -109,36 +109,65 @@ class DeferredCompression:
     The reference compresses layer by layer inside the attention forward (llama_model.py:136-142), but nothing reads a
     layer's compressed cache before decode -- only the TSP layer's index is needed while the prompt is still in flight.  An
     attention module hands a layer's q / k / v over with `add`; layers of one geometry are then compressed together through
-    `ops.update_kv_entries` (device-side pointer tables: no stacking copies).  Two regimes:
-      * short layers (<= `max_len` tokens: the layers behind the TSP layer, whose launches are all latency -- 16.5 + 8.2 us per
-        layer for 8 MiB of traffic) wait for `flush` at the end of the forward pass: 16 post-TSP layers in 114 us instead of 407;
-      * long layers wait for ONE peer only (`hold_long`, default 2: what the fused scoring kernel holds resident at 32k): the pair
-        runs as soon as the second layer arrives -- 135 -> 122 us per pair at 32k -- so that no more than one layer's full q / k / v
-        (400 MiB at 32k, the query tensor included) is kept alive beyond its own attention.  `hold_long = 0` with `max_len` at the prompt length defers
-        every layer to the end (two per launch sequence all the same, but 2 GB of K/V held at 32k).
+    `ops.update_kv_entries` (device-side pointer tables: no stacking copies; the library scores them in as many fused launches as
+    the chip's residency asks for -- two 32k layers per launch -- and selects / copies ALL of them with one launch each).
+    A waiting layer keeps its q / k / v alive (400 MiB at 32k); with `q_window` (FASTKV_DEFER_QWINDOW=1) only K, V and a 64 KiB copy of
+    the query WINDOW rows -- the only query rows the operator reads (utils.py:93) -- at the price of one small copy launch per layer.
+    Two regimes:
+      * short layers (<= `max_len` tokens: the layers behind the TSP layer, whose launches are all latency) wait for `flush` at the
+        end of the forward pass: 16 post-TSP layers in ~107 us instead of 407;
+      * long layers wait for `hold_long` - 1 peers (default 8: up to seven more layers' q / k / v held, 2.8 GB at 32k -- the TSP layer 15 of the reference's recipe then closes the second group of eight; FASTKV_DEFER_HOLD): the group runs as
+        soon as it is full.  `hold_long = 0` with `max_len` at the prompt length defers every layer to the end.
     `add` returns None when the layer keeps everything (utils.py:89-91: the caller caches K/V as they are), else the list of
     (layer_idx, k_compressed, v_compressed) that became ready with this call (usually empty); `flush` returns the rest.
     Same rows, same order as the per-layer calls (tests/test_wiring_gpu.py)."""
 
     _max_entries = {}                                              # geometry -> entries per launch sequence (process-wide)
+    _fused_ok = {}                                                 # (H, Hkv, S, D, window, kernel) -> entries one fused launch holds
 
-    def __init__(self, max_len: int = 4096, hold_long: int = 2):
+    def __init__(self, max_len: int = 4096, hold_long: int = 8, q_window: Optional[bool] = None):
         self.max_len = max_len
         self.hold_long = hold_long
+        # keep only the window rows of q per waiting layer (a 64 KiB copy instead of the 256 MiB tensor at 32k).  Off by default: the copy
+        # is one more small launch per layer -- measured 0.15 ms per 32-layer step, more than grouping four layers saves -- so it is
+        # for callers who are short of memory, not of time (FASTKV_DEFER_QWINDOW=1)
+        self.q_window = (os.environ.get("FASTKV_DEFER_QWINDOW", "0") == "1") if q_window is None else bool(q_window)
         self.groups = {}
+
+    def _q_of(self, q, window):
+        return ops.window_rows(q, window) if self.q_window else q
+
+    @classmethod
+    def _on_fused_path(cls, cluster, key_states, query_states) -> bool:
+        """Batched entries exist on the fused scoring path only: asked from the library once per geometry (host only)."""
+        g = (query_states.shape[1], key_states.shape[1], key_states.shape[2], key_states.shape[3], cluster.window_size, cluster.kernel_size)
+        ok = cls._fused_ok.get(g)
+        if ok is None:
+            try:
+                ok = cls._fused_ok[g] = ops.fused_entries(*g)
+            except Exception:   # noqa: BLE001 -- an odd kernel size etc.: the per-layer call reports it
+                ok = cls._fused_ok[g] = 0
+        return ok > 0
 
     def eligible(self, cluster, key_states, query_states) -> bool:
         # (an instance whose update_kv was wrapped -- a spy, an adapter -- expects to be called: not deferred)
         return (type(cluster) is FastKVCluster and "update_kv" not in vars(cluster)
                 and key_states.is_cuda and key_states.dtype == torch.float16
                 and query_states.dtype == torch.float16
-                and (key_states.shape[2] <= self.max_len or self.hold_long >= 2))
+                and (key_states.shape[2] <= self.max_len or self.hold_long >= 2)
+                and not torch.cuda.is_current_stream_capturing()          # (the address tables are staged through the host)
+                and self._on_fused_path(cluster, key_states, query_states))
+
+    @staticmethod
+    def _key(cluster, plan, q, k, v, outs):
+        return ((cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order), tuple(q.shape), q.stride(),
+                tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
 
     def add_tsp_layer(self, layer_idx, cluster, key_states, query_states, value_states, out_factory=None):
-        """The TSP layer cannot wait (its index is needed at once), but it can take a WAITING peer of its geometry along: the
-        pair runs now, with the TSP selection computed for both entries and the peer's discarded.  Returns
-        (k_compressed, v_compressed, tsp_idx, ready) -- `ready` = the peer's (layer_idx, k, v), if there was one -- or None when
-        the layer keeps everything (utils.py:89-91)."""
+        """The TSP layer cannot wait (its index is needed at once), but it takes the WAITING peers of its geometry along: the
+        group runs now, with the TSP selection computed for every entry and the peers' discarded.  Returns
+        (k_compressed, v_compressed, tsp_idx, ready) -- `ready` = the peers' (layer_idx, k, v) -- or None when the layer keeps
+        everything (utils.py:89-91)."""
         plan = cluster.plan(query_states.shape[2])
         if plan.early_out:
             return None
@@ -147,23 +176,23 @@ class DeferredCompression:
             B, Hkv, _, D = key_states.shape
             outs = out_factory(B, Hkv, plan.capacity, D, key_states.dtype, key_states.device)
         q, k, v = query_states, key_states, value_states
-        key = ((cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order), tuple(q.shape), q.stride(),
-               tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
+        key = self._key(cluster, plan, q, k, v, outs)
         peers = self.groups.get(key, [])
-        if plan.tsp_len and len(peers) == 1 and self._max_entries.get(key, 2) >= 2 and not torch.cuda.is_current_stream_capturing():
-            peer = peers[0]
+        if plan.tsp_len and peers and self._max_entries.get(key, len(peers) + 1) >= len(peers) + 1 \
+                and not torch.cuda.is_current_stream_capturing():
             try:
-                o = None if outs is None else ([peer[4][0], outs[0]], [peer[4][1], outs[1]])
-                k_outs, v_outs, tsp = ops.update_kv_entries([peer[1], q], [peer[2], k], [peer[3], v], cluster.window_size,
-                                                            cluster.kernel_size, cluster.pooling, plan.capacity, plan.tsp_len,
-                                                            cluster.kv_order, outs=o)
+                qw = [p_[1] for p_ in peers] + [self._q_of(q, cluster.window_size)]
+                o = None if outs is None else ([p_[4][0] for p_ in peers] + [outs[0]], [p_[4][1] for p_ in peers] + [outs[1]])
+                k_outs, v_outs, tsp = ops.update_kv_entries(qw, [p_[2] for p_ in peers] + [k], [p_[3] for p_ in peers] + [v],
+                                                            cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity,
+                                                            plan.tsp_len, cluster.kv_order, outs=o, q_window=self.q_window)
                 self.groups.pop(key)
-                Bq = q.shape[0]                                   # (rows i*Bq .. of the index tensor belong to entry i)
-                return k_outs[1], v_outs[1], tsp[Bq:2 * Bq], [(peer[0], k_outs[0], v_outs[0])]
+                Bq, n = q.shape[0], len(peers)                    # (rows i*Bq .. of the index tensor belong to entry i)
+                return k_outs[n], v_outs[n], tsp[n * Bq:(n + 1) * Bq], [(p_[0], k_outs[i], v_outs[i]) for i, p_ in enumerate(peers)]
             except FastKVNativeError as e:
-                # Only "this pair cannot go through one launch sequence" (nothing was launched) sends the TSP layer on alone; the
-                # peer stays in its group for `flush`.  Anything else -- FASTKV_EABORTED from an EARLIER launch, FASTKV_ELAUNCH --
-                # is not this pair's to absorb: it must reach the caller.
+                # Only "this group cannot go through one launch sequence" (nothing was launched) sends the TSP layer on alone; the
+                # peers stay in their group for `flush`.  Anything else -- FASTKV_EABORTED from an EARLIER launch, FASTKV_ELAUNCH --
+                # is not this group's to absorb: it must reach the caller.
                 if e.code != FASTKV_EUNSUPPORTED:
                     raise
         ko, vo, tsp = ops.update_kv(q, k, v, cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, plan.tsp_len,
@@ -180,10 +209,9 @@ class DeferredCompression:
             B, Hkv, _, D = key_states.shape
             outs = out_factory(B, Hkv, plan.capacity, D, key_states.dtype, key_states.device)
         q, k, v = query_states, key_states, value_states
-        key = ((cluster.window_size, cluster.kernel_size, cluster.pooling, plan.capacity, cluster.kv_order), tuple(q.shape), q.stride(),
-               tuple(k.shape), k.stride(), v.stride(), None if outs is None else outs[0].stride())
+        key = self._key(cluster, plan, q, k, v, outs)
         pending = self.groups.setdefault(key, [])
-        pending.append((layer_idx, q, k, v, outs))
+        pending.append((layer_idx, self._q_of(q, cluster.window_size), k, v, outs))
         if k.shape[2] > self.max_len:
             # a long layer: run as soon as a launch sequence is full (or at once if this geometry only ever runs alone)
             if len(pending) >= max(1, min(self.hold_long, self._max_entries.get(key, self.hold_long))):
@@ -200,8 +228,8 @@ class DeferredCompression:
         its = self.groups.pop(key, [])
         window, ksize, pooling, cap, order = key[0]
         done, pos = [], 0
-        # as many entries per launch sequence as the fused scoring kernel holds resident for this geometry (found by shrinking,
-        # remembered per geometry): all 16 post-TSP layers at once, two 32k layers, one entry at a time off the fused path
+        # as many entries per launch sequence as the library takes for this geometry (all of them, normally: it splits the scoring
+        # into resident launches itself; a refusal is remembered per geometry and the sequence shrinks)
         while pos < len(its):
             n = min(self._max_entries.get(key, len(its)), len(its) - pos)
             if torch.cuda.is_current_stream_capturing():
@@ -209,24 +237,19 @@ class DeferredCompression:
             chunk = its[pos:pos + n]
             qs, ks, vs = [i[1] for i in chunk], [i[2] for i in chunk], [i[3] for i in chunk]
             outs = None if chunk[0][4] is None else ([i[4][0] for i in chunk], [i[4][1] for i in chunk])
-            if n >= 2:
-                try:
-                    k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order, outs=outs)
-                except FastKVNativeError as e:
-                    # FASTKV_EUNSUPPORTED = more entries than the fused kernel holds resident, a geometry off the fused path or
-                    # entries of different layouts: nothing was launched, retry with fewer (remembered per geometry).  Every other
-                    # code (FASTKV_EABORTED: an earlier launch of this process gave up a wait and ITS outputs are invalid;
-                    # FASTKV_ELAUNCH) is an error of the run, not a property of the geometry: the pending entries go back so that a
-                    # caller who handles the error can flush again, `_max_entries` is left alone, and the error is raised.
-                    if e.code != FASTKV_EUNSUPPORTED:
-                        self.groups.setdefault(key, [])[:0] = its[pos:]
-                        raise
-                    self._max_entries[key] = n // 2 if n > 3 else n - 1
-                    continue
-            else:
-                k_outs, v_outs, _ = ops.update_kv(qs[0], ks[0], vs[0], window, ksize, pooling, cap, 0, order,
-                                                  out=None if outs is None else (outs[0][0], outs[1][0]))
-                k_outs, v_outs = [k_outs], [v_outs]
+            try:
+                k_outs, v_outs, _ = ops.update_kv_entries(qs, ks, vs, window, ksize, pooling, cap, 0, order, outs=outs, q_window=self.q_window)
+            except FastKVNativeError as e:
+                # FASTKV_EUNSUPPORTED = more entries than the library takes for this geometry or entries of different layouts:
+                # nothing was launched, retry with fewer (remembered per geometry).  Every other code (FASTKV_EABORTED: an earlier
+                # launch of this process gave up a wait and ITS outputs are invalid; FASTKV_ELAUNCH) is an error of the run, not a
+                # property of the geometry: the pending entries go back so that a caller who handles the error can flush again,
+                # `_max_entries` is left alone, and the error is raised.
+                if e.code != FASTKV_EUNSUPPORTED or n == 1:
+                    self.groups.setdefault(key, [])[:0] = its[pos:]
+                    raise
+                self._max_entries[key] = n // 2 if n > 3 else n - 1
+                continue
             done += [(i[0], ko, vo) for i, ko, vo in zip(chunk, k_outs, v_outs)]
             pos += n
         return done

@@ -331,6 +331,12 @@ int fastkv_update_kv_ptrs_f16(const fastkv_problem *p, const void *const *q_ptrs
                           tsp_idx_out, nullptr, workspace, workspace_bytes, stream, &pt);
 }
 
+int fastkv_fused_entries_f16(const fastkv_problem *p)
+{
+    if (check_problem(p) != FASTKV_OK) return 0;
+    return fused_entries_per_launch(*p);
+}
+
 int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t src_row_stride_bytes, const int64_t *idx,
                        int64_t idx_batch_stride, int64_t batches, int64_t rows_out, int64_t rows_in, int64_t row_bytes,
                        void *dst, void *stream)

@@ -100,6 +100,7 @@ hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q,
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err, const PtrTables *pt = nullptr);
+int fused_entries_per_launch(const fastkv_problem &p);      // fused.hip: entries one fused launch holds (0: geometry off the fused path)
 hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st);
 hipError_t launch_head_sum(const uint16_t *c, int64_t B, int64_t R, int64_t n, uint16_t *t_out, hipStream_t st);
 hipError_t launch_pool_rows(const uint16_t *in, int64_t in_stride, int64_t rows, int64_t n, int ksize, int pooling, uint16_t *out,

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
@@ -122,8 +122,11 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
     // Unit = (kv head, virtual head) of this batch row; stream s of the workgroup works for unit hvp + s * UH / NS.
     const int UH = Hkv * VH, UP = UH / NS;
-    const int hvp = blockIdx.x % UP, blk = blockIdx.x / UP, nblk = gridDim.x / UP, b = blockIdx.y;
-    const int BG = gridDim.y * Hkv;
+    // A batch that does not fit one launch is scored by several launches of `gridDim.y` entries each (launch_score_fused): `b` is the
+    // entry of the WHOLE problem (addresses, score rows, histograms), `blockIdx.y` the entry inside this launch (hand-off records:
+    // every launch uses the same record areas, told apart by `sub` mixed into the token)
+    const int hvp = blockIdx.x % UP, blk = blockIdx.x / UP, nblk = gridDim.x / UP, b = (int)blockIdx.y + b0;
+    const int BG = BG_total;
     int g_s[NS], vh_s[NS], bg_s[NS], bgv_s[NS];
     const uint16_t *kb_s[NS];
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         g_s[s] = hv / VH;
         vh_s[s] = hv - g_s[s] * VH;
         bg_s[s] = b * Hkv + g_s[s];
-        bgv_s[s] = bg_s[s] * VH + vh_s[s];                    // hand-off records are per virtual head
+        bgv_s[s] = ((int)blockIdx.y * Hkv + g_s[s]) * VH + vh_s[s];       // hand-off records are per virtual head of THIS launch
         kb_s[s] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[s] * ks_h;   // (per-entry base: fk_host.h PtrTables)
     }
     const int n = S - W;
@@ -178,7 +181,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         if (threadIdx.x == 0) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    const uint32_t token = handoff_token(ctrl[2]);
+    uint32_t token = handoff_token(ctrl[2]) ^ (sub * 0x85EBCA6Bu);     // (sub 0: the operator call's token, shared with the selection)
+    token = token ? token : 0x6B43A9B5u;
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (threadIdx.x == 0) s_abort = 0;
     FKF_STAMP(0);
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
                 __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    {
+    if (sub == 0) {
         const int first = BG * HIST12, rest = zero_words - first;
         const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
         const int per = (rest + nwg - 1) / nwg;
@@ -886,6 +890,25 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
 
 // Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
 // covered and the caller must take the three-kernel path.
+struct FusedPlan { int NBV, PERT, NS, nblk, wgs; };
+static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl);
+
+// Largest number of batch entries ONE fused scoring launch holds for this geometry (p.B is ignored), 0 = the geometry is off the
+// fused path.  What a caller that batches entries itself wants to know up front (fastkv_amd.cluster.DeferredCompression).
+int fused_entries_per_launch(const fastkv_problem &p)
+{
+    static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
+    const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4;
+    const bool engine_ok = G < 4 ? (p.reserved & 3) != ENGINE_VALU : (p.reserved & 3) != ENGINE_VALU && G * p.window >= 24;
+    if (disabled || !engine_ok || p.window != 8 || (G >= 4 && G % 4 != 0) || VH > 8 || p.kernel > 63 || !abort_flag_device()) return 0;
+    FusedPlan pl;
+    int best = 0;
+    for (int cand = 1; cand <= 64; ++cand)
+        if (fused_plan_for(p, p.Hkv * VH, ns_pref, cand, pl)) best = cand;
+    return best;
+}
+
 bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err, const PtrTables *pt)
@@ -902,33 +925,14 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     uint32_t *host_flag = abort_flag_device();
     if (!host_flag) return false;                                // no way to report an abandoned launch: staged path
     const int UH = p.Hkv * VH;                                   // units (kv head, virtual head) per batch row
-    // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
-    const int NBV = (int64_t)p.B * UH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
-    const int TKV = 32 * NBV;
-    const int nwt = (p.S + TKV - 1) / TKV;
-    // one stream per workgroup: a workgroup owns 4 * PER consecutive tiles of ONE unit, at most 512 workgroups (2 per CU)
-    int nblk1 = (2 * 256) / (p.B * UH);
-    if (nblk1 < 1) return false;
-    if (nblk1 > (nwt + 3) / 4) nblk1 = (nwt + 3) / 4;
-    const int per1 = (nwt + nblk1 * 4 - 1) / (nblk1 * 4);
-    if (per1 > 4) return false;
-    int PERT = per1 <= 1 ? 1 : per1 <= 2 ? 2 : 4;              // tiles per wave the kernel is instantiated for
-    int NS = 1;
-    // Two streams: the workgroup owns 4 * PER / 2 consecutive tiles of TWO units (hvp and hvp + UH/2).  Needs an even number
-    // of units per batch row, rows that split into whole workgroup spans (no ragged or missing tiles: the prefetch chain runs
-    // straight from the last tile of stream 0 into the first tile of stream 1) and both query operands in LDS.
-    if (ns_pref == 2 && UH % 2 == 0 && p.D == 128) {
-        const int per2 = 2;                                     // one tile per stream and wave (the instantiated case)
-        if (PERT > 2) goto one_stream;
-        const int span = 4 * (per2 / 2) * TKV;                  // positions of a workgroup per stream
-        if (p.S % span == 0) { NS = 2; PERT = per2; }
-    }
-one_stream:
-    const int PS = PERT / NS;
-    const int nblk = (nwt + PS * 4 - 1) / (PS * 4);            // workgroups (spans) per unit
-    const size_t vwgs = (size_t)p.B * UH * nblk;                // hand-off records are per unit and span
-    if (vwgs > FUSED_MAX_WGS) return false;
-    const int wgs = (int)(vwgs / NS);
+    // Entries per launch.  A launch holds `sb` entries of the batch: all of them when that fits the chip, else the largest divisor
+    // of the batch that does (a batch of FOUR 32k layers = two launches of two, then ONE selection and ONE copy over all four: the
+    // launches whose cost is latency are paid once per call, not once per launch that fits).
+    FusedPlan pl;
+    int sb = 0;
+    for (int cand = p.B; cand >= 1; --cand)
+        if (fused_plan_for(p, UH, ns_pref, cand, pl)) { sb = cand; break; }
+    if (!sb) return false;                                       // not even one entry fits: staged path
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);
@@ -936,10 +940,7 @@ one_stream:
     const uint64_t spin_ticks = spin_limit_ticks();
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [unit span][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
-    dim3 grid(nblk * UH / NS, p.B);
     uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
-    bool resident = false;
-    if (!fused_dispatch(p.D, PERT, NBV, NS, [&](auto fl) { resident = decltype(fl)::resident(wgs); }) || !resident) return false;
     // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
     // for each other until the spin limit and be reported as FASTKV_EABORTED).  Within this process the library sees to it:
     // when a launch comes on another stream than the previous one, an event recorded on the previous stream (now: behind
@@ -975,14 +976,54 @@ one_stream:
             have_last[dev] = true;
         }
     }
-    ProfScope ps_(K_FUSED, st);
-    fused_dispatch(p.D, PERT, NBV, NS, [&](auto fl) {
-        decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
-                             p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
-                             c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                             pt ? pt->k : nullptr, HV);
-    });
-    *err = hipGetLastError();
+    *err = hipSuccess;
+    uint32_t sub = 0;
+    for (int b0 = 0; b0 < p.B && *err == hipSuccess; ++sub) {
+        // launches of `sb` entries; the last one takes what is left (its own plan: fewer entries may mean fewer tiles per wave)
+        int take = p.B - b0 < sb ? p.B - b0 : sb;
+        while (take > 1 && !fused_plan_for(p, UH, ns_pref, take, pl)) --take;
+        if (!fused_plan_for(p, UH, ns_pref, take, pl)) { *err = hipErrorLaunchFailure; break; }      // (cannot happen: one entry fits)
+        const dim3 grid(pl.nblk * UH / pl.NS, take);
+        ProfScope ps_(K_FUSED, st);
+        fused_dispatch(p.D, pl.PERT, pl.NBV, pl.NS, [&](auto fl) {
+            decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
+                                 p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
+                                 c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub);
+        });
+        *err = hipGetLastError();
+        b0 += take;
+    }
+    return true;
+}
+
+static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl)
+{
+    // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
+    pl.NBV = (int64_t)Bn * UH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
+    const int TKV = 32 * pl.NBV;
+    const int nwt = (p.S + TKV - 1) / TKV;
+    // one stream per workgroup: a workgroup owns 4 * PER consecutive tiles of ONE unit, at most 512 workgroups (2 per CU)
+    int nblk1 = (2 * 256) / (Bn * UH);
+    if (nblk1 < 1) return false;
+    if (nblk1 > (nwt + 3) / 4) nblk1 = (nwt + 3) / 4;
+    const int per1 = (nwt + nblk1 * 4 - 1) / (nblk1 * 4);
+    if (per1 > 4) return false;
+    pl.PERT = per1 <= 1 ? 1 : per1 <= 2 ? 2 : 4;                // tiles per wave the kernel is instantiated for
+    pl.NS = 1;
+    // Two streams (experiment): the workgroup owns 4 * PER / 2 consecutive tiles of TWO units (hvp and hvp + UH/2).  Needs an
+    // even number of units per batch row, rows that split into whole workgroup spans and both query operands in LDS.
+    if (ns_pref == 2 && UH % 2 == 0 && p.D == 128 && pl.PERT <= 2) {
+        const int span = 4 * 1 * TKV;                           // positions of a workgroup per stream (one tile per stream and wave)
+        if (p.S % span == 0) { pl.NS = 2; pl.PERT = 2; }
+    }
+    const int PS = pl.PERT / pl.NS;
+    pl.nblk = (nwt + PS * 4 - 1) / (PS * 4);                   // workgroups (spans) per unit
+    const size_t vwgs = (size_t)Bn * UH * pl.nblk;              // hand-off records are per unit and span
+    if (vwgs > FUSED_MAX_WGS) return false;
+    pl.wgs = (int)(vwgs / pl.NS);
+    bool resident = false;
+    if (!fused_dispatch(p.D, pl.PERT, pl.NBV, pl.NS, [&](auto fl) { resident = decltype(fl)::resident(pl.wgs); }) || !resident) return false;
     return true;
 }
 

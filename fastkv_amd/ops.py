@@ -460,18 +460,44 @@ def _stage_ptr_table(rows, device: torch.device) -> torch.Tensor:
     return dev
 
 
+def fused_entries(H: int, Hkv: int, S: int, D: int, window: int, kernel_size: int) -> int:
+    """Entries ONE fused scoring launch holds for this geometry (0: the geometry takes the staged path; `update_kv_entries` then
+    refuses it).  Host only."""
+    p = Problem(B=1, H=H, Hkv=Hkv, S=S, D=D, window=window, kernel=kernel_size, pooling=0, capacity=S, tsp_len=0, order=0, reserved=_engine)
+    return int(load().fastkv_fused_entries_f16(ctypes.byref(p)))
+
+
+def window_rows(q: torch.Tensor, window: int) -> torch.Tensor:
+    """The only rows of the query tensor the operator reads (utils.py:93: `query_states[..., -window:, :]`), as a contiguous
+    [B,H,window,D] copy: 64 KiB for Llama-3-8B where the tensor itself is 256 MiB at 32k -- what a deferred entry keeps alive
+    (`update_kv_entries(..., q_window=True)`)."""
+    return q[:, :, q.shape[2] - window:, :].contiguous()
+
+
 def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, capacity: int, tsp_len: int = 0, order: str = "score",
-                      outs=None, return_indices: bool = False):
+                      outs=None, return_indices: bool = False, q_window: bool = False):
     """`update_kv` over SEPARATELY ALLOCATED entries in one launch sequence (fastkv_update_kv_ptrs_f16): qs / ks / vs are lists
     of [Bq,H,S,D] / [Bq,Hkv,S,D] fp16 tensors of ONE geometry and ONE memory layout (e.g. the layers of a model whose compression
     was deferred to the end of the forward pass; every batch row of every tensor becomes one entry of the library call).
     Returns (k_outs, v_outs, tsp_idx [n*Bq,tsp_len] | None[, kv_idx [n*Bq,Hkv,cap-W]]), rows i*Bq .. (i+1)*Bq-1 belonging to tensor i;
     `outs` = (list of k buffers, list of v buffers), [Bq,Hkv,cap,D] views of one stride pattern, to write into.
-    Raises FastKVNativeError(FASTKV_EUNSUPPORTED) for geometries off the fused scoring path: call `update_kv` per entry then."""
+    `q_window`: every qs[i] is `window_rows(q_i, window)` ([Bq,H,window,D] contiguous) instead of the whole query tensor; the library
+    is handed an address `S - window` rows in front of it, so that row S - window + r of "the query tensor" is row r of the copy.
+    A batch that does not fit one fused scoring launch is scored by several (the library splits it) and selected / copied by ONE
+    launch each.  Raises FastKVNativeError(FASTKV_EUNSUPPORTED) for geometries off the fused scoring path: call `update_kv` per
+    entry then."""
     n = len(qs)
     assert n >= 1 and len(ks) == n and len(vs) == n
     q0, k0, v0 = qs[0], ks[0], vs[0]
-    _check_qkv(q0, k0, v0)
+    if q_window:
+        S_full = k0.shape[2]
+        for q in qs:
+            if q.dim() != 4 or q.shape[2] != window or not q.is_contiguous() or q.dtype != torch.float16:
+                raise ValueError("fastkv_amd.update_kv_entries(q_window=True): [B,H,window,D] contiguous fp16 copies of the window rows expected")
+        _check_qkv(k0, k0, v0)
+        _require_cuda(q0)
+    else:
+        _check_qkv(q0, k0, v0)
     Bq = q0.shape[0]
 
     def same_layout(ok: bool, what: str):
@@ -486,7 +512,13 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
         same_layout(q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16, "dtype")
         same_layout((q.data_ptr() | k.data_ptr() | v.data_ptr()) % 16 == 0, "16-byte alignment")
     L = load()
-    p = _problem(q0, k0, window, kernel_size, pooling, capacity, tsp_len, order)
+    if q_window:
+        if pooling not in POOLING:
+            raise ValueError("Pooling method not supported")
+        p = Problem(B=Bq, H=q0.shape[1], Hkv=k0.shape[1], S=S_full, D=q0.shape[3], window=window, kernel=kernel_size, pooling=POOLING[pooling],
+                    capacity=capacity, tsp_len=tsp_len, order=ORDER[order], reserved=_engine)
+    else:
+        p = _problem(q0, k0, window, kernel_size, pooling, capacity, tsp_len, order)
     p.B = n * Bq
     Hkv, D, dev = p.Hkv, p.D, q0.device
     if outs is None:
@@ -504,10 +536,12 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
         for t in (q0, k0, v0, k_outs[0]):
             same_layout((t.stride(0) * 2) % 16 == 0, "16-byte alignment of the batch rows")
 
-    def rows_of(lst):                                              # one address per batch row of every tensor
-        return [t.data_ptr() + b * t.stride(0) * 2 for t in lst for b in range(Bq)]
+    def rows_of(lst, back=0):                                      # one address per batch row of every tensor
+        return [t.data_ptr() + b * t.stride(0) * 2 - back for t in lst for b in range(Bq)]
 
-    tab = _device_ptr_table([rows_of(lst) for lst in (qs, ks, vs, k_outs, v_outs)], dev)
+    # (window copies: the kernel addresses query row S - window + r as base + (S - window + r) * row stride)
+    q_back = (S_full - window) * q0.stride(2) * 2 if q_window else 0
+    tab = _device_ptr_table([rows_of(qs, q_back)] + [rows_of(lst) for lst in (ks, vs, k_outs, v_outs)], dev)
     kv_idx = torch.empty(n * Bq, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
     tsp = torch.zeros(n * Bq, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None        # (see update_kv)
     ws = _workspace(L.fastkv_workspace_bytes(ctypes.byref(p)), dev)

@@ -142,13 +142,23 @@ int fastkv_update_kv_strided_f16(const fastkv_problem *p,
  * tsp_idx_out [B,tsp_len] are ordinary batched tensors.  One launch sequence for all entries: the per-launch latencies of
  * the small post-TSP layers (16.5 + 8.2 us each) are paid once.  Entries must be 16-B aligned (not checked: the addresses
  * are on the device).  Fused scoring path only: FASTKV_EUNSUPPORTED (nothing launched) for geometries that would take the
- * three-kernel path -- call the strided entry point per entry then.
+ * three-kernel path (fastkv_fused_entries_f16 == 0) -- call the strided entry point per entry then.  More entries than one fused
+ * scoring launch holds are scored by several launches; the selection and the copy always run once over all entries.
  */
 int fastkv_update_kv_ptrs_f16(const fastkv_problem *p, const void *const *q_ptrs, const int64_t q_strides[4],
                               const void *const *k_ptrs, const int64_t k_strides[4], const void *const *v_ptrs,
                               const int64_t v_strides[4], void *const *k_out_ptrs, void *const *v_out_ptrs,
                               const int64_t out_strides[3], int64_t *kv_idx_out, int64_t *tsp_idx_out, void *workspace,
                               size_t workspace_bytes, void *stream);
+
+/*
+ * How many batch entries ONE fused scoring launch holds for this geometry (p->B is ignored; 2 for Llama-3-8B at 32k, 16 at 2k), 0 when
+ * the geometry takes the staged three-kernel path (a window other than 8, 5-7 query heads per KV head, FASTKV_FUSED=0, a prompt too
+ * long for the resident grid).  fastkv_update_kv_ptrs_f16 accepts ANY number of entries of a geometry with a non-zero answer: it
+ * scores them in launches of this many and selects / copies all of them with one launch each.  For callers that decide up front
+ * whether to batch calls (fastkv_amd.cluster.DeferredCompression).
+ */
+int fastkv_fused_entries_f16(const fastkv_problem *p);
 
 /*
  * Stage 1 alone: window-attention scores (utils.py:93-112 [+ :127 head sum]).

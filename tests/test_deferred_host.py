@@ -12,7 +12,9 @@ class Recorder:
     def __init__(self, max_entries):
         self.max_entries, self.calls = max_entries, []
 
-    def entries(self, qs, ks, vs, window, ksize, pooling, cap, tsp_len=0, order="score", outs=None, return_indices=False):
+    def entries(self, qs, ks, vs, window, ksize, pooling, cap, tsp_len=0, order="score", outs=None, return_indices=False, q_window=False):
+        assert not q_window or all(q.shape[2] == window for q in qs)     # (q_window: a waiting layer keeps the window rows of q only)
+        self.q_window_seen = q_window
         if len(qs) > self.max_entries:
             raise FastKVNativeError("unsupported configuration", code=-4)
         self.calls.append(("entries", len(qs), tsp_len))
@@ -67,6 +69,24 @@ def test_long_layers_pair_up_and_the_tsp_layer_takes_its_peer_along(rec):
         assert val == float(j)
 
 
+@pytest.mark.parametrize("q_window", [False, True])
+def test_groups_of_four_and_the_tsp_layer_takes_every_waiting_peer(rec, q_window):
+    rec.max_entries = 16
+    d = C.DeferredCompression(max_len=100, hold_long=4, q_window=q_window)
+    done = {}
+    for i in range(7):                                             # layers 0..6 long, layer 7 = TSP layer
+        q, k, v = _layer(i, 1000)
+        for j, ko, vo in d.add(i, _cluster(), k, q, v):
+            done[j] = float(ko[0, 0, 0, 0])
+    assert rec.calls == [("entries", 4, 0)] and sorted(done) == [0, 1, 2, 3]                         # layers 4-6 wait
+    q, k, v = _layer(7, 1000)
+    ko, vo, tsp, ready = d.add_tsp_layer(7, _cluster(tsp_layer=True), k, q, v)
+    assert rec.calls[-1] == ("entries", 4, 64) and [r[0] for r in ready] == [4, 5, 6]
+    assert float(ko[0, 0, 0, 0]) == 7.0 and [float(r[1][0, 0, 0, 0]) for r in ready] == [4.0, 5.0, 6.0]
+    assert tsp.shape == (1, 64) and int(tsp[0, 0]) == 3 * 64                                           # the LAST entry's row: the TSP layer's
+    assert d.flush() == [] and rec.q_window_seen == q_window
+
+
 def test_short_layers_wait_for_the_end_and_shrink_to_what_fits(rec):
     rec.max_entries = 3
     d = C.DeferredCompression(max_len=4096, hold_long=2)
@@ -75,7 +95,7 @@ def test_short_layers_wait_for_the_end_and_shrink_to_what_fits(rec):
         assert d.add(i, _cluster(), k, q, v) == []
     out = d.flush()
     assert [o[0] for o in out] == list(range(7)) and all(float(o[1][0, 0, 0, 0]) == float(o[0]) for o in out)
-    assert rec.calls == [("entries", 3, 0), ("entries", 3, 0), ("single", 1, 0)]                      # 7 refused, 3 fits: 3 + 3 + 1
+    assert rec.calls == [("entries", 3, 0), ("entries", 3, 0), ("entries", 1, 0)]                     # 7 refused, 3 fits: 3 + 3 + 1
     # the limit is remembered per geometry: the next prompt asks for 3 at once
     rec.calls.clear()
     for i in range(3):

@@ -830,17 +830,22 @@ def test_operator_over_separately_allocated_entries(dev):
         assert got[0][i].shape == (2, 8, 300, 128)
         assert torch.equal(got[0][i].cpu(), want[0]) and torch.equal(got[1][i].cpu(), want[1]), i
         assert torch.equal(got[3][2 * i:2 * i + 2].cpu(), want[2]) and torch.equal(got[2][2 * i:2 * i + 2].cpu(), want[3]), i
-    # two 32k layers per launch sequence (four tiles per wave) is what the residency limit allows; three are refused
-    from fastkv_amd._lib import FastKVNativeError
-    ins = [make_qkv(700 + i, 1, 32, 8, 32768, 128, 8) for i in range(3)]
+    # two 32k layers per fused scoring launch (four tiles per wave) is what the residency limit allows: the library scores a longer
+    # list in several launches (2 + 2 for four entries, 1 + 1 + 1 for three) and selects / copies all entries with one launch each.
+    # The same with only the WINDOW rows of q kept (what a waiting layer of DeferredCompression holds).
+    assert ops.fused_entries(32, 8, 32768, 128, 8, 7) == 2 and ops.fused_entries(32, 8, 2048, 128, 8, 7) >= 16
+    assert ops.fused_entries(32, 8, 32768, 128, 4, 7) == 0                                             # window 4: the staged path
+    ins = [make_qkv(700 + i, 1, 32, 8, 32768, 128, 8) for i in range(4)]
     qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
-    got = ops.update_kv_entries(qs[:2], kks[:2], vs[:2], 8, 7, "maxpool", 2048, 0, "score", return_indices=True)
-    torch.cuda.synchronize()
-    for i in range(2):
-        want = O.update_kv(*ins[i], 8, 7, "maxpool", 2048, 0, "score")
-        assert torch.equal(got[0][i].cpu(), want[0]) and torch.equal(got[1][i].cpu(), want[1]) and torch.equal(got[3][i:i + 1].cpu(), want[2])
-    with pytest.raises(FastKVNativeError):
-        ops.update_kv_entries(qs, kks, vs, 8, 7, "maxpool", 2048, 0, "score")
+    wants = [O.update_kv(*ins[i], 8, 7, "maxpool", 2048, 2048, "score") for i in range(4)]
+    for n, qwin in ((2, False), (3, False), (4, False), (4, True)):
+        qq = [ops.window_rows(t, 8) for t in qs[:n]] if qwin else qs[:n]
+        got = ops.update_kv_entries(qq, kks[:n], vs[:n], 8, 7, "maxpool", 2048, 2048, "score", return_indices=True, q_window=qwin)
+        torch.cuda.synchronize()
+        for i in range(n):
+            want = wants[i]
+            assert torch.equal(got[0][i].cpu(), want[0]) and torch.equal(got[1][i].cpu(), want[1]), (n, qwin, i)
+            assert torch.equal(got[3][i:i + 1].cpu(), want[2]) and torch.equal(got[2][i:i + 1].cpu(), want[3]), (n, qwin, i)
     # a geometry off the fused path is refused before anything is launched (window 4): the caller goes entry by entry
     ins = [make_qkv(900 + i, 1, 8, 2, 1000, 128, 4) for i in range(2)]
     qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
