@@ -58,7 +58,10 @@ if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1>") for k in pmc.get("FE
             "score_fused_pair_write_kib": pw,
             "pair_note": "two 32k layers per launch (score_fused_kernel<128,4,2,1>): algorithmic 134.35 MB; no scratch traffic to speak of "
                          "(12 B per lane: four values parked across phase B); the exponentials of two of a wave's four tiles wait for phase C in LDS"}
-cf, cw = kib("FETCH_SIZE", "fk::compact_kv_kernel<16> grid=524288"), kib("WRITE_SIZE", "fk::compact_kv_kernel<16> grid=524288")
+# the copy launches of the bench step: the one-layer launch (grid 524288: the layer-by-layer leg) when the run has it, else the largest
+ckey = "fk::compact_kv_kernel<16> grid=524288" if any(k.startswith("fk::compact_kv_kernel<16> grid=524288") for k in pmc.get("FETCH_SIZE", {})) \
+    else "fk::compact_kv_kernel<16>"
+cf, cw = kib("FETCH_SIZE", ckey), kib("WRITE_SIZE", ckey)
 json.dump({**pair, **{
     "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
               "--no-extras`, medians over launches; counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide 16-B/lane "
