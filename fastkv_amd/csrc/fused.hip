@@ -73,7 +73,7 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
 // across two: tools/probes/probe_overlap.hip).  The kernel is issue bound (per SIMD: A 27, B 9, C 5, D 4 us), and two streams
 // pay every hand-off's record sweep twice, with twice the producers per head.
 template <int D, int PER, int NB, int NS>
-__global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
+__device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
                                                              uint64_t *__restrict__ edges, uint64_t *__restrict__ pmax,
@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     __shared__ uint32_t s_rb[FUSED_PARTS][32];
     __shared__ float s_gm[NS][32], s_ri[NS][32];               // row maxima / reciprocal row sums of the streams' heads
     __shared__ uint32_t s_abort;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned tix = threadIdx.x;
+    const int lane = tix & 63, w = __builtin_amdgcn_readfirstlane(tix >> 6);
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int u = 0; u < QV; ++u) {
-            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const int item = u * 256 + tix, rowl = item / (D / 8), ch = item - rowl * (D / 8);
             const int i = rowl / W, r = rowl - i * W;
             // HV < 4 (models with 1-3 query heads per KV head; then VH == 1): the block's rows of the missing heads are zero
             // queries -- their logits, maxima and sums are computed and never used (phases C / D stop at HV heads)
@@ -178,13 +179,13 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         // workspace never initialised (fastkv_workspace_init): no hand-off of this launch could be trusted.  Reported like an
         // abandoned wait -- the process-wide flag in pinned host memory, FASTKV_EABORTED at the next call -- and every workgroup
         // leaves at once (the condition is the same for all of them); nothing traps, the context stays usable.
-        if (threadIdx.x == 0) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
+        if (tix == 0) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
     }
     uint32_t token = handoff_token(ctrl[2]) ^ (sub * 0x85EBCA6Bu);     // (sub 0: the operator call's token, shared with the selection)
     token = token ? token : 0x6B43A9B5u;
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
-    if (threadIdx.x == 0) s_abort = 0;
+    if (tix == 0) s_abort = 0;
     FKF_STAMP(0);
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     for (int s = 0; s < NS; ++s)
         if (vh_s[s] == VH - 1) {                               // the group that fills the histogram in phase D
             uint32_t *hist_row = zero_area + (size_t)bg_s[s] * HIST12;
-            for (int i = blk * 256 + (int)threadIdx.x; i < HIST12; i += nblk * 256)
+            for (int i = blk * 256 + (int)tix; i < HIST12; i += nblk * 256)
                 __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     if (sub == 0) {
@@ -202,14 +203,14 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
         const int per = (rest + nwg - 1) / nwg;
         const int lo = wg * per, hi2 = min(lo + per, rest);
-        for (int i = lo + (int)threadIdx.x; i < hi2; i += 256) zero_area[first + i] = 0;
+        for (int i = lo + (int)tix; i < hi2; i += 256) zero_area[first + i] = 0;
     }
 
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int u = 0; u < QV; ++u) {
-            const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            const int item = u * 256 + tix, rowl = item / (D / 8), ch = item - rowl * (D / 8);
             const uint32_t wds[4] = {qv[s][u].x, qv[s][u].y, qv[s][u].z, qv[s][u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         __syncthreads();
         if (s_abort) return false;
         FKF_STAMP(23);
-        const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int row = tix & 31, part = tix >> 5;
         for (;;) {
             float v = -INFINITY;
             bool ok = true;
@@ -379,16 +380,16 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             }
             s_rf[part][row] = v;
             if (__syncthreads_and(ok)) break;
-            if (threadIdx.x == 0 && spin_failed(sp)) s_abort = 1;      // a record behind a current granule 0 is still old: rare
+            if (tix == 0 && spin_failed(sp)) s_abort = 1;      // a record behind a current granule 0 is still old: rare
             __syncthreads();
             if (s_abort) return false;
         }
         FKF_STAMP(24);
-        if (threadIdx.x < 32) {
-            float v = s_rf[0][threadIdx.x];
+        if (tix < 32) {
+            float v = s_rf[0][tix];
 #pragma unroll
-            for (int u = 1; u < FUSED_PARTS; ++u) v = fmaxf(v, s_rf[u][threadIdx.x]);
-            s_gm[s][threadIdx.x] = v;
+            for (int u = 1; u < FUSED_PARTS; ++u) v = fmaxf(v, s_rf[u][tix]);
+            s_gm[s][tix] = v;
         }
         __syncthreads();
         return true;
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         __syncthreads();
         if (s_abort) return false;
         FKF_STAMP(27);
-        const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int row = tix & 31, part = tix >> 5;
         for (;;) {
             uint64_t s2 = 0;
             uint32_t bad = 0;
@@ -519,17 +520,17 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             s_ru[part][row] = s2;
             s_rb[part][row] = bad;
             if (__syncthreads_and(ok)) break;
-            if (threadIdx.x == 0 && spin_failed(sp)) s_abort = 1;
+            if (tix == 0 && spin_failed(sp)) s_abort = 1;
             __syncthreads();
             if (s_abort) return false;
         }
         FKF_STAMP(28);
-        if (threadIdx.x < 32) {
+        if (tix < 32) {
             uint64_t sm = 0;
             uint32_t bad = 0;
 #pragma unroll
-            for (int u = 0; u < FUSED_PARTS; ++u) { sm += s_ru[u][threadIdx.x]; bad |= s_rb[u][threadIdx.x]; }
-            s_ri[s][threadIdx.x] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(sm);          // utils.py:103
+            for (int u = 0; u < FUSED_PARTS; ++u) { sm += s_ru[u][tix]; bad |= s_rb[u][tix]; }
+            s_ri[s][tix] = bad ? __builtin_nanf("") : 1.0f / fix_to_f32(sm);          // utils.py:103
         }
         __syncthreads();
         return true;
@@ -608,11 +609,11 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         __syncthreads();
         // (the histogram may lie where the parked exponentials were: cleared only now that every wave has consumed them; phase D,
         // its first user, starts behind the barrier of read_halo)
-        if (want_hist) for (int i = threadIdx.x; i < HIST12; i += 256) s_hist[i] = 0;
+        if (want_hist) for (int i = tix; i < HIST12; i += 256) s_hist[i] = 0;
         // halo: pooling reaches `pad` positions into the neighbouring workgroups of the head.  Every workgroup publishes its
         // first and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the flag)
         uint64_t *eg = edges + ((size_t)bgv_s[s] * nblk + blk) * (2 * G * PADMAX);
-        const int tt = threadIdx.x, per_side = G * pad;
+        const int tt = tix, per_side = G * pad;
         if (tt < 2 * per_side && (tt % per_side) / pad < HV) {
             const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
             const float v = tl_get(tile[i4][PADMAX + (side ? TWG - pad + e : e)]);
@@ -625,7 +626,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     auto read_halo = [&](auto sc) -> bool {
         constexpr int s = decltype(sc)::value;
         tile_t(*tile)[TW] = tile_of(s);
-        const int tt = threadIdx.x, per_side = G * pad;
+        const int tt = tix, per_side = G * pad;
         if (tt < 2 * per_side && (tt % per_side) / pad < HV) {
             const int side = tt >= per_side, q2 = tt - side * per_side, i4 = q2 / pad, e = q2 - i4 * pad;
             // side 0 of this thread = the LEFT halo of this workgroup = the right edge (side 1) of workgroup blk - 1, and vice versa
@@ -659,7 +660,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         const bool last_vh = vh == VH - 1;
 #pragma unroll
         for (int u = 0; u * 256 < TWG; ++u) {
-            const int lp = u * 256 + threadIdx.x, j = lo + lp;
+            const int lp = u * 256 + tix, j = lo + lp;
             const bool is_out = lp < TWG && j < n;
             float gsum = 0.0f;
             if (is_out && vh > 0) {                              // the head sum so far: {token, fp32 bits} granule of this position
@@ -689,10 +690,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
         }
         FKF_STAMP(31);
-        if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
+        if (all_keys && last_vh && blk == 0 && (int)tix < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + tix] = 0;
         if (want_hist && last_vh) {
             __syncthreads();
-            for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
+            for (int i = tix; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
         }
     };
 
@@ -711,7 +712,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
         const bool last_vh = vh == VH - 1;
 #pragma unroll
         for (int u = 0; u * 1024 < TWG; ++u) {
-            const int lp = (u * 256 + (int)threadIdx.x) * 4, j = lo + lp;
+            const int lp = (u * 256 + (int)tix) * 4, j = lo + lp;
             const bool any = lp < TWG && j < n;
             float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (any && vh > 0) {
@@ -807,10 +808,10 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
             }
         }
         FKF_STAMP(31);
-        if (all_keys && last_vh && blk == 0 && (int)threadIdx.x < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + threadIdx.x] = 0;
+        if (all_keys && last_vh && blk == 0 && (int)tix < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + tix] = 0;
         if (want_hist && last_vh) {
             __syncthreads();
-            for (int i = threadIdx.x; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
+            for (int i = tix; i < HIST12; i += 256) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&hist_row[i], v); }
         }
     };
     auto phaseD_any = [&](auto sc) {
@@ -826,24 +827,48 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
     FKF_STAMP(1);
     if (NS == 2) phaseA(S1{});
     FKF_STAMP(2);
-    if (!read_max(S0{})) return;
+    if (!read_max(S0{})) return false;
     FKF_STAMP(3);
     phaseB(S0{});
     FKF_STAMP(4);
-    if (NS == 2) { if (!read_max(S1{})) return; FKF_STAMP(5); phaseB(S1{}); }
+    if (NS == 2) { if (!read_max(S1{})) return false; FKF_STAMP(5); phaseB(S1{}); }
     FKF_STAMP(6);
-    if (!read_sum(S0{})) return;
+    if (!read_sum(S0{})) return false;
     FKF_STAMP(7);
     phaseC(S0{});
     FKF_STAMP(8);
-    if (NS == 2) { if (!read_sum(S1{})) return; FKF_STAMP(9); phaseC(S1{}); }
+    if (NS == 2) { if (!read_sum(S1{})) return false; FKF_STAMP(9); phaseC(S1{}); }
     FKF_STAMP(10);
-    if (!read_halo(S0{})) return;
+    if (!read_halo(S0{})) return false;
     FKF_STAMP(11);
     phaseD_any(S0{});
     FKF_STAMP(12);
-    if (NS == 2) { if (!read_halo(S1{})) return; FKF_STAMP(13); phaseD_any(S1{}); }
+    if (NS == 2) { if (!read_halo(S1{})) return false; FKF_STAMP(13); phaseD_any(S1{}); }
     FKF_STAMP(14);
+    return true;
+}
+
+// The launch.  (Round 3 also built a variant that runs the sub-batches of a batch one after the other inside ONE launch -- a workgroup
+// that has finished its unit of one sub-batch starts on the next at once, so that start-up and the spread of the waves at the end are
+// paid once per launch: bit-exact, and no faster than one launch per sub-batch (0.822 vs 0.825 ms per step) once both used the same
+// register allocation; the loop needs the thread index laundered through an opaque move or everything derived from it is hoisted
+// and spilled.  Dropped: separate launches are simpler and cannot reuse a hand-off record too early.)
+template <int D, int PER, int NB, int NS>
+__global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
+                                                             const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
+                                                             int H, int Hkv, int S, float sqrtD, float rsqrtD,
+                                                             uint64_t *__restrict__ edges, uint64_t *__restrict__ pmax,
+                                                             uint64_t *__restrict__ psum, uint32_t *__restrict__ ctrl,
+                                                             uint32_t *__restrict__ zero_area, int zero_words, int ksize, int pooling,
+                                                             uint16_t *__restrict__ c_out, int64_t c_row_stride,
+                                                             int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
+                                                             int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
+                                                             uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub)
+{
+    (void)score_fused_body<D, PER, NB, NS>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
+                                           zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -879,7 +904,7 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
 {
 #define FK_CASE(DV, PV, NBV, NSV) if (D == DV && per == PV && nb == NBV && ns == NSV) { f(FusedLaunch<DV, PV, NBV, NSV>{}); return true; }
 #define FK_CASES_D(DV)                                                                                          \
-    FK_CASE(DV, 1, 1, 1) FK_CASE(DV, 2, 1, 1) FK_CASE(DV, 4, 1, 1) FK_CASE(DV, 1, 2, 1) FK_CASE(DV, 2, 2, 1) FK_CASE(DV, 4, 2, 1)
+    FK_CASE(DV, 1, 1, 1) FK_CASE(DV, 1, 2, 1) FK_CASE(DV, 2, 2, 1) FK_CASE(DV, 4, 2, 1)      /* (32-key tiles only ever come one per wave) */
     FK_CASES_D(64) FK_CASES_D(128) FK_CASES_D(256)
     // two streams (experiment): head dim 128, one tile per stream and wave
     FK_CASE(128, 2, 1, 2) FK_CASE(128, 2, 2, 2)
