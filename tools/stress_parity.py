@@ -76,10 +76,14 @@ for it in range(N):
         # (nothing launched) when that many do not fit the fused kernel's residency
         ne = rng.choice([2, 2, 3, 5, 16])
         ins = [(q, k, v)] + [make_qkv(9000 + it + 100000 * j, B, Hkv * G, Hkv, S, D, W, peaked=peaked) for j in range(1, ne)]
-        if S * ne * Hkv * D < 60e6:
+        if S * ne * Hkv * D < 150e6:
             try:
                 dq, dk, dv = ([t[j].transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in ins] for j in range(3))
-                ge = ops.update_kv_entries(dq, dk, dv, W, ks, pooling, cap, tsp_len, order, return_indices=True)
+                qwin = rng.random() < 0.4                        # only the window rows of q kept (a waiting layer of DeferredCompression)
+                if qwin:
+                    dq = [ops.window_rows(t, W) for t in dq]
+                # (more entries than one fused launch holds are scored by several launches and selected / copied once)
+                ge = ops.update_kv_entries(dq, dk, dv, W, ks, pooling, cap, tsp_len, order, return_indices=True, q_window=qwin)
                 torch.cuda.synchronize()
                 n_entries_runs += 1
                 for j, (qj, kj, vj) in enumerate(ins):
