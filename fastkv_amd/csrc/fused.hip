@@ -83,8 +83,11 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu)
 {
+#if defined(FK_DBG_DELAY) && !defined(FK_DBG_WHO)
+#define FK_DBG_WHO (yb == 0)
+#endif
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
     static_assert(PER % NS == 0, "tiles split evenly over the streams");
@@ -126,7 +129,25 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // A batch that does not fit one launch is scored by several launches of `gridDim.y` entries each (launch_score_fused): `b` is the
     // entry of the WHOLE problem (addresses, score rows, histograms), `blockIdx.y` the entry inside this launch (hand-off records:
     // every launch uses the same record areas, told apart by `sub` mixed into the token)
-    const int hvp = blockIdx.x % UP, blk = blockIdx.x / UP, nblk = gridDim.x / UP, b = (int)blockIdx.y + b0;
+    // Which (entry, unit, span) a workgroup works for.  With more workgroups than compute units the hardware puts workgroup p and
+    // workgroup p + ncu on one unit (dispatch is round robin over the units while all of them have room; checked through HW_ID,
+    // tools/probes/probe_lds_iso.hip): the two are given ADJACENT SPANS OF ONE UNIT (the host makes the span count even), so that the
+    // hand-offs keep them in step -- neither can be a phase ahead of the other (maxima, sums and halo all need the partner's record).
+    // Why that matters: a workgroup that runs its later phases beside one still in phase A (another entry's, held up by the NaN redo
+    // or anything else) was measured to produce wrong row sums / window-row sums now and then (tools/repro_nan_mate.py).
+    const int nblk = gridDim.x / UP;
+    int hvp, blk, yb;
+    if (NS == 1) {
+        const int T = gridDim.x * gridDim.y, p = blockIdx.y * gridDim.x + blockIdx.x, P = T > ncu ? T - ncu : 0;
+        const int l = p >= ncu ? 2 * (p - ncu) + 1 : (p < P ? 2 * p : 2 * P + (p - P));     // logical index: unit-major, span fastest
+        const int unit = l / nblk;
+        blk = l - unit * nblk;
+        yb = unit / UH;
+        hvp = unit - yb * UH;
+    } else {
+        hvp = blockIdx.x % UP; blk = blockIdx.x / UP; yb = blockIdx.y;
+    }
+    const int b = yb + b0;
     const int BG = BG_total;
     int g_s[NS], vh_s[NS], bg_s[NS], bgv_s[NS];
     const uint16_t *kb_s[NS];
@@ -136,7 +157,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         g_s[s] = hv / VH;
         vh_s[s] = hv - g_s[s] * VH;
         bg_s[s] = b * Hkv + g_s[s];
-        bgv_s[s] = ((int)blockIdx.y * Hkv + g_s[s]) * VH + vh_s[s];       // hand-off records are per virtual head of THIS launch
+        bgv_s[s] = (yb * Hkv + g_s[s]) * VH + vh_s[s];       // hand-off records are per virtual head of THIS launch
         kb_s[s] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[s] * ks_h;   // (per-entry base: fk_host.h PtrTables)
     }
     const int n = S - W;
@@ -187,6 +208,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (tix == 0) s_abort = 0;
     FKF_STAMP(0);
+#if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 8
+    if (blockIdx.y == 0) { const uint64_t t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
+#endif
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
     // is published, so passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of
@@ -279,6 +303,18 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 FKF_STAMP(17 + 2 * (t % 2));
+#if defined(FK_DBG_DELAY) && FK_DBG_DELAY < 8
+                if (FK_DBG_WHO) {                                // debug: some workgroups are slow in phase A (no NaN involved)
+                    const uint64_t t_end = wall_clock64() + 1500;     // 100 MHz ticks: 15 us per tile
+#if FK_DBG_DELAY == 4
+                    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
+#else
+                    float zz = acc0[0];
+                    while (wall_clock64() < t_end) { for (int q9 = 0; q9 < 64; ++q9) zz = __builtin_fmaf(zz, 1.0000001f, 1e-30f); }
+                    if (zz == 123.456f) acc0[0] = zz;
+#endif
+                }
+#endif
                 if (redo_tile_if_nan<NPH, NB>(acc0, acc1, kb_s[s], ks_s, key0, S, lane, my, As + s * AS_FLOATS + lane, n31, sh))
                     tile_nan |= 1u << t;
                 const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
@@ -356,6 +392,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // (returns false when the launch is abandoned: every thread of the workgroup leaves)
     auto read_max = [&](auto sc) -> bool {
         constexpr int s = decltype(sc)::value;
+#if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 9
+        if (FK_DBG_WHO) { const uint64_t t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
+#endif
         const uint64_t *pm = pmax + (size_t)bgv_s[s] * nblk * 32;     // [nblk][32] granules: row maxima
         if (w == 0 && !wait_first_granules(pm, 32, nblk, token, lane, sp)) s_abort = 1;
         __syncthreads();
@@ -864,14 +903,23 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu)
 {
     (void)score_fused_body<D, PER, NB, NS>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu);
 }
 
 // ------------------------------------------------------------------------------------------ host side
+static int device_cus()
+{
+    static const int cus = []() {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }();
+    return cus;
+}
 template <int D, int PER, int NB, int NS> static bool fused_resident(int grid_wgs)
 {
     struct Info { int wgs_per_cu, cus; };
@@ -1014,7 +1062,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus());
         });
         *err = hipGetLastError();
         b0 += take;
@@ -1044,6 +1092,11 @@ static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn,
     }
     const int PS = pl.PERT / pl.NS;
     pl.nblk = (nwt + PS * 4 - 1) / (PS * 4);                   // workgroups (spans) per unit
+    // more workgroups than compute units: two share a unit, and the kernel pairs ADJACENT SPANS OF ONE UNIT there (see its comment):
+    // an even span count (the extra span owns no keys: it only takes part in the hand-offs)
+    const int cus = device_cus();
+    if (cus <= 0) return false;
+    if (pl.NS == 1 && (int64_t)Bn * UH * pl.nblk > cus && (pl.nblk & 1)) ++pl.nblk;
     const size_t vwgs = (size_t)Bn * UH * pl.nblk;              // hand-off records are per unit and span
     if (vwgs > FUSED_MAX_WGS) return false;
     pl.wgs = (int)(vwgs / pl.NS);

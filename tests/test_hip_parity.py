@@ -652,6 +652,22 @@ print('child ok')
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_a_launch_of_at_most_one_workgroup_per_unit_gets_through_a_held_gpu(dev):
+    """Workgroups are numbered unit by unit (round 3): a fused launch with no more workgroups than the chip has compute units (here
+    8k: 8 heads x 32 spans = 256) is dispatched head after head, so a head's workgroups become resident together even when another
+    kernel holds half of the chip -- the launch completes while the other kernel is still running, same bits, nothing reported,
+    although the wait limit (40 ms) is far below the other kernel's hold (600 ms).  (Launches with two workgroups per unit still
+    need all of them resident: the two tests above.)"""
+    code = "HOLD_MS = 600\n" + _RESIDENCY_CHILD.replace("32768", "8192") + """
+assert dt < 300, dt                                                         # it did not wait for the other kernel
+assert same(out) and L.fastkv_last_status() == 0
+torch.cuda.synchronize()
+print('child ok')
+"""
+    r = _child(code, {"FASTKV_SPIN_LIMIT_MS": "40"})
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_seed_sweep_32k_on_gpu(dev):
     """All 24 sweep cases at S = 32768 (tests/golden/sweep32k.npz: canonical top-k of the REFERENCE's scores, 12 seeds x the
     constant budget and 12 x the published proportional recipe) replayed through the operator: identical index sets on every
@@ -791,6 +807,37 @@ def test_every_operator_call_spends_its_handoff_token(dev):
         run(c49, w49)
 
 
+
+
+def test_a_slow_entry_does_not_disturb_the_entries_beside_it(dev):
+    """Regression (round 3): more workgroups than compute units = two workgroups per unit.  With the launch's linear order the
+    partner of a workgroup belonged to ANOTHER entry; when that entry was slow in phase A (a NaN in its query window sends every
+    tile through the vector-ALU redo) the partner ran its later phases beside it and produced wrong row sums / window-row sums in
+    10-20 % of the launches (tools/repro_nan_mate.py).  The kernel now pairs adjacent spans of ONE unit, which the
+    hand-offs keep in step.  16 entries x 2 virtual heads x 15 (-> 16) spans = 512 workgroups; the NaN entry itself is NaN all over
+    (as in the oracle), every other entry must be bit-exact, launch after launch."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    H, Hkv, S, D, W, ks, cap, tsp_len, n = 8, 1, 14695, 128, 8, 13, 8316, 10400, 16
+    ins = [make_qkv(9197 + 100000 * j, 1, H, Hkv, S, D, W, peaked=50) for j in range(n)]
+    q0 = ins[5][0].clone()
+    q0[0, 3, S - 2, 9] = float("nan")
+    ins[5] = (q0, ins[5][1], ins[5][2])
+    wants = [O.update_kv(q, k, v, W, ks, "avgpool", cap, tsp_len, "index") for q, k, v in ins]
+    qs, kks, vs = ([_to_dev(t[j], dev) for t in ins] for j in range(3))
+    for rnd in range(40):
+        got = ops.update_kv_entries(qs, kks, vs, W, ks, "avgpool", cap, tsp_len, "index", return_indices=True)
+        torch.cuda.synchronize()
+        for i, want in enumerate(wants):
+            assert torch.equal(got[3][i:i + 1].cpu(), want[2]) and torch.equal(got[2][i:i + 1].cpu(), want[3]), (rnd, i)
+            assert torch.equal(got[0][i].cpu().view(torch.int16), want[0].view(torch.int16)), (rnd, i)
+    # the same through the batched entry point, scores compared element by element (NaN rows by their bit patterns)
+    q, k, v = (torch.cat([t[j] for t in ins], dim=0) for j in range(3))
+    want = O.update_kv(q, k, v, W, ks, "avgpool", cap, tsp_len, "index", return_scores=True)
+    qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+    for rnd in range(20):
+        got = ops.update_kv(qd, kd, vd, W, ks, "avgpool", cap, tsp_len, "index", return_indices=True, return_scores=True)
+        assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), rnd
 
 
 def test_operator_over_separately_allocated_entries(dev):

@@ -200,7 +200,9 @@ replace_llama('fastkv')
 torch.manual_seed(3)
 model = prefill.build_model(a, 'cuda')
 set_model(model, a)
-ids = torch.randint(0, 1000, (1, 4096), generator=torch.Generator().manual_seed(5)).cuda()
+# 8192 tokens: the pair's fused launch has 512 workgroups, two per compute unit -- the launches that need all their workgroups resident
+# (a launch of up to 256 workgroups is dispatched unit by unit and gets through a partly occupied GPU: its units complete one after the other)
+ids = torch.randint(0, 1000, (1, 8192), generator=torch.Generator().manual_seed(5)).cuda()
 with torch.no_grad():
     ref = model(ids)                                                       # idle GPU: layers 0 and 1 run as a deferred PAIR
 torch.cuda.synchronize()
