@@ -22,6 +22,11 @@
 //   compaction kernel of EVERY operator call advances the epoch, whichever scoring path ran: the split selection tags its
 //   counters with the same token), never a launch argument that a graph replay would freeze: a granule left by an earlier
 //   launch never matches.
+//
+// Which workgroup works for which (entry, unit, span): numbered unit by unit, span fastest -- a launch of up to one workgroup per
+// compute unit is dispatched unit after unit and gets through a partly occupied GPU.  With more workgroups than compute units,
+// workgroup p and workgroup p + #CUs sit on ONE compute unit; they are given adjacent spans of one unit, so that the hand-offs keep
+// the two in step (see the kernel body; the measurement behind this is in DESIGN.md section 8).
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
@@ -40,6 +45,10 @@ __device__ unsigned long long g_fstamps[4096 * 48];
 #endif
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+// Test hook (fastkv_debug_fused_placement): where the workgroups of the last fused launch ran -- per workgroup of the launch's linear
+// order {HW_ID, XCC_ID, unit, span}.  The pairing of workgroups that share a compute unit (see the kernel) rests on the dispatch order
+// of the GPU: tests/test_hip_parity.py reads this back and checks it on the machine it runs on.
+__device__ uint32_t g_placement[1024 * 4];
 constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the nblk partial records
 
 // Hand-off records are 8-byte {token, 32-bit value} granules, written by ONE write-through (sc1) store each: the data is
@@ -83,7 +92,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place)
 {
 #if defined(FK_DBG_DELAY) && !defined(FK_DBG_WHO)
 #define FK_DBG_WHO (yb == 0)
@@ -148,6 +157,13 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         hvp = blockIdx.x % UP; blk = blockIdx.x / UP; yb = blockIdx.y;
     }
     const int b = yb + b0;
+    if (place && tix == 0) {
+        uint32_t *pl = place + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        pl[0] = __builtin_amdgcn_s_getreg(63492);                  // HW_ID (all 32 bits)
+        pl[1] = __builtin_amdgcn_s_getreg(63508);                  // XCC_ID
+        pl[2] = (uint32_t)(yb * UH + hvp);
+        pl[3] = (uint32_t)blk;
+    }
     const int BG = BG_total;
     int g_s[NS], vh_s[NS], bg_s[NS], bgv_s[NS];
     const uint16_t *kb_s[NS];
@@ -903,14 +919,21 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place)
 {
     (void)score_fused_body<D, PER, NB, NS>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place);
 }
 
 // ------------------------------------------------------------------------------------------ host side
+static bool g_record_placement = false;
+static uint32_t *placement_buffer()
+{
+    if (!g_record_placement) return nullptr;
+    void *ptr = nullptr;
+    return hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_placement)) == hipSuccess ? static_cast<uint32_t *>(ptr) : nullptr;
+}
 static int device_cus()
 {
     static const int cus = []() {
@@ -1062,7 +1085,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus());
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer());
         });
         *err = hipGetLastError();
         b0 += take;
@@ -1105,6 +1128,15 @@ static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn,
     return true;
 }
 
+}  // namespace fk
+extern "C" int fastkv_debug_fused_placement(int enable, unsigned int *host, size_t n_words)
+{
+    fk::g_record_placement = enable != 0;
+    if (!host || !n_words) return FASTKV_OK;
+    if (n_words > 1024 * 4) return FASTKV_EINVAL;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::g_placement), n_words * sizeof(unsigned int)) == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+namespace fk {
 #ifdef FK_STAMP
 }  // namespace fk
 extern "C" int fastkv_debug_read_fused_stamps(unsigned long long *host, size_t n)

@@ -357,6 +357,11 @@ int fastkv_debug_contract(int op, const float *a, const float *b, float *out, ui
 /* Test hook: `wgs` 256-thread workgroups that each hold `lds_bytes` of LDS for `usec` microseconds -- "another kernel is
  * holding compute units" for the residency tests of the in-launch hand-offs. */
 int fastkv_debug_occupy(int wgs, int lds_bytes, int64_t usec, void *stream);
+/* Test hook: `enable` != 0 makes every following fused scoring launch record, per workgroup of its linear launch order, the words
+ * {HW_ID, XCC_ID, unit, span} (where it ran, what it worked on); `host` != NULL copies the first `n_words` (<= 4096) recorded words
+ * out (call after synchronising).  The kernel gives two workgroups that share a compute unit adjacent spans of one unit; which two
+ * share is the GPU's dispatch order, and this is how the tests check that order on the machine they run on. */
+int fastkv_debug_fused_placement(int enable, unsigned int *host, size_t n_words);
 
 /*
  * Measurement hooks (bench.py): when enabled, every kernel launch is bracketed by HIP events on its stream.

@@ -809,6 +809,46 @@ def test_every_operator_call_spends_its_handoff_token(dev):
 
 
 
+def test_workgroups_sharing_a_compute_unit_are_neighbours_of_one_unit(dev):
+    """The pairing of `score_fused` rests on the GPU's dispatch order (workgroup p and p + #CUs land on one compute unit when the
+    launch has more workgroups than units).  Checked HERE, on the machine the tests run on, through the placement hook: every
+    compute unit that hosted two workgroups of a 512-workgroup launch hosted spans 2j and 2j + 1 of ONE unit; launches of up to 256
+    workgroups put one workgroup on a unit and number them unit by unit."""
+    import ctypes
+    from fastkv_amd import ops
+    from fastkv_amd._lib import load
+    L = load()
+    def placement(n_wgs):
+        buf = (ctypes.c_uint32 * (4 * n_wgs))()
+        assert L.fastkv_debug_fused_placement(1, ctypes.cast(buf, ctypes.c_void_p), 4 * n_wgs) == 0
+        rows = [tuple(buf[4 * i:4 * i + 4]) for i in range(n_wgs)]
+        # HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID 3:0
+        return [dict(where=(x & 15, (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15), unit=u, span=sp) for h, x, u, sp in rows]
+    try:
+        assert L.fastkv_debug_fused_placement(1, None, 0) == 0
+        for S, Hkv, H, B, n_wgs in ((32768, 8, 32, 1, 512), (14695, 1, 8, 16, 512), (8192, 8, 32, 1, 256)):
+            q, k, v = make_qkv(321, B, H, Hkv, S, 128, 8)
+            qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+            ops.update_kv(qd, kd, vd, 8, 7, "maxpool", 2048, 0, "index")
+            torch.cuda.synchronize()
+            pl = placement(n_wgs)
+            nspan = max(w["span"] for w in pl) + 1
+            assert sorted((w["unit"], w["span"]) for w in pl) == [(u, sp) for u in range(n_wgs // nspan) for sp in range(nspan)], S   # each once
+            by_cu = {}
+            for w in pl:
+                by_cu.setdefault(w["where"], []).append(w)
+            if n_wgs > 256:
+                assert len(by_cu) == 256 and all(len(ws) == 2 for ws in by_cu.values()), (S, len(by_cu))
+                for ws in by_cu.values():
+                    a, b2 = sorted(ws, key=lambda w: w["span"])
+                    assert a["unit"] == b2["unit"] and a["span"] % 2 == 0 and b2["span"] == a["span"] + 1, (S, ws)
+            else:
+                assert len(by_cu) == n_wgs, (S, len(by_cu))          # one workgroup per compute unit
+                assert [(w["unit"], w["span"]) for w in pl] == sorted((w["unit"], w["span"]) for w in pl)   # unit by unit in launch order
+    finally:
+        L.fastkv_debug_fused_placement(0, None, 0)
+
+
 def test_a_slow_entry_does_not_disturb_the_entries_beside_it(dev):
     """Regression (round 3): more workgroups than compute units = two workgroups per unit.  With the launch's linear order the
     partner of a workgroup belonged to ANOTHER entry; when that entry was slow in phase A (a NaN in its query window sends every
