@@ -18,6 +18,7 @@
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
+#include <cstdlib>
 
 namespace fk {
 
@@ -156,6 +157,24 @@ __global__ void __launch_bounds__(256) decode_gemv_kernel(GemvArgs a)
                     for (int i = 0; i < OR; ++i) acc[i][b] = gv_dot8(wv[i][u], xv, acc[i][b]);
                 }
         }
+        // (what is left of K: 4 segments at a time where U is 8 -- K = 14336 is three batches of 8 and one of 4 --, then singly)
+        if (U >= 8) {
+            for (; c + 512 * 4 <= K; c += 512 * 4) {
+                gv_u4 wq[OR][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < OR; ++i) wq[i][u] = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(wr[i] + c + u * 512));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int b = 0; b < BB; ++b) {
+                        const gv_u4 xv = *reinterpret_cast<const gv_u4 *>(s_x + b * K + c + u * 512 + lane * 8);
+#pragma unroll
+                        for (int i = 0; i < OR; ++i) acc[i][b] = gv_dot8(wq[i][u], xv, acc[i][b]);
+                    }
+            }
+        }
         for (; c < K; c += 512) {
             gv_u4 wt[OR];
 #pragma unroll
@@ -235,7 +254,8 @@ extern "C" int fastkv_decode_gemv_f16(int32_t B, int32_t K, const void *x, int64
     ProfScope ps_(K_DECODE, st);
     // rows in flight per wave: 4 x 4 segments for wide outputs, 2 x 8 for narrow ones (more workgroups; either way 16 loads
     // of 16 B per lane are outstanding).  Workgroups are sized so that every one runs the same number of iterations.
-    const bool wide = glu || nout >= 16384;
+    static const int force_cfg = []() { const char *e = getenv("FASTKV_GEMV_CFG"); return e ? atoi(e) : 0; }();   // measurement aid: 1 narrow, 2 wide, 3 = 4 rows x 8 segments
+    const bool wide = force_cfg ? force_cfg >= 2 : (glu || nout >= 16384);
     const int nr = wide ? 4 : 2;
     const int orows = glu ? nr / 2 : nr;
     const int64_t iters = (nout + 4 * orows - 1) / (4 * orows);
@@ -244,7 +264,8 @@ extern "C" int fastkv_decode_gemv_f16(int32_t B, int32_t K, const void *x, int64
     const size_t lds = (size_t)B * K * 2;
 #define FK_GEMV(BBV)                                                                                             \
     do {                                                                                                         \
-        if (wide) hipLaunchKernelGGL((decode_gemv_kernel<BBV, 4, 4>), dim3((unsigned)wgs), dim3(256), lds, st, a); \
+        if (force_cfg == 3) hipLaunchKernelGGL((decode_gemv_kernel<BBV, 4, 8>), dim3((unsigned)wgs), dim3(256), lds, st, a); \
+        else if (wide) hipLaunchKernelGGL((decode_gemv_kernel<BBV, 4, 4>), dim3((unsigned)wgs), dim3(256), lds, st, a); \
         else hipLaunchKernelGGL((decode_gemv_kernel<BBV, 2, 8>), dim3((unsigned)wgs), dim3(256), lds, st, a);      \
     } while (0)
     if (B == 1) FK_GEMV(1);
