@@ -587,7 +587,10 @@ def main():
                       "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
            "ttft_hotpath_ms": round(ms_per_step, 4),
            "ranks_seen": dist.get_world_size() if dist is not None else 1,
-           "backend": (dist.get_backend() if dist is not None else "none")}
+           "backend": (dist.get_backend() if dist is not None else "none"),
+           # the fused launches' own check of where their workgroups ran (include/fastkv_hip.h: fastkv_placement_violations): 0 = every
+           # pair of workgroups that shared a compute unit in the warm-up and timed steps belonged to one head, as the kernel assumes
+           "placement_violations": int(lib.fastkv_placement_violations(0))}
     out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
                                  f"sequence after the last layer, the layers in front of it in groups of {work.defer_hold} (FASTKV_DEFER_HOLD: a layer waits "
                                  "for its peers, q / k / v held meanwhile: 400 MiB per waiting layer; the library scores a group two layers per "

@@ -11,7 +11,7 @@ from . import _build
 
 
 # return codes of the C ABI (include/fastkv_hip.h)
-FASTKV_OK, FASTKV_EINVAL, FASTKV_EWORKSPACE, FASTKV_ELAUNCH, FASTKV_EUNSUPPORTED, FASTKV_EABORTED, FASTKV_EOVERFLOW, FASTKV_EBOUNDS = 0, -1, -2, -3, -4, -5, -6, -7
+FASTKV_OK, FASTKV_EINVAL, FASTKV_EWORKSPACE, FASTKV_ELAUNCH, FASTKV_EUNSUPPORTED, FASTKV_EABORTED, FASTKV_EOVERFLOW, FASTKV_EBOUNDS, FASTKV_EPLACEMENT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class FastKVNativeError(RuntimeError):
@@ -39,7 +39,7 @@ EXPORTS = ["fastkv_workspace_bytes", "fastkv_workspace_init", "fastkv_update_kv_
            "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_compact_ranked_f16", "fastkv_gather_rows", "fastkv_head_sum_f16", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
            "fastkv_sp_scores_f16", "fastkv_sp_pack_f16", "fastkv_sp_unpack_f16", "fastkv_sp_pick",
            "fastkv_sp_compact_f16", "fastkv_decode_workspace_bytes", "fastkv_decode_append_f16", "fastkv_decode_attention_f16",
-           "fastkv_decode_rmsnorm_f16", "fastkv_decode_rope_f16", "fastkv_decode_silu_mul_f16", "fastkv_decode_gemv_f16", "fastkv_update_kv_ptrs_f16", "fastkv_fused_entries_f16", "fastkv_pool_f16", "fastkv_decode_step_attention_f16", "fastkv_debug_contract", "fastkv_debug_occupy", "fastkv_debug_fused_placement", "fastkv_last_status", "fastkv_profile_enable",
+           "fastkv_decode_rmsnorm_f16", "fastkv_decode_rope_f16", "fastkv_decode_silu_mul_f16", "fastkv_decode_gemv_f16", "fastkv_update_kv_ptrs_f16", "fastkv_fused_entries_f16", "fastkv_pool_f16", "fastkv_decode_step_attention_f16", "fastkv_debug_contract", "fastkv_debug_occupy", "fastkv_debug_fused_placement", "fastkv_placement_violations", "fastkv_last_status", "fastkv_profile_enable",
            "fastkv_profile_kernels", "fastkv_profile_kernel_name", "fastkv_profile_read", "fastkv_strerror", "fastkv_version"]
 
 _lib = None
@@ -127,6 +127,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_debug_occupy.restype = ci
     L.fastkv_debug_fused_placement.argtypes = [ci, vp, ctypes.c_size_t]
     L.fastkv_debug_fused_placement.restype = ci
+    L.fastkv_placement_violations.argtypes = [ci]
+    L.fastkv_placement_violations.restype = ci
     L.fastkv_last_status.argtypes = []
     L.fastkv_last_status.restype = ci
     L.fastkv_debug_contract.argtypes = [ci, vp, vp, vp, vp, ci, vp]

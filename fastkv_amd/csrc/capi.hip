@@ -23,6 +23,7 @@ uint32_t *abort_flag_device()
         reinterpret_cast<volatile uint32_t *>(h)[0] = 0;
         reinterpret_cast<volatile uint32_t *>(h)[1] = 0;
         reinterpret_cast<volatile uint32_t *>(h)[2] = 0;
+        reinterpret_cast<volatile uint32_t *>(h)[3] = 0;
         g_abort_host = reinterpret_cast<uint32_t *>(h);
         g_abort_dev = reinterpret_cast<uint32_t *>(d);
     });
@@ -45,9 +46,21 @@ static int take_abort_status()
     if (__atomic_load_n(g_abort_host + 1, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 1, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EOVERFLOW;
     // word 2 (FASTKV_DEBUG_BOUNDS=1 only): a gather was handed an index outside [0, S) (compact.hip)
     if (__atomic_load_n(g_abort_host + 2, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 2, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EBOUNDS;
+    // word 3: workgroups of a fused scoring launch that met a workgroup of ANOTHER unit on their compute unit (fused.hip: placement
+    // check).  A count, not an error -- unless FASTKV_STRICT_PLACEMENT=1 asks for one
+    static const bool strict = []() { const char *e = getenv("FASTKV_STRICT_PLACEMENT"); return e && e[0] == '1'; }();
+    if (strict && __atomic_load_n(g_abort_host + 3, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 3, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EPLACEMENT;
     return FASTKV_OK;
 }
 }  // namespace fk
+
+extern "C" int fastkv_placement_violations(int reset)
+{
+    (void)fk::abort_flag_device();
+    if (!fk::g_abort_host) return 0;
+    const uint32_t v = reset ? __atomic_exchange_n(fk::g_abort_host + 3, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(fk::g_abort_host + 3, __ATOMIC_ACQUIRE);
+    return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
 
 namespace {
 
@@ -461,6 +474,9 @@ const char *fastkv_strerror(int code)
                "the last cached row was overwritten, the tokens from that step on are invalid";
     case FASTKV_EBOUNDS:
         return "index-bounds debug mode (FASTKV_DEBUG_BOUNDS=1): an earlier gather was handed a row index outside [0, S) (it read a clamped row)";
+    case FASTKV_EPLACEMENT:
+        return "FASTKV_STRICT_PLACEMENT=1: workgroups of an earlier fused scoring launch shared a compute unit with workgroups of another "
+               "unit (foreign kernels on the GPU, or a launch that was not resident all at once): see fastkv_placement_violations()";
     case FASTKV_EUNSUPPORTED: return "unsupported configuration (head_dim must be 64/128/256, S < 2^24)";
     default: return "unknown error";
     }

@@ -13,6 +13,7 @@ constexpr size_t CTRL_BYTES = 8192;  // control block at the start of every oper
                                      // u64 magic, u32 epoch (the rest is reserved)
                                      // u64 magic, u32 epoch, u32 abort word (token of a launch that gave up waiting)
 constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
+constexpr int FUSED_CU_SLOTS = 2048;  // {XCC_ID, SE, SH, CU} of HW_ID as an index: who ran on a compute unit in this launch (placement check of the fused kernel)
 constexpr int FUSED_MAX_WGS = 1024;  // (unit, span) pairs of one fused score launch -- 512 workgroups (2 per CU) x up to 2 streams: sizes its hand-off records
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
@@ -73,7 +74,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
     L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 256, 256);   // ... and 32 8-byte granules per chunk
-    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8), 256);   // fused score: row max / row sum / halo granules
+    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + FUSED_CU_SLOTS * 8, 256);   // fused score: row max / row sum / halo granules + one {token, unit} granule per compute unit
     // fused score with more than 4 query heads per KV head: per-position head-sum granules between virtual heads
     L.off_fchain = o; o += (p.H / p.Hkv > 4) ? align_up((size_t)512 * 1024 * 8, 256) : 0;          // [unit span][positions]: 512 Ki granules at most
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);

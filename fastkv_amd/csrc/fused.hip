@@ -92,7 +92,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots)
 {
 #if defined(FK_DBG_DELAY) && !defined(FK_DBG_WHO)
 #define FK_DBG_WHO (yb == 0)
@@ -223,6 +223,18 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     token = token ? token : 0x6B43A9B5u;
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (tix == 0) s_abort = 0;
+    // Placement check.  The pairing above ASSUMES which workgroups share a compute unit; this notices when the assumption did not hold:
+    // every workgroup swaps {token, its unit} into the slot of the compute unit it runs on (one returning atomic, asked for now, looked
+    // at when the kernel ends).  Meeting this launch's token with ANOTHER unit in it = a workgroup of another unit ran on this compute
+    // unit during the launch (beside this one, or before it where a launch was not resident all at once): counted in pinned word 3,
+    // fastkv_placement_violations().  Never on an idle GPU (tests); expected beside a foreign kernel.
+    uint64_t cu_seen = 0;
+    const uint32_t my_unit = (uint32_t)bgv_s[0] + 1u;
+    if (cu_slots && tix == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xc = __builtin_amdgcn_s_getreg(63508);
+        cu_seen = __hip_atomic_exchange(cu_slots + (((xc & 7u) << 8) | ((hw >> 8) & 0xffu)), granule(token, my_unit), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+    }
     FKF_STAMP(0);
 #if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 8
     if (blockIdx.y == 0) { const uint64_t t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
@@ -900,6 +912,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     FKF_STAMP(12);
     if (NS == 2) { if (!read_halo(S1{})) return false; FKF_STAMP(13); phaseD_any(S1{}); }
     FKF_STAMP(14);
+    if (cu_slots && tix == 0 && (uint32_t)(cu_seen >> 32) == token && (uint32_t)cu_seen != my_unit)
+        __hip_atomic_fetch_add(host_flag + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return true;
 }
 
@@ -919,11 +933,11 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots)
 {
     (void)score_fused_body<D, PER, NB, NS>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1036,6 +1050,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     const uint64_t spin_ticks = spin_limit_ticks();
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [unit span][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
+    uint64_t *cu_slots = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8));
     uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
     // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
     // for each other until the spin limit and be reported as FASTKV_EABORTED).  Within this process the library sees to it:
@@ -1085,7 +1100,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer());
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), cu_slots);
         });
         *err = hipGetLastError();
         b0 += take;

@@ -37,6 +37,8 @@ extern "C" {
 #define FASTKV_EOVERFLOW (-6)  /* an EARLIER static-decode step found its cache slab full (reported like FASTKV_EABORTED) */
 #define FASTKV_EBOUNDS (-7)    /* FASTKV_DEBUG_BOUNDS=1 only: an EARLIER gather was handed a row index outside [0, S) (it read a
                                   clamped row, as always; reported like FASTKV_EABORTED) */
+#define FASTKV_EPLACEMENT (-8) /* FASTKV_STRICT_PLACEMENT=1 only: workgroups of an EARLIER fused scoring launch shared a compute unit
+                                  with workgroups of another unit (see fastkv_placement_violations; reported like FASTKV_EABORTED) */
 
 #define FASTKV_POOL_AVG 0 /* F.avg_pool1d(k, padding=k//2, stride=1)   utils.py:105-106 */
 #define FASTKV_POOL_MAX 1 /* F.max_pool1d(k, padding=k//2, stride=1)   utils.py:107-108 */
@@ -101,6 +103,17 @@ int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
  * cached row and the length stops advancing); clears the report; else 0.
  * Host-only (reads two words of pinned memory); call it after synchronising to learn about the calls just completed. */
 int fastkv_last_status(void);
+/*
+ * The fused scoring kernel gives the two workgroups that share a compute unit adjacent spans of one (batch row, kv head): which two
+ * share is the GPU's dispatch order on an idle device, an observation and not a promise (DESIGN.md section 8 on why the kernel
+ * cares: a workgroup that ran a phase ahead of a DIFFERENT unit's workgroup on its compute unit was measured to produce wrong sums
+ * now and then).  Every launch checks it: a workgroup that finds another unit's workgroup of the same launch on its compute unit
+ * is counted in pinned host memory.  Returns the count since the last reset (host only, no synchronisation; complete once the
+ * stream has been synchronised).  0 on an idle GPU (the tests assert it); > 0 beside foreign kernels, or when a launch could not
+ * become resident all at once -- results were bit-exact in every such test, but the guarantee of the pairing is gone: a shared GPU
+ * should run FASTKV_FUSED=0.  FASTKV_STRICT_PLACEMENT=1 turns a non-zero count into FASTKV_EPLACEMENT at the next call.
+ */
+int fastkv_placement_violations(int reset);
 
 /*
  * The whole operator: replaces the compress branch of FastKVCluster.update_kv (utils.py:93-132).

@@ -619,6 +619,9 @@ t0 = time.perf_counter()
 out = run()
 dt = (time.perf_counter() - t0) * 1e3
 print('held call took %.1f ms' % dt)
+torch.cuda.current_stream().synchronize()
+viol = L.fastkv_placement_violations(RESET)
+print('placement violations', viol)
 """
 
 
@@ -626,8 +629,22 @@ def test_operator_next_to_a_kernel_that_holds_half_the_chip(dev):
     """A long-running kernel on another stream holds half of the compute units while the operator runs (32k shape: the fused
     scoring kernel's 512 workgroups and the split selection wait for partners that cannot become resident until the other
     kernel ends).  The launch is delayed, not broken: same bits as the oracle, no report."""
-    r = _child("HOLD_MS = 300\n" + _RESIDENCY_CHILD +
-               "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nprint('child ok')\n", {})
+    r = _child("HOLD_MS = 300\nRESET = 1\n" + _RESIDENCY_CHILD +
+               "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nassert viol > 0, viol\nprint('child ok')\n", {})
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    # (viol > 0: squeezed onto half of the chip, workgroups of different heads shared compute units -- the launch's own placement check
+    # counts that; the result was right all the same.  With FASTKV_STRICT_PLACEMENT=1 the next call reports it:)
+    r = _child("HOLD_MS = 300\nRESET = 0\n" + _RESIDENCY_CHILD + """
+from fastkv_amd._lib import FASTKV_EPLACEMENT
+try:
+    run()
+    raise SystemExit('no report in strict mode')
+except FastKVNativeError as e:
+    assert e.code == FASTKV_EPLACEMENT, str(e)
+torch.cuda.synchronize()
+assert same(run()) and L.fastkv_last_status() == 0
+print('child ok')
+""", {"FASTKV_STRICT_PLACEMENT": "1"})
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
@@ -635,7 +652,7 @@ def test_abandoned_launch_is_reported_not_trapped(dev):
     """The same with a wait limit (FASTKV_SPIN_LIMIT_MS=40) shorter than the other kernel's hold: the waiting workgroups give
     up, the launch ends (no trap, no hang, no fault in the stages behind it), the process learns about it through
     FASTKV_EABORTED at the next call -- and the context is alive: the call after that is bit-exact again."""
-    code = "HOLD_MS = 600\n" + _RESIDENCY_CHILD + """
+    code = "HOLD_MS = 600\nRESET = 1\n" + _RESIDENCY_CHILD + """
 assert dt < 550, dt                                                         # it did not wait for the other kernel
 try:
     run()                                                                   # the NEXT call reports the abandoned one
@@ -658,7 +675,7 @@ def test_a_launch_of_at_most_one_workgroup_per_unit_gets_through_a_held_gpu(dev)
     kernel holds half of the chip -- the launch completes while the other kernel is still running, same bits, nothing reported,
     although the wait limit (40 ms) is far below the other kernel's hold (600 ms).  (Launches with two workgroups per unit still
     need all of them resident: the two tests above.)"""
-    code = "HOLD_MS = 600\n" + _RESIDENCY_CHILD.replace("32768", "8192") + """
+    code = "HOLD_MS = 600\nRESET = 1\n" + _RESIDENCY_CHILD.replace("32768", "8192") + """
 assert dt < 300, dt                                                         # it did not wait for the other kernel
 assert same(out) and L.fastkv_last_status() == 0
 torch.cuda.synchronize()
@@ -826,6 +843,7 @@ def test_workgroups_sharing_a_compute_unit_are_neighbours_of_one_unit(dev):
         return [dict(where=(x & 15, (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15), unit=u, span=sp) for h, x, u, sp in rows]
     try:
         assert L.fastkv_debug_fused_placement(1, None, 0) == 0
+        L.fastkv_placement_violations(1)
         for S, Hkv, H, B, n_wgs in ((32768, 8, 32, 1, 512), (14695, 1, 8, 16, 512), (8192, 8, 32, 1, 256)):
             q, k, v = make_qkv(321, B, H, Hkv, S, 128, 8)
             qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
@@ -845,6 +863,8 @@ def test_workgroups_sharing_a_compute_unit_are_neighbours_of_one_unit(dev):
             else:
                 assert len(by_cu) == n_wgs, (S, len(by_cu))          # one workgroup per compute unit
                 assert [(w["unit"], w["span"]) for w in pl] == sorted((w["unit"], w["span"]) for w in pl)   # unit by unit in launch order
+        # ... and the kernel's own check (every launch, every workgroup) agrees: nobody met another unit on its compute unit
+        assert L.fastkv_placement_violations(0) == 0
     finally:
         L.fastkv_debug_fused_placement(0, None, 0)
 
@@ -878,6 +898,8 @@ def test_a_slow_entry_does_not_disturb_the_entries_beside_it(dev):
     for rnd in range(20):
         got = ops.update_kv(qd, kd, vd, W, ks, "avgpool", cap, tsp_len, "index", return_indices=True, return_scores=True)
         assert torch.equal(got[4].cpu().view(torch.int16), want[4].view(torch.int16)), rnd
+    from fastkv_amd._lib import load
+    assert load().fastkv_placement_violations(0) == 0                     # (the placement check of every launch so far in this process)
 
 
 def test_operator_over_separately_allocated_entries(dev):

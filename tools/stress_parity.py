@@ -167,5 +167,7 @@ for it in range(N):
         print("replaying", tag, {x: case[x] for x in ("engine", "stream_pick", "pre", "slab", "ne", "qwin")}, flush=True)
     for rep in range(REPEAT if ONLY >= 0 else 1):
         fails += run_case(case, rep)
+from fastkv_amd._lib import load as _load
+print("placement violations counted by the fused launches:", _load().fastkv_placement_violations(0))
 print(f"{N} cases, {fails} mismatches, {time.time() - t0:.0f} s (entries calls: {n_entries_runs} run, {n_entries_refused} refused)")
 sys.exit(1 if fails else 0)
