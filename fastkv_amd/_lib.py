@@ -154,10 +154,23 @@ def check(rc: int, what: str) -> None:
         raise FastKVNativeError(f"fastkv_amd.{what}: {msg} (code {rc})", code=rc)
 
 
+_violations_seen = 0
+
+
 def raise_if_aborted(what: str = "last_status") -> None:
     """Host-only read of the library's asynchronous-error word (fastkv_last_status): raises FastKVNativeError(FASTKV_EABORTED /
     FASTKV_EOVERFLOW) if a launch of this process that has ALREADY RUN gave up a bounded in-kernel wait or overran a decode slab
     since the last report.  Costs a load of pinned memory: no synchronisation.  Call it behind a synchronisation point to learn
     about everything enqueued before it (benchmark/prefill.py, benchmark/e2e.py); the wiring also calls it un-synchronised at the
     end of every prefill, which reports what has completed by then."""
-    check(load().fastkv_last_status(), what)
+    L = load()
+    check(L.fastkv_last_status(), what)
+    global _violations_seen
+    total = L.fastkv_placement_violations(0)                # (not reset: bench.py and tests read the running count)
+    n, _violations_seen = total - _violations_seen if total >= _violations_seen else total, total
+    if n:
+        # not an error (FASTKV_STRICT_PLACEMENT=1 makes it one): the results were right in every test, the pairing's guarantee is gone
+        import warnings
+        warnings.warn(f"fastkv_amd.{what}: {n} workgroup(s) of fused scoring launches shared a compute unit with another head's workgroups "
+                      "(foreign kernels on the GPU, or a launch that was not resident all at once); set FASTKV_FUSED=0 on a shared GPU "
+                      "(include/fastkv_hip.h: fastkv_placement_violations)", RuntimeWarning, stacklevel=2)
