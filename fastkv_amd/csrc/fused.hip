@@ -64,7 +64,9 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
         for (int l = lane; l < nblk; l += 64)
             ok = ok && ((uint32_t)(__hip_atomic_load(rec + (size_t)l * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token);
         if (__all(ok)) break;
+#ifndef FK_DBG_NOSLEEP
         __builtin_amdgcn_s_sleep(8);
+#endif
         if (__builtin_amdgcn_readfirstlane((int)spin_failed(sp))) return false;     // a partner never arrived: give up, loudly (host flag)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: every load of handed-over bytes is an sc1 load
@@ -128,6 +130,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     __shared__ uint32_t s_rb[FUSED_PARTS][32];
     __shared__ float s_gm[NS][32], s_ri[NS][32];               // row maxima / reciprocal row sums of the streams' heads
     __shared__ uint32_t s_abort;
+#ifdef FK_DBG_SYNCAND
+    __shared__ uint32_t s_dbg_flag;
+#endif
     const unsigned tix = threadIdx.x;
     const int lane = tix & 63, w = __builtin_amdgcn_readfirstlane(tix >> 6);
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
@@ -146,7 +151,11 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // or anything else) was measured to produce wrong row sums / window-row sums now and then (tools/repro_nan_mate.py).
     const int nblk = gridDim.x / UP;
     int hvp, blk, yb;
+#ifdef FK_OLD_NUMBERING                                          // (measurement builds of the hunt in DESIGN.md section 8 only)
+    if (false) {
+#else
     if (NS == 1) {
+#endif
         const int T = gridDim.x * gridDim.y, p = blockIdx.y * gridDim.x + blockIdx.x, P = T > ncu ? T - ncu : 0;
         const int l = p >= ncu ? 2 * (p - ncu) + 1 : (p < P ? 2 * p : 2 * P + (p - P));     // logical index: unit-major, span fastest
         const int unit = l / nblk;
@@ -237,7 +246,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     }
     FKF_STAMP(0);
 #if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 8
-    if (blockIdx.y == 0) { const uint64_t t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
+    if (FK_DBG_WHO) { const uint64_t t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
 #endif
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
@@ -446,7 +455,15 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                 }
             }
             s_rf[part][row] = v;
+#ifdef FK_DBG_SYNCAND
+            if (tix == 0) s_dbg_flag = 0;
+            __syncthreads();
+            if (!ok) s_dbg_flag = 1;
+            __syncthreads();
+            if (!s_dbg_flag) break;
+#else
             if (__syncthreads_and(ok)) break;
+#endif
             if (tix == 0 && spin_failed(sp)) s_abort = 1;      // a record behind a current granule 0 is still old: rare
             __syncthreads();
             if (s_abort) return false;
@@ -586,7 +603,15 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
             }
             s_ru[part][row] = s2;
             s_rb[part][row] = bad;
+#ifdef FK_DBG_SYNCAND
+            if (tix == 0) s_dbg_flag = 0;
+            __syncthreads();
+            if (!ok) s_dbg_flag = 1;
+            __syncthreads();
+            if (!s_dbg_flag) break;
+#else
             if (__syncthreads_and(ok)) break;
+#endif
             if (tix == 0 && spin_failed(sp)) s_abort = 1;
             __syncthreads();
             if (s_abort) return false;
@@ -754,7 +779,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
                 }
             }
+#ifndef FK_DBG_NO_HIST
             if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
+#endif
         }
         FKF_STAMP(31);
         if (all_keys && last_vh && blk == 0 && (int)tix < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + tix] = 0;
