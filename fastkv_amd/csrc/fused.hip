@@ -343,7 +343,12 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #if defined(FK_DBG_DELAY) && FK_DBG_DELAY < 8
                 if (FK_DBG_WHO) {                                // debug: some workgroups are slow in phase A (no NaN involved)
                     const uint64_t t_end = wall_clock64() + 1500;     // 100 MHz ticks: 15 us per tile
-#if FK_DBG_DELAY == 4
+#if FK_DBG_DELAY == 6
+                    // every workgroup, but only SOME of its waves (a hash of workgroup, wave and tile picks them): the waves of a workgroup
+                    // reach the end of phase A far apart -- does the kernel depend on its waves running in step?
+                    if ((((blockIdx.y * gridDim.x + blockIdx.x) * 2654435761u + w * 40503u + t * 977u) >> 7 & 3u) == 0u)
+                        while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
+#elif FK_DBG_DELAY == 4
                     while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
 #else
                     float zz = acc0[0];
