@@ -331,9 +331,16 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     const bool more = nt < PER && tile_wt(nt) < nwt;
                     const uint16_t *nkb = kb_s[(nt / PS) % NS];
                     const int nkey = tile_key0(nt);
+#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_NOLDS)          // hunt: the delayed workgroups stage no K (no LDS writes, no loads)
+                    if (FK_DBG_WHO) { }
+                    else
+#endif
                     if (useA) { k_commit<NB>(sA, lane, my); if (more) k_fetch<NB>(sA, nkb, ks_s, nkey, S, nph, lane); }
                     else { k_commit<NB>(sB, lane, my); if (more) k_fetch<NB>(sB, nkb, ks_s, nkey, S, nph, lane); }
                     __builtin_amdgcn_sched_barrier(0);
+#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_NOMFMA)         // ... or issue no MFMA (and read no LDS)
+                    if (!(FK_DBG_WHO))
+#endif
                     mfma_phase_mx<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();

@@ -48,8 +48,10 @@ __device__ __forceinline__ float expo1(float d)
     return __builtin_bit_cast(float, (uint32_t)((int32_t)__builtin_bit_cast(uint32_t, p) + (int32_t)n * (1 << 23)));
 }
 constexpr int LDS_BYTES = 80896;
-__global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t *hw, int a_mode, int b_mode, int iters)
+__global__ void __launch_bounds__(256, 2) probe(uint32_t *out, uint32_t *hw, int a_mode, int b_mode, int iters)
 {
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");               // the kernel owns all 256 registers: the second wave of a SIMD starts at 256
+
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const uint32_t wg = blockIdx.x, tix = threadIdx.x, lane = tix & 63;
     for (int i = tix; i < LDS_BYTES / 4; i += 256) reinterpret_cast<uint32_t *>(smem)[i] = 0x3c003c00u + i;
