@@ -341,6 +341,24 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_NOMFMA)         // ... or issue no MFMA (and read no LDS)
                     if (!(FK_DBG_WHO))
 #endif
+#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_VALUCVT)        // ... or convert K on the vector ALU: fp32 MFMAs only, none of the fp16 ones
+                    if (FK_DBG_WHO) mfma_phase<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, sh);
+                    else
+#endif
+#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_REGMFMA)        // ... or the same MFMAs on register operands: no LDS read in the matrix phase
+                    if (FK_DBG_WHO) {
+                        f32x16 z9;
+                        for (int i9 = 0; i9 < 16; ++i9) z9[i9] = 0.0f;
+                        for (int r9 = 0; r9 < 4; ++r9) {
+                            z9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pm0, pm1, z9, 0, 0, 0);
+                            z9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pm1, pm0, z9, 0, 0, 0);
+                        }
+                        for (int r9 = 0; r9 < 32; ++r9) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(z9[r9 & 15], 1.0f, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, z9[r9 & 15], acc1, 0, 0, 0);
+                        }
+                    } else
+#endif
                     mfma_phase_mx<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
