@@ -49,6 +49,9 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 // order {HW_ID, XCC_ID, unit, span}.  The pairing of workgroups that share a compute unit (see the kernel) rests on the dispatch order
 // of the GPU: tests/test_hip_parity.py reads this back and checks it on the machine it runs on.
 __device__ uint32_t g_placement[1024 * 4];
+#ifdef FK_DBG_DELAY
+__device__ int g_dbg_delay_ticks = 1500;                         // 100 MHz ticks per delay of the measurement builds (fastkv_debug_set_delay)
+#endif
 constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the nblk partial records
 
 // Hand-off records are 8-byte {token, 32-bit value} granules, written by ONE write-through (sc1) store each: the data is
@@ -345,6 +348,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     if (FK_DBG_WHO) mfma_phase<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, sh);
                     else
 #endif
+#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_CUT)            // ... or one of the cuts of mfma_phase_mx (mfma_tile.h)
+                    if (FK_DBG_WHO) mfma_phase_mx<NB, FK_DBG_MATE_CUT>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
+                    else
+#endif
 #if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_REGMFMA)        // ... or the same MFMAs on register operands: no LDS read in the matrix phase
                     if (FK_DBG_WHO) {
                         f32x16 z9;
@@ -367,7 +374,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                 FKF_STAMP(17 + 2 * (t % 2));
 #if defined(FK_DBG_DELAY) && FK_DBG_DELAY < 8
                 if (FK_DBG_WHO) {                                // debug: some workgroups are slow in phase A (no NaN involved)
-                    const uint64_t t_end = wall_clock64() + 1500;     // 100 MHz ticks: 15 us per tile
+                    const uint64_t t_end = wall_clock64() + g_dbg_delay_ticks;     // 100 MHz ticks: 15 us per tile unless set otherwise
 #if FK_DBG_DELAY == 6
                     // every workgroup, but only SOME of its waves (a hash of workgroup, wave and tile picks them): the waves of a workgroup
                     // reach the end of phase A far apart -- does the kernel depend on its waves running in step?
@@ -1208,6 +1215,12 @@ extern "C" int fastkv_debug_fused_placement(int enable, unsigned int *host, size
     if (n_words > 1024 * 4) return FASTKV_EINVAL;
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::g_placement), n_words * sizeof(unsigned int)) == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
+#ifdef FK_DBG_DELAY
+extern "C" int fastkv_debug_set_delay(int ticks)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_delay_ticks), &ticks, sizeof(int)) == hipSuccess ? 0 : -3;
+}
+#endif
 namespace fk {
 #ifdef FK_STAMP
 }  // namespace fk

@@ -139,7 +139,10 @@ __device__ __forceinline__ void perm_operands(int lane, f16x8 &p0, f16x8 &p1)
         p1[e] = (_Float16)(delta == 16 + 8 * h + e ? 1.0f : 0.0f);
     }
 }
-template <int NB = 2>
+// (CUT: measurement builds of the hunt in DESIGN.md section 8 -- 0 the kernel's phase; 1 the fp16 MFMAs take their K operand from
+// registers instead of LDS; 2 the fp32 MFMAs take a constant B operand instead of the fp16 MFMAs' results; 3 the fp32 MFMAs take their A
+// operand from registers instead of LDS; 4 the kernel's phase with the fp16 MFMAs' results copied by v_mov_b32 before the fp32 MFMAs read them.  Results are garbage for CUT != 0: only the delayed workgroups run those.)
+template <int NB = 2, int CUT = 0>
 __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const unsigned char *my, const float *Ap, int n31, int hi,
                                               f16x8 p0, f16x8 p1)
 {
@@ -148,9 +151,14 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
     for (int i = 0; i < 16; ++i) z[i] = 0.0f;
     auto conv = [&](int blk, int ch) {
         const unsigned char *rowp = my + (blk * 32 + n31) * ROWB + ch * 64 + hi * 16;
-        const f16x8 s0 = *reinterpret_cast<const f16x8 *>(rowp), s1 = *reinterpret_cast<const f16x8 *>(rowp + 32);
+        const f16x8 s0 = CUT == 1 ? p1 : *reinterpret_cast<const f16x8 *>(rowp), s1 = CUT == 1 ? p0 : *reinterpret_cast<const f16x8 *>(rowp + 32);
         f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, s0, z, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, s1, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, s1, d, 0, 0, 0);
+        if (CUT == 4) {                                          // the fp32 MFMAs read copies made by the vector ALU, not the matrix pipe's own result registers
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { float o; asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(d[i])); d[i] = o; }
+        }
+        return d;
     };
     f32x16 b0 = conv(0, 0), b1 = NB == 2 ? conv(1, 0) : z;
 #pragma unroll
@@ -158,13 +166,14 @@ __device__ __forceinline__ void mfma_phase_mx(f32x16 &acc0, f32x16 &acc1, const 
         f32x16 n0 = b0, n1 = b1;
         float av[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) av[i] = Ap[(ch * 16 + i) * 64];
+        for (int i = 0; i < 16; ++i) av[i] = CUT == 3 ? (float)(n31 + i) : Ap[(ch * 16 + i) * 64];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], acc0, 0, 0, 0);
-            if (NB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], CUT == 2 ? 1.0f : b0[i], acc0, 0, 0, 0);
+            if (NB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], CUT == 2 ? 2.0f : b1[i], acc1, 0, 0, 0);
             if (ch == 0 && i == 7) { n0 = conv(0, 1); if (NB == 2) n1 = conv(1, 1); }
         }
+        if (CUT == 2) { acc0[0] += b0[0] * 1e-30f + b1[0] * 1e-30f; }
         b0 = n0; b1 = n1;
     }
 }

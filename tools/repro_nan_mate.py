@@ -22,6 +22,9 @@ if kind == "KALL": k[0, 0, :, 17] = float("nan")
 want = O.update_kv(q, k, v, W, ks, "avgpool", cap, tsp_len, "index", return_scores=True)
 qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
 wsc = want[4].view(torch.int16)
+if os.environ.get("DELAY_TICKS"):                        # measurement builds with -DFK_DBG_DELAY: the length of a delay in 100 MHz ticks
+    from fastkv_amd._lib import load
+    assert load().fastkv_debug_set_delay(int(os.environ["DELAY_TICKS"])) == 0
 nbad = 0
 for it in range(N):
     got = ops.update_kv(qd, kd, vd, W, ks, "avgpool", cap, tsp_len, "index", return_indices=True, return_scores=True)
