@@ -466,6 +466,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // (returns false when the launch is abandoned: every thread of the workgroup leaves)
     auto read_max = [&](auto sc) -> bool {
         constexpr int s = decltype(sc)::value;
+#if defined(FK_DBG_DELAY) && defined(FK_DBG_VICTIM_WAIT)          // hunt: everybody ELSE sits out 150 us between phase A and the first hand-off
+        if (!(FK_DBG_WHO)) { const uint64_t t_end = wall_clock64() + 15000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
+#endif
 #if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 9
         if (FK_DBG_WHO) { const uint64_t t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
 #endif
