@@ -18,7 +18,7 @@ SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "sp.hip", "dec
 HEADERS = ["fk_device.h", "fk_host.h", "prof.h", "rank.h", "mfma_tile.h", os.path.join("..", "..", "include", "fastkv_hip.h")]
 # -ffp-contract=off: the arithmetic contract (csrc/fk_device.h) spells every fma out; nothing may be fused or split
 # `-target-feature -packed-fp32-ops`: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code (the same IEEE operations per
-# component, issued one by one: no measurable cost, the kernels are not bound by them).  Why: a workgroup of the fused scoring kernel that
+# component, issued one by one: +1.4 us on the 77.5 us two-layer scoring launch in the trace, inside the noise of the step).  Why: a workgroup of the fused scoring kernel that
 # ran its packed-fp32 phases beside a partner's matrix phase on one compute unit computed wrong values now and then; without the packed
 # instructions the strongest reproducer of that goes from 40 % wrong launches to 0 of 600.  The host half of the
 # compilation does not know the feature and says so ("not a recognized feature for this target (ignoring feature)"): harmless.
