@@ -106,3 +106,16 @@ def test_cpu_tensors_are_rejected_not_emulated():
     q = torch.zeros(1, 4, 600, 128, dtype=torch.float16)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.update_kv(q, k, k, 8, 7, "avgpool", 64)
+
+
+def test_library_is_built_without_packed_fp32_instructions():
+    """Round 3: packed-fp32 vector instructions of one workgroup beside another workgroup's matrix phase on a
+    compute unit produced wrong values now and then; the library is therefore compiled with `-target-feature -packed-fp32-ops`.
+    The flag must stay in the build, and the objects of the shipped library must have been compiled with it."""
+    import os
+    from fastkv_amd import _build
+    flags = " ".join(_build.HIPCC_FLAGS)
+    assert "-target-feature -Xclang -packed-fp32-ops" in flags
+    stamps = [f for f in os.listdir(_build.OBJDIR) if f.endswith(".flags")] if os.path.isdir(_build.OBJDIR) else []
+    for f in stamps:
+        assert "-packed-fp32-ops" in open(os.path.join(_build.OBJDIR, f)).read(), f
