@@ -8,9 +8,10 @@ peak memory report (`:132-146`) and the appended txt line (`:148-176`).
 Differences forced by the environment: there is no network and no checkpoint on the GPU box, so `--model_path` may
 be a geometry name ("llama3-8b", "mistral-7b", "llama3-70b-tp8-rank", "tiny") and the model is random-initialised from
 the config; `--context_lengths` overrides the 8192/32768/131072 loop; attention runs through PyTorch-ROCm SDPA
-(`flash_attn` is not installed); on a machine without a GPU the harness still runs (config 1, CPU plumbing) with
-`--device cpu`, using wall-clock timing and the CPU oracle as the cluster (the reference cannot: it needs
-`torch.cuda.Event`)."""
+(`flash_attn` is not installed).  `--device cpu` (config 1, CPU plumbing; the reference cannot run there at all: it needs
+`torch.cuda.Event`) times with the wall clock and works as it stands for `--method fullkv`; `--method fastkv` on the CPU
+RAISES by design -- the product cluster has no CPU fallback -- unless the caller injects a cluster (`args.cluster_factory`,
+which is what tests/test_wiring.py does with the oracle's cluster)."""
 from __future__ import annotations
 
 import argparse
