@@ -335,7 +335,9 @@ def make_model_forward(modeling, mask_fn_for):
         position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
         # Prefill: layers whose compressed cache is not needed while the prompt is in flight (all but the TSP layer) are compressed
         # together with their peers -- the <= 4096-token layers behind the TSP layer after the last layer, the long ones in front of
-        # it in pairs (fastkv_amd.cluster.DeferredCompression; FASTKV_DEFER=0: layer by layer as the reference)
+        # it in groups of up to FASTKV_DEFER_HOLD (default 8: up to seven more layers' q / k / v alive, 0.4 GB each per batch row at
+        # 32k; size it down for long prompts x big batches) (fastkv_amd.cluster.DeferredCompression; FASTKV_DEFER=0: layer by layer
+        # as the reference)
         defer = None
         if sp is None and (type(past_key_values) is DynamicCache or isinstance(past_key_values, FastKVSlabCache)) \
                 and inputs_embeds.shape[1] > 1 and inputs_embeds.is_cuda \

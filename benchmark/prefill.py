@@ -58,7 +58,9 @@ def build_model(args, device):
                   num_key_value_heads=kvh, intermediate_size=inter, vocab_size=vocab, head_dim=128 if hidden >= 1024 else 32,
                   max_position_embeddings=max(args.context_lengths) + 64, rope_theta=500000.0, use_cache=args.use_cache)
         if mtype == "mistral":
-            kw["sliding_window"] = None
+            # v0.2+ checkpoints ship `sliding_window: null`; v0.1's 4096 reaches the mask builder and the attention call
+            # (/root/reference/baselines/fastkv/mistral_model.py:143-153) through `--sliding_window`
+            kw["sliding_window"] = getattr(args, "sliding_window", None) or None
         cfg = Cfg(**kw)
         cfg._attn_implementation = args.attn_implementation
         with torch.device(device):
@@ -181,6 +183,8 @@ def parse_args(argv=None):
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--num_layers", type=int, default=0, help="override the depth of a geometry (0 = as published)")
     p.add_argument("--random_tokens", action="store_true")
+    p.add_argument("--sliding_window", type=int, default=0, help="Mistral geometries: sliding-window attention of this many tokens "
+                                                               "(0 = none, as the v0.2+ checkpoints)")
     a = p.parse_args(argv)
     a.dtype = torch.float16 if a.device != "cpu" else torch.float32
     a.cluster_factory = None

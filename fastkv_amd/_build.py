@@ -76,6 +76,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if not force and not needs_build():
                 return LIB
             extra = os.environ.get("FASTKV_CXXFLAGS", "").split()          # measurement builds only (e.g. -DFK_STAMP)
+            if extra and not os.environ.get("FASTKV_BUILD_DIR"):
+                # needs_build() knows nothing about these flags: an instrumented build in-tree would either silently stay the
+                # product's .so or silently replace it
+                raise RuntimeError("FASTKV_CXXFLAGS needs FASTKV_BUILD_DIR=<scratch directory>: measurement builds never go in-tree")
             if force:
                 for f in os.listdir(OBJDIR):
                     os.remove(os.path.join(OBJDIR, f))

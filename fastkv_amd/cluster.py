@@ -140,6 +140,8 @@ class DeferredCompression:
     @classmethod
     def _on_fused_path(cls, cluster, key_states, query_states) -> bool:
         """Batched entries exist on the fused scoring path only: asked from the library once per geometry (host only)."""
+        if ops.no_wait_mode():                                    # FASTKV_FUSED=0 or the fail-safe switch after a placement report
+            return False
         g = (query_states.shape[1], key_states.shape[1], key_states.shape[2], key_states.shape[3], cluster.window_size, cluster.kernel_size)
         ok = cls._fused_ok.get(g)
         if ok is None:
@@ -245,9 +247,18 @@ class DeferredCompression:
                 # launch of this process gave up a wait and ITS outputs are invalid; FASTKV_ELAUNCH) is an error of the run, not a
                 # property of the geometry: the pending entries go back so that a caller who handles the error can flush again,
                 # `_max_entries` is left alone, and the error is raised.
-                if e.code != FASTKV_EUNSUPPORTED or n == 1:
+                if e.code != FASTKV_EUNSUPPORTED:
                     self.groups.setdefault(key, [])[:0] = its[pos:]
                     raise
+                if n == 1 or getattr(e, "layout", False):
+                    # the pointer-table path does not take this entry / these tensors (a view whose address or batch stride is not
+                    # 16-byte aligned, outputs of another stride pattern, the no-wait mode since the group was queued): nothing was
+                    # launched -- one by one through the strided entry point, and nothing is remembered about the GEOMETRY
+                    for i in chunk:
+                        o = ops.update_kv(i[1], i[2], i[3], window, ksize, pooling, cap, 0, order, out=i[4], q_window=self.q_window)
+                        done.append((i[0], o[0], o[1]))
+                    pos += n
+                    continue
                 self._max_entries[key] = n // 2 if n > 3 else n - 1
                 continue
             done += [(i[0], ko, vo) for i, ko, vo in zip(chunk, k_outs, v_outs)]

@@ -3,6 +3,7 @@
 // No allocation, no synchronisation, no exceptions; everything goes on the caller's stream.
 #include "fk_host.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -38,6 +39,23 @@ uint64_t spin_limit_ticks()
     }();
     return ticks;
 }
+static std::atomic<uint32_t> g_violations_reported{0};       // violations already turned into a report (word 3 was cleared)
+std::atomic<int> &no_wait_flag()
+{
+    static std::atomic<int> f{0};
+    return f;
+}
+static std::atomic<int> &placement_policy()
+{
+    static std::atomic<int> pol{[]() { const char *e = getenv("FASTKV_STRICT_PLACEMENT"); return !e ? 2 : e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2; }()};
+    return pol;
+}
+// FASTKV_FUSED=0, or the fail-safe switch after a placement violation: no kernel with an in-launch wait is launched any more
+bool no_wait_mode()
+{
+    static const bool env_off = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    return env_off || no_wait_flag().load(std::memory_order_acquire) != 0;
+}
 static int take_abort_status()
 {
     if (!g_abort_host) return FASTKV_OK;
@@ -47,9 +65,20 @@ static int take_abort_status()
     // word 2 (FASTKV_DEBUG_BOUNDS=1 only): a gather was handed an index outside [0, S) (compact.hip)
     if (__atomic_load_n(g_abort_host + 2, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 2, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EBOUNDS;
     // word 3: workgroups of a fused scoring launch that met a workgroup of ANOTHER unit on their compute unit (fused.hip: placement
-    // check).  A count, not an error -- unless FASTKV_STRICT_PLACEMENT=1 asks for one
-    static const bool strict = []() { const char *e = getenv("FASTKV_STRICT_PLACEMENT"); return e && e[0] == '1'; }();
-    if (strict && __atomic_load_n(g_abort_host + 3, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 3, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EPLACEMENT;
+    // check).  Policy (fastkv_set_placement_policy; FASTKV_STRICT_PLACEMENT at load):
+    //   2 (default, "fail safe"): the launches that counted cannot vouch for their pairing -- report FASTKV_EPLACEMENT once (the caller
+    //      redoes the affected calls) AND put the process into the no-wait mode (staged scoring, wait-free selection: no fused launch
+    //      is ever exposed again), so that the redo is safe whatever else runs on the GPU;
+    //   1 ("strict"): report FASTKV_EPLACEMENT, change nothing;   0: count only (fastkv_placement_violations), report nothing.
+    const int policy = placement_policy().load(std::memory_order_relaxed);
+    if (policy != 0 && __atomic_load_n(g_abort_host + 3, __ATOMIC_ACQUIRE) != 0u) {
+        const uint32_t n = __atomic_exchange_n(g_abort_host + 3, 0u, __ATOMIC_ACQ_REL);
+        if (n) {
+            g_violations_reported.fetch_add(n, std::memory_order_relaxed);
+            if (policy == 2) no_wait_flag().store(1, std::memory_order_release);
+            return FASTKV_EPLACEMENT;
+        }
+    }
     return FASTKV_OK;
 }
 }  // namespace fk
@@ -58,9 +87,26 @@ extern "C" int fastkv_placement_violations(int reset)
 {
     (void)fk::abort_flag_device();
     if (!fk::g_abort_host) return 0;
-    const uint32_t v = reset ? __atomic_exchange_n(fk::g_abort_host + 3, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(fk::g_abort_host + 3, __ATOMIC_ACQUIRE);
+    // pending (counted by launches, not yet reported) + already reported
+    uint64_t v = reset ? __atomic_exchange_n(fk::g_abort_host + 3, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(fk::g_abort_host + 3, __ATOMIC_ACQUIRE);
+    v += reset ? fk::g_violations_reported.exchange(0, std::memory_order_relaxed) : fk::g_violations_reported.load(std::memory_order_relaxed);
     return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
 }
+
+extern "C" int fastkv_set_placement_policy(int policy)
+{
+    if (policy < 0 || policy > 2) return FASTKV_EINVAL;
+    fk::placement_policy().store(policy, std::memory_order_relaxed);
+    return FASTKV_OK;
+}
+
+extern "C" int fastkv_set_no_wait_mode(int on)
+{
+    const int was = fk::no_wait_flag().exchange(on ? 1 : 0, std::memory_order_acq_rel);
+    return was;
+}
+
+extern "C" int fastkv_no_wait_mode(void) { return fk::no_wait_mode() ? 1 : 0; }
 
 namespace {
 
@@ -475,8 +521,10 @@ const char *fastkv_strerror(int code)
     case FASTKV_EBOUNDS:
         return "index-bounds debug mode (FASTKV_DEBUG_BOUNDS=1): an earlier gather was handed a row index outside [0, S) (it read a clamped row)";
     case FASTKV_EPLACEMENT:
-        return "FASTKV_STRICT_PLACEMENT=1: workgroups of an earlier fused scoring launch shared a compute unit with workgroups of another "
-               "unit (foreign kernels on the GPU, or a launch that was not resident all at once): see fastkv_placement_violations()";
+        return "workgroups of an earlier fused scoring launch shared a compute unit with workgroups of another unit (foreign kernels on "
+               "the GPU, or a launch that was not resident all at once): the pairing that keeps co-resident workgroups in step cannot be "
+               "vouched for -- redo the calls since the last report; under the default policy the process now runs the no-wait kernels "
+               "(as FASTKV_FUSED=0), see fastkv_set_placement_policy()";
     case FASTKV_EUNSUPPORTED: return "unsupported configuration (head_dim must be 64/128/256, S < 2^24)";
     default: return "unknown error";
     }

@@ -91,6 +91,7 @@ static inline Layout make_layout(const fastkv_problem &p)
 // the allocation failed: the launchers then take the staged path) and the wall-clock limit in s_memrealtime ticks
 uint32_t *abort_flag_device();
 uint64_t spin_limit_ticks();
+bool no_wait_mode();              // FASTKV_FUSED=0 or the fail-safe switch after a placement violation (capi.hip)
 
 // launchers (defined in score.hip / select.hip / compact.hip); all return hipError_t of the launch
 hipError_t launch_score(const fastkv_problem &p, const Layout &L, const void *q, const int64_t *qs, const void *k,

@@ -1074,7 +1074,7 @@ static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn,
 // fused path.  What a caller that batches entries itself wants to know up front (fastkv_amd.cluster.DeferredCompression).
 int fused_entries_per_launch(const fastkv_problem &p)
 {
-    static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    const bool disabled = no_wait_mode();
     static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
     const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4;
     const bool engine_ok = G < 4 ? (p.reserved & 3) != ENGINE_VALU : (p.reserved & 3) != ENGINE_VALU && G * p.window >= 24;
@@ -1090,7 +1090,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                         const int64_t *ks, uint16_t *c_out, int64_t c_row_stride, int64_t *all_idx, uint16_t *all_keys,
                         int64_t all_key_stride, char *ws, hipStream_t st, hipError_t *err, const PtrTables *pt)
 {
-    static const bool disabled = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    const bool disabled = no_wait_mode();
     // FASTKV_FUSED_STREAMS=2: the two-heads-per-workgroup experiment (measured slower, see the kernel's comment); default 1
     static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
     // virtual heads of 4 query heads per KV head; a group of 1-3 query heads (MHA, G = 2 models, the per-query-head rule's

@@ -554,7 +554,7 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
     // FASTKV_FUSED=0 is the library's "no in-launch waits" mode (processes sharing a GPU, include/fastkv_hip.h): the selection
     // then counts the row in every chunk instead of exchanging counters -- measured 18.4 us against 11.0 us per launch at 32k
     // (64 KiB of row per workgroup instead of one hand-off), which is why it is not the default
-    static const bool no_waits = []() { const char *e = getenv("FASTKV_FUSED"); return e && e[0] == '0'; }();
+    const bool no_waits = no_wait_mode();
     const bool table_ok = hist12 && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec;
     if (table_ok && !no_waits) {
         ProfScope ps_(K_SELECT_SPLIT, st);

@@ -50,6 +50,26 @@ def _workspace(nbytes: int, device: torch.device, kind: str = "op") -> torch.Ten
     return ws
 
 
+PLACEMENT_POLICY = {"count": 0, "strict": 1, "failsafe": 2}
+
+
+def set_placement_policy(name: str) -> None:
+    """What a fused scoring launch that did not get its compute-unit pairing leads to (include/fastkv_hip.h,
+    fastkv_set_placement_policy): "failsafe" (default) = FASTKV_EPLACEMENT once + the process switches to the no-wait kernels;
+    "strict" = the error only; "count" = `fastkv_placement_violations()` only."""
+    check(load().fastkv_set_placement_policy(PLACEMENT_POLICY[name]), "set_placement_policy")
+
+
+def no_wait_mode() -> bool:
+    """True when the library launches no kernel with an in-launch wait (FASTKV_FUSED=0, or the fail-safe switch)."""
+    return bool(load().fastkv_no_wait_mode())
+
+
+def set_no_wait_mode(on: bool) -> bool:
+    """Force / leave the no-wait mode at run time; returns the previous setting of the switch."""
+    return bool(load().fastkv_set_no_wait_mode(1 if on else 0))
+
+
 ENGINE = {"auto": 0, "valu": 1, "mfma": 2}
 _engine = ENGINE[os.environ.get("FASTKV_SCORE_ENGINE", "auto")]
 
@@ -83,15 +103,29 @@ def _check_qkv(q, k, v=None):
 
 def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, kernel_size: int, pooling: str,
               capacity: int, tsp_len: int = 0, order: str = "score", return_indices: bool = False,
-              return_scores: bool = False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+              return_scores: bool = False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, q_window: bool = False):
     """Compress branch of FastKVCluster.update_kv (utils.py:93-132) in one stream-ordered call.
 
     Returns (k_out [B,Hkv,cap,D], v_out, tsp_idx [B,tsp_len] int64 | None[, kv_idx][, scores]).
     `out` = (k_buf, v_buf): write the compacted rows into these [B,Hkv,cap,D] fp16 views instead of fresh tensors (unit
-    head_dim stride, other strides multiples of 8 -- e.g. `slab[:, :, :cap]` of a pre-sized cache slab)."""
-    _check_qkv(q, k, v)
+    head_dim stride, other strides multiples of 8 -- e.g. `slab[:, :, :cap]` of a pre-sized cache slab).
+    `q_window`: q is `window_rows(q, window)` ([B,H,window,D] contiguous, the only query rows the operator reads); the library is
+    handed an address `S - window` rows in front of it."""
+    q_ptr = q.data_ptr()
+    if q_window:
+        if q.dim() != 4 or q.shape[2] != window or not q.is_contiguous() or q.dtype != torch.float16:
+            raise ValueError("fastkv_amd.update_kv(q_window=True): a [B,H,window,D] contiguous fp16 copy of the window rows expected")
+        _check_qkv(k, k, v)
+        _require_cuda(q)
+        if pooling not in POOLING:
+            raise ValueError("Pooling method not supported")
+        p = Problem(B=q.shape[0], H=q.shape[1], Hkv=k.shape[1], S=k.shape[2], D=q.shape[3], window=window, kernel=kernel_size,
+                    pooling=POOLING[pooling], capacity=capacity, tsp_len=tsp_len, order=ORDER[order], reserved=_engine)
+        q_ptr -= (k.shape[2] - window) * q.stride(2) * 2          # row S - window + r of "the query tensor" = row r of the copy
+    else:
+        _check_qkv(q, k, v)
+        p = _problem(q, k, window, kernel_size, pooling, capacity, tsp_len, order)
     L = load()
-    p = _problem(q, k, window, kernel_size, pooling, capacity, tsp_len, order)
     B, Hkv, D = p.B, p.Hkv, p.D
     dev = q.device
     if out is None:
@@ -114,7 +148,7 @@ def update_kv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, window: int, ke
     if nbytes == 0:
         check(-1, "workspace_bytes")
     ws = _workspace(nbytes, dev)
-    rc = L.fastkv_update_kv_strided_f16(ctypes.byref(p), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), v.data_ptr(),
+    rc = L.fastkv_update_kv_strided_f16(ctypes.byref(p), q_ptr, _strides(q), k.data_ptr(), _strides(k), v.data_ptr(),
                                 _strides(v), ko.data_ptr(), vo.data_ptr(), ostr,
                                 kv_idx.data_ptr() if kv_idx is not None else None,
                                 tsp.data_ptr() if tsp is not None else None,
@@ -504,7 +538,9 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
         # entries that do not share one geometry / layout / alignment cannot go through one launch sequence: the caller runs them
         # one by one (the only condition besides the library's own FASTKV_EUNSUPPORTED that DeferredCompression falls back on)
         if not ok:
-            raise FastKVNativeError(f"fastkv_amd.update_kv_entries: entries differ in {what}", code=FASTKV_EUNSUPPORTED)
+            e = FastKVNativeError(f"fastkv_amd.update_kv_entries: entries differ in {what}", code=FASTKV_EUNSUPPORTED)
+            e.layout = True                                       # a property of THESE tensors, not of the geometry (DeferredCompression)
+            raise e
 
     for q, k, v in zip(qs, ks, vs):
         same_layout(q.shape == q0.shape and k.shape == k0.shape and v.shape == v0.shape, "shape")

@@ -37,8 +37,9 @@ extern "C" {
 #define FASTKV_EOVERFLOW (-6)  /* an EARLIER static-decode step found its cache slab full (reported like FASTKV_EABORTED) */
 #define FASTKV_EBOUNDS (-7)    /* FASTKV_DEBUG_BOUNDS=1 only: an EARLIER gather was handed a row index outside [0, S) (it read a
                                   clamped row, as always; reported like FASTKV_EABORTED) */
-#define FASTKV_EPLACEMENT (-8) /* FASTKV_STRICT_PLACEMENT=1 only: workgroups of an EARLIER fused scoring launch shared a compute unit
-                                  with workgroups of another unit (see fastkv_placement_violations; reported like FASTKV_EABORTED) */
+#define FASTKV_EPLACEMENT (-8) /* workgroups of an EARLIER fused scoring launch shared a compute unit with workgroups of another unit:
+                                  redo the calls since the last report (see fastkv_set_placement_policy; reported like
+                                  FASTKV_EABORTED) */
 
 #define FASTKV_POOL_AVG 0 /* F.avg_pool1d(k, padding=k//2, stride=1)   utils.py:105-106 */
 #define FASTKV_POOL_MAX 1 /* F.max_pool1d(k, padding=k//2, stride=1)   utils.py:107-108 */
@@ -111,9 +112,23 @@ int fastkv_last_status(void);
  * is counted in pinned host memory.  Returns the count since the last reset (host only, no synchronisation; complete once the
  * stream has been synchronised).  0 on an idle GPU (the tests assert it); > 0 beside foreign kernels, or when a launch could not
  * become resident all at once -- results were bit-exact in every such test, but the guarantee of the pairing is gone: a shared GPU
- * should run FASTKV_FUSED=0.  FASTKV_STRICT_PLACEMENT=1 turns a non-zero count into FASTKV_EPLACEMENT at the next call.
+ * should run FASTKV_FUSED=0.  The count is a running total (reported violations included) until `reset`.
  */
 int fastkv_placement_violations(int reset);
+/*
+ * What a counted violation leads to (process-wide; initial value from FASTKV_STRICT_PLACEMENT: unset -> 2, "1" -> 1, "0" -> 0):
+ *   2  fail safe (default): the next operator call / fastkv_last_status() returns FASTKV_EPLACEMENT once -- the outputs of the calls
+ *      since the last report are not vouched for, redo them -- AND the process switches to the no-wait kernels (staged scoring,
+ *      wait-free selection: what FASTKV_FUSED=0 selects), so that the redo, and everything after it, has no exposure left;
+ *   1  strict: the report only, the fused kernels stay;
+ *   0  count only.
+ * Returns 0, FASTKV_EINVAL for another value.
+ */
+int fastkv_set_placement_policy(int policy);
+/* The no-wait switch itself: fastkv_set_no_wait_mode(on) returns the previous setting (FASTKV_FUSED=0 cannot be undone by it);
+ * fastkv_no_wait_mode() = 1 when no kernel with an in-launch wait will be launched (the environment variable or the switch). */
+int fastkv_set_no_wait_mode(int on);
+int fastkv_no_wait_mode(void);
 
 /*
  * The whole operator: replaces the compress branch of FastKVCluster.update_kv (utils.py:93-132).

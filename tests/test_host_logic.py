@@ -119,3 +119,27 @@ def test_library_is_built_without_packed_fp32_instructions():
     stamps = [f for f in os.listdir(_build.OBJDIR) if f.endswith(".flags")] if os.path.isdir(_build.OBJDIR) else []
     for f in stamps:
         assert "-packed-fp32-ops" in open(os.path.join(_build.OBJDIR, f)).read(), f
+
+
+def test_shipped_code_object_holds_no_packed_fp32_arithmetic(tmp_path):
+    """the flag check above trusts strings; this one reads the gfx950 code objects of the library that will be loaded
+    (llvm-objdump --offloading -> disassembly, in a scratch directory): not one v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, and the
+    matrix instructions of the scoring kernels are there (so the disassembly really saw the kernels)."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from fastkv_amd import _build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    lib = _build.build()
+    local = shutil.copy(lib, str(tmp_path / "lib.so"))
+    subprocess.run([objdump, "--offloading", local], cwd=str(tmp_path), check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]
+    assert objs, os.listdir(tmp_path)
+    asm = "".join(subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+                  for f in objs)
+    assert len(re.findall(r"v_mfma_f32_32x32x2_f32", asm)) > 1000 and "v_mfma_f32_32x32x16_f16" in asm
+    packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
+    assert not packed, f"{len(packed)} packed-fp32 instructions in the shipped code object"

@@ -130,6 +130,71 @@ def test_mistral_patch_runs():
     assert out.logits.shape == (1, 1, 500)
 
 
+@pytest.mark.parametrize("tsp", [False, True])
+def test_mistral_sliding_window_prefill_matches_the_stock_sliding_window_attention(tsp):
+    """A Mistral config WITH `sliding_window` (v0.1): the reference hands the window to the flash-attention call of the prefill
+    (/root/reference/baselines/fastkv/mistral_model.py:143-153); here it reaches the mask builder and the attention interface.
+    Prompt longer than the window, budgets that compress every layer's cache:
+      * no TSP (tsp_len >= prompt): the logits equal those of the STOCK MistralForCausalLM (unpatched classes, eager sliding-window
+        attention) on the same weights -- compression only changes what is cached;
+      * TSP at layer 0: the layers behind it attend causally + windowed over the surviving TOKENS; cache rows of every layer
+        equal the oracle cluster's on the captured q / k / v (the wiring hands the operator un-windowed K/V: the window is the
+        attention's business, utils.py:93-132 never sees it)."""
+    from baselines.monkeypatch import replace_mistral, set_model
+    from transformers import MistralConfig, MistralForCausalLM
+    S, win = 200, 48
+    cfg = MistralConfig(hidden_size=128, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, intermediate_size=256,
+                        vocab_size=500, head_dim=32, sliding_window=win, max_position_embeddings=512)
+    ids = torch.randint(0, 500, (1, S), generator=torch.Generator().manual_seed(29))
+    a = types.SimpleNamespace(method="fastkv", window_size=8, kernel_size=5, pooling="avgpool", max_capacity_prompts=32,
+                              tsp_len=100 if tsp else 4096, tsp_rate=0.2, eviction_mode="constant", tsp_idx=0, retain_rate=0.1)
+    replace_mistral("fastkv")
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(31)
+    model = MistralForCausalLM(cfg).eval()
+    assert type(model.model.layers[0].self_attn).__name__ == "MistralFastKVAttention"
+    set_model(model, a)
+    captured = []
+    for layer in model.model.layers:
+        cl = layer.self_attn.kv_cluster = _oracle_cluster(layer.self_attn.kv_cluster)
+        orig = cl.update_kv
+
+        def spy(k, q, v, m, g, li, _orig=orig):
+            out = _orig(k, q, v, m, g, li)
+            captured.append((li, k.shape[2], out))
+            return out
+
+        cl.update_kv = spy
+    with torch.no_grad():
+        out = model(ids, attention_mask=torch.ones_like(ids))
+    assert [c[1] for c in captured] == ([S, 100, 100] if tsp else [S, S, S])
+    for li, _, (kc, vc, t) in captured:
+        # (transformers' sliding-window cache layer keeps the LAST window - 1 rows of what `update` was handed)
+        have = out.past_key_values.layers[li].keys
+        assert have.shape[-2] == min(32, win - 1) and torch.equal(have, kc[:, :, -have.shape[-2]:])
+    if tsp:
+        assert captured[0][2][2].shape == (1, 100) and torch.isfinite(out.logits).all()
+        return
+    replace_mistral("fullkv")
+    try:
+        cfg2 = MistralConfig(**{**cfg.to_dict(), "sliding_window": win})
+        cfg2._attn_implementation = "eager"
+        stock = MistralForCausalLM(cfg2).eval()
+        assert type(stock.model.layers[0].self_attn).__name__ == "MistralAttention"
+        stock.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            want = stock(ids, attention_mask=torch.ones_like(ids)).logits[:, -1:]
+            cfg3 = MistralConfig(**{**cfg.to_dict(), "sliding_window": None})
+            cfg3._attn_implementation = "eager"
+            nowin = MistralForCausalLM(cfg3).eval()
+            nowin.load_state_dict(model.state_dict())
+            other = nowin(ids, attention_mask=torch.ones_like(ids)).logits[:, -1:]
+    finally:
+        replace_mistral("fastkv")
+    assert torch.allclose(out.logits, want, atol=2e-4, rtol=1e-4), float((out.logits - want).abs().max())
+    assert not torch.allclose(other, want, atol=2e-3)                # (the window matters at this length: the test would see it missing)
+
+
 def test_unsupported_methods_are_refused():
     from baselines.monkeypatch import replace_llama
     with pytest.raises(NotImplementedError):

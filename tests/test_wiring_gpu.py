@@ -249,7 +249,7 @@ def test_abandoned_deferred_pair_is_raised(mode):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FASTKV_SPIN_LIMIT_MS="30", FASTKV_DEFER_MAX_LEN="1024", FASTKV_DEFER_HOLD="2",
+    env = dict(os.environ, FASTKV_SPIN_LIMIT_MS="30", FASTKV_DEFER_MAX_LEN="1024", FASTKV_DEFER_HOLD="2", FASTKV_STRICT_PLACEMENT="0",
                FASTKV_CHECK_SYNC="1" if mode == "sync" else "0")
     r = subprocess.run([sys.executable, "-c", f"MODE = {mode!r}\n" + _ABORT_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]

@@ -1,4 +1,4 @@
-"""Measurement build only (FASTKV_CXXFLAGS=-DFK_STAMP python fastkv_amd/_build.py): per-wave stage cycles of score_logits_mfma."""
+"""Measurement build only (FASTKV_BUILD_DIR=build_x_stamp FASTKV_CXXFLAGS=-DFK_STAMP python fastkv_amd/_build.py): per-wave stage cycles of score_logits_mfma."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
