@@ -50,6 +50,12 @@ static std::atomic<int> &placement_policy()
     static std::atomic<int> pol{[]() { const char *e = getenv("FASTKV_STRICT_PLACEMENT"); return !e ? 2 : e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2; }()};
     return pol;
 }
+// the contract AUTO resolves to: FASTKV_CONTRACTION=fmaf selects the fp32 fma chain, anything else the fp16 matrix instruction
+bool default_contract_f16()
+{
+    static const bool f16 = []() { const char *e = getenv("FASTKV_CONTRACTION"); return !(e && (e[0] == 'f' || e[0] == 'F')); }();
+    return f16;
+}
 // FASTKV_FUSED=0, or the fail-safe switch after a placement violation: no kernel with an in-launch wait is launched any more
 bool no_wait_mode()
 {
@@ -117,7 +123,7 @@ int check_problem(const fastkv_problem *p)
     if (p->D != 64 && p->D != 128 && p->D != 256) return FASTKV_EUNSUPPORTED;
     if (p->window < 1 || p->window > 64 || p->S <= p->window) return FASTKV_EINVAL;
     if ((p->H / p->Hkv) * p->window > 1024) return FASTKV_EUNSUPPORTED;
-    if ((p->reserved & 3) == 3 || (p->reserved & ~3)) return FASTKV_EINVAL;
+    if (p->reserved & ~3) return FASTKV_EINVAL;
     if (p->kernel < 1 || (p->kernel & 1) == 0 || p->kernel > 63) return FASTKV_EINVAL;   // even kernels break the reference's view() too
     if (p->pooling != FASTKV_POOL_AVG && p->pooling != FASTKV_POOL_MAX) return FASTKV_EINVAL;
     if ((int64_t)p->S >= (1ll << 24)) return FASTKV_EUNSUPPORTED;                          // fixed-point softmax sum headroom

@@ -36,6 +36,26 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
     out[i] = r;
     if (out64) out64[i] = r64;
 }
+// Test hook of the "mfma16" contract: the raw v_mfma_f32_32x32x16_f16 on caller-supplied tiles, so that tests can hold the oracle's
+// restatement of the instruction (oracle/fastkv_oracle.c mfma16_block) against the chip they run on.  One wave per tile: A [32][dd],
+// Bt [32][dd] fp16 row-major (lane l holds d = 16 c + 8 (l / 32) + j of chunk c, as the scoring kernels do), C [32][32] fp32 or null
+// (+0), out [32][32]: dd / 16 chained instructions.
+typedef _Float16 dbg_f16x8 __attribute__((ext_vector_type(8)));
+typedef float dbg_f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(64) debug_mfma16_kernel(const _Float16 *A, const _Float16 *Bt, const float *C, float *out, int dd)
+{
+    const size_t t = blockIdx.x;
+    A += t * 32 * dd; Bt += t * 32 * dd; out += t * 1024;
+    const int l = threadIdx.x, r = l & 31, h = l >> 5;
+    dbg_f32x16 acc;
+    for (int i = 0; i < 16; i++) { const int m = (i & 3) + 8 * (i >> 2) + 4 * h; acc[i] = C ? C[t * 1024 + m * 32 + r] : 0.0f; }
+    for (int c = 0; c < dd / 16; c++) {
+        dbg_f16x8 a, b;
+        for (int j = 0; j < 8; j++) { a[j] = A[r * dd + 16 * c + 8 * h + j]; b[j] = Bt[r * dd + 16 * c + 8 * h + j]; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+    for (int i = 0; i < 16; i++) { const int m = (i & 3) + 8 * (i >> 2) + 4 * h; out[m * 32 + r] = acc[i]; }
+}
 // Test hook: `wgs` workgroups that each hold `lds_bytes` of LDS and spin for `usec` microseconds of wall clock -- "another
 // kernel is holding compute units" for the residency tests.
 __global__ void __launch_bounds__(256) debug_occupy_kernel(uint64_t ticks, uint32_t *sink)
@@ -59,6 +79,14 @@ extern "C" int fastkv_debug_occupy(int wgs, int lds_bytes, int64_t usec, void *s
         attr = true;
     }
     hipLaunchKernelGGL(fk::debug_occupy_kernel, dim3(wgs), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (uint64_t)usec * 100u, sink);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+extern "C" int fastkv_debug_mfma16(const void *a, const void *bt, const float *c, float *out, int ntiles, int dd, void *stream)
+{
+    if (!a || !bt || !out || ntiles < 0 || dd < 16 || (dd & 15) || dd > 1024) return FASTKV_EINVAL;
+    if (!ntiles) return FASTKV_OK;
+    hipLaunchKernelGGL(fk::debug_mfma16_kernel, dim3(ntiles), dim3(64), 0, (hipStream_t)stream, (const _Float16 *)a, (const _Float16 *)bt, c, out, dd);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -19,7 +19,12 @@ constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that sc
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-enum { ENGINE_AUTO = 0, ENGINE_VALU = 1, ENGINE_MFMA = 2 };   // fastkv_problem.reserved bits 0-1
+// fastkv_problem.reserved bits 0-1.  Two arithmetic CONTRACTS for the contraction of utils.py:94 (oracle/fastkv_oracle.c, "the
+// contraction"): the fp32 fma chain -- engines VALU and MFMA (v_mfma_f32_32x32x2_f32), bit-identical to each other -- and "mfma16",
+// what v_mfma_f32_32x32x16_f16 computes on the fp16 operands themselves (16x the matrix rate).  AUTO = the library's default
+// contract (FASTKV_CONTRACTION=mfma16 | fmaf, default mfma16) with the engine that suits the shape.
+enum { ENGINE_AUTO = 0, ENGINE_VALU = 1, ENGINE_MFMA = 2, ENGINE_MFMA16 = 3 };
+bool default_contract_f16();      // capi.hip
 
 struct Layout {
     int engine;                      // contraction engine of score_logits (both are the oracle's fmaf chain)
@@ -46,15 +51,22 @@ struct PtrTables {
     const uint64_t *k_out, *v_out;
 };
 
+static inline int resolve_engine(const fastkv_problem &p)
+{
+    const int e = p.reserved & 3, R = (p.H / p.Hkv) * p.window;
+    return e != ENGINE_AUTO ? e : default_contract_f16() ? ENGINE_MFMA16 : (R >= 24 ? ENGINE_MFMA : ENGINE_VALU);
+}
+
 static inline Layout make_layout(const fastkv_problem &p)
 {
     Layout L;
     L.G = p.H / p.Hkv;
     L.R = L.G * p.window;
     L.engine = p.reserved & 3;
-    if (L.engine == ENGINE_AUTO) L.engine = L.R >= 24 ? ENGINE_MFMA : ENGINE_VALU;   // a 32-row MFMA block needs rows to fill it
+    if (L.engine == ENGINE_AUTO)     // (fmaf contract: a 32-row MFMA block needs rows to fill it; mfma16: missing rows are zero queries)
+        L.engine = default_contract_f16() ? ENGINE_MFMA16 : (L.R >= 24 ? ENGINE_MFMA : ENGINE_VALU);
     int r8 = (L.R + 7) / 8 * 8;
-    if (L.engine == ENGINE_MFMA) { L.RB = 32; L.passes = (L.R + 31) / 32; }
+    if (L.engine == ENGINE_MFMA || L.engine == ENGINE_MFMA16) { L.RB = 32; L.passes = (L.R + 31) / 32; }
     else if (r8 <= 64) { L.RB = r8 <= 8 ? 8 : r8 <= 16 ? 16 : r8 <= 32 ? 32 : 64; L.passes = 1; }
     else { L.RB = 64; L.passes = (r8 + 63) / 64; }
     L.R_alloc = L.RB * L.passes;

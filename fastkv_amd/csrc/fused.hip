@@ -86,7 +86,7 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
 // wave is the other wave of its SIMD using the issue slots (vector-ALU work and fp32 MFMAs of a SIMD add up, in one wave or
 // across two: tools/probes/probe_overlap.hip).  The kernel is issue bound (per SIMD: A 27, B 9, C 5, D 4 us), and two streams
 // pay every hand-off's record sweep twice, with twice the producers per head.
-template <int D, int PER, int NB, int NS>
+template <int D, int PER, int NB, int NS, bool F16>
 __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -275,6 +275,12 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #pragma unroll
         for (int u = 0; u < QV; ++u) {
             const int item = u * 256 + tix, rowl = item / (D / 8), ch = item - rowl * (D / 8);
+            if (F16) {
+                // contract "mfma16": the query block stays fp16, as A-operand fragments of v_mfma_f32_32x32x16_f16 -- fragment
+                // [chunk c][lane = 32 h + row] = dims 16 c + 8 h .. + 7 of the row, i.e. the row's 16-B piece ch = 2 c + h as it is
+                reinterpret_cast<uint4 *>(As + s * AS_FLOATS)[((ch >> 1) * 64) + (ch & 1) * 32 + rowl] = qv[s][u];
+                continue;
+            }
             const uint32_t wds[4] = {qv[s][u].x, qv[s][u].y, qv[s][u].z, qv[s][u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -366,6 +372,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                         }
                     } else
 #endif
+                    if (F16) mfma_phase_f16<NB>(acc0, acc1, my, reinterpret_cast<const f16x8 *>(As + s * AS_FLOATS) + ph * 4 * 64 + lane, n31, hi);
+                    else
                     mfma_phase_mx<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -389,6 +397,14 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #endif
                 }
 #endif
+                if (F16) {
+                    // the instruction follows IEEE on Inf / NaN operands, element by element, and so does the oracle's restatement of
+                    // it: nothing to redo -- only remember that the tile holds a NaN (general softmax path later on)
+                    bool bad = false;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) bad = bad || (NB == 2 ? __builtin_isunordered(acc0[i], acc1[i]) : acc0[i] != acc0[i]);
+                    if (__any(bad)) tile_nan |= 1u << t;
+                } else
                 if (redo_tile_if_nan<NPH, NB>(acc0, acc1, kb_s[s], ks_s, key0, S, lane, my, As + s * AS_FLOATS + lane, n31, sh))
                     tile_nan |= 1u << t;
                 const int jA = key0 + n31, jB = NB == 2 ? jA + 32 : jA;    // columns of the low / high half of a word
@@ -989,7 +1005,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 // paid once per launch: bit-exact, and no faster than one launch per sub-batch (0.822 vs 0.825 ms per step) once both used the same
 // register allocation; the loop needs the thread index laundered through an opaque move or everything derived from it is hoisted
 // and spilled.  Dropped: separate launches are simpler and cannot reuse a hand-off record too early.)
-template <int D, int PER, int NB, int NS>
+template <int D, int PER, int NB, int NS, bool F16>
 __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -1002,7 +1018,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
                                                              const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots)
 {
-    (void)score_fused_body<D, PER, NB, NS>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
+    (void)score_fused_body<D, PER, NB, NS, F16>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
                                            spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots);
 }
@@ -1024,7 +1040,7 @@ static int device_cus()
     }();
     return cus;
 }
-template <int D, int PER, int NB, int NS> static bool fused_resident(int grid_wgs)
+template <int D, int PER, int NB, int NS, bool F16> static bool fused_resident(int grid_wgs)
 {
     struct Info { int wgs_per_cu, cus; };
     static const Info info = []() {                            // initialised once, thread-safe (C++11 static)
@@ -1032,7 +1048,7 @@ template <int D, int PER, int NB, int NS> static bool fused_resident(int grid_wg
         int dev = 0, nb = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB, NS>), 256, 0) ==
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB, NS, F16>), 256, 0) ==
                 hipSuccess) {
             r.wgs_per_cu = nb;
             r.cus = prop.multiProcessorCount;
@@ -1043,23 +1059,24 @@ template <int D, int PER, int NB, int NS> static bool fused_resident(int grid_wg
 }
 
 // One instantiation: residency check + launch.
-template <int D, int PER, int NB, int NS> struct FusedLaunch {
-    static bool resident(int wgs) { return fused_resident<D, PER, NB, NS>(wgs); }
+template <int D, int PER, int NB, int NS, bool F16> struct FusedLaunch {
+    static bool resident(int wgs) { return fused_resident<D, PER, NB, NS, F16>(wgs); }
     template <typename... Args> static void launch(dim3 grid, hipStream_t st, Args... args)
     {
-        hipLaunchKernelGGL((score_fused_kernel<D, PER, NB, NS>), grid, dim3(256), 0, st, args...);
+        hipLaunchKernelGGL((score_fused_kernel<D, PER, NB, NS, F16>), grid, dim3(256), 0, st, args...);
     }
 };
 
-// Calls f(FusedLaunch<D, PER, NB, NS>{}) for the runtime shape; false if that combination is not instantiated.
-template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, F &&f)
+// Calls f(FusedLaunch<D, PER, NB, NS, F16>{}) for the runtime shape; false if that combination is not instantiated.
+template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, bool f16, F &&f)
 {
-#define FK_CASE(DV, PV, NBV, NSV) if (D == DV && per == PV && nb == NBV && ns == NSV) { f(FusedLaunch<DV, PV, NBV, NSV>{}); return true; }
-#define FK_CASES_D(DV)                                                                                          \
-    FK_CASE(DV, 1, 1, 1) FK_CASE(DV, 1, 2, 1) FK_CASE(DV, 2, 2, 1) FK_CASE(DV, 4, 2, 1)      /* (32-key tiles only ever come one per wave) */
-    FK_CASES_D(64) FK_CASES_D(128) FK_CASES_D(256)
-    // two streams (experiment): head dim 128, one tile per stream and wave
-    FK_CASE(128, 2, 1, 2) FK_CASE(128, 2, 2, 2)
+#define FK_CASE(DV, PV, NBV, NSV, FV) if (D == DV && per == PV && nb == NBV && ns == NSV && f16 == FV) { f(FusedLaunch<DV, PV, NBV, NSV, FV>{}); return true; }
+#define FK_CASES_D(DV, FV)                                                                                          \
+    FK_CASE(DV, 1, 1, 1, FV) FK_CASE(DV, 1, 2, 1, FV) FK_CASE(DV, 2, 2, 1, FV) FK_CASE(DV, 4, 2, 1, FV)      /* (32-key tiles only ever come one per wave) */
+    FK_CASES_D(64, false) FK_CASES_D(128, false) FK_CASES_D(256, false)
+    FK_CASES_D(64, true) FK_CASES_D(128, true) FK_CASES_D(256, true)
+    // two streams (experiment, fp32 contract only): head dim 128, one tile per stream and wave
+    FK_CASE(128, 2, 1, 2, false) FK_CASE(128, 2, 2, 2, false)
 #undef FK_CASES_D
 #undef FK_CASE
     return false;
@@ -1068,21 +1085,23 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
 // Returns true when the fused kernel was launched (and *err holds the launch status); false when the shape is not
 // covered and the caller must take the three-kernel path.
 struct FusedPlan { int NBV, PERT, NS, nblk, wgs; };
-static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl);
+static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl, bool f16);
 
 // Largest number of batch entries ONE fused scoring launch holds for this geometry (p.B is ignored), 0 = the geometry is off the
 // fused path.  What a caller that batches entries itself wants to know up front (fastkv_amd.cluster.DeferredCompression).
 int fused_entries_per_launch(const fastkv_problem &p)
 {
     const bool disabled = no_wait_mode();
-    static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
+    static const int ns_pref_env = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
     const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4;
-    const bool engine_ok = G < 4 ? (p.reserved & 3) != ENGINE_VALU : (p.reserved & 3) != ENGINE_VALU && G * p.window >= 24;
+    const bool f16 = resolve_engine(p) == ENGINE_MFMA16;
+    const int ns_pref = f16 ? 1 : ns_pref_env;
+    const bool engine_ok = f16 || (G < 4 ? (p.reserved & 3) != ENGINE_VALU : (p.reserved & 3) != ENGINE_VALU && G * p.window >= 24);
     if (disabled || !engine_ok || p.window != 8 || (G >= 4 && G % 4 != 0) || VH > 8 || p.kernel > 63 || !abort_flag_device()) return 0;
     FusedPlan pl;
     int best = 0;
     for (int cand = 1; cand <= 64; ++cand)
-        if (fused_plan_for(p, p.Hkv * VH, ns_pref, cand, pl)) best = cand;
+        if (fused_plan_for(p, p.Hkv * VH, ns_pref, cand, pl, f16)) best = cand;
     return best;
 }
 
@@ -1092,12 +1111,14 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 {
     const bool disabled = no_wait_mode();
     // FASTKV_FUSED_STREAMS=2: the two-heads-per-workgroup experiment (measured slower, see the kernel's comment); default 1
-    static const int ns_pref = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
+    static const int ns_pref_env = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
     // virtual heads of 4 query heads per KV head; a group of 1-3 query heads (MHA, G = 2 models, the per-query-head rule's
     // views) is ONE block whose missing heads are zero queries: a quarter to three quarters of the block's matrix work is
     // spent on rows nobody reads, and the launch still beats the three staged kernels with their logits round trip
     const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4, HV = G < 4 ? G : 4;
-    const bool engine_ok = G < 4 ? (p.reserved & 3) != ENGINE_VALU : L.engine == ENGINE_MFMA;     // (tests force engines through `reserved`)
+    const bool f16 = L.engine == ENGINE_MFMA16;                  // contract "mfma16": the fp16 matrix instruction itself (mfma_tile.h)
+    const int ns_pref = f16 ? 1 : ns_pref_env;
+    const bool engine_ok = f16 || (G < 4 ? (p.reserved & 3) != ENGINE_VALU : L.engine == ENGINE_MFMA);     // (tests force engines through `reserved`)
     if (disabled || !engine_ok || p.window != 8 || (G >= 4 && G % 4 != 0) || VH > 8 || p.kernel > 63) return false;
     uint32_t *host_flag = abort_flag_device();
     if (!host_flag) return false;                                // no way to report an abandoned launch: staged path
@@ -1108,7 +1129,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     FusedPlan pl;
     int sb = 0;
     for (int cand = p.B; cand >= 1; --cand)
-        if (fused_plan_for(p, UH, ns_pref, cand, pl)) { sb = cand; break; }
+        if (fused_plan_for(p, UH, ns_pref, cand, pl, f16)) { sb = cand; break; }
     if (!sb) return false;                                       // not even one entry fits: staged path
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
@@ -1159,11 +1180,11 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     for (int b0 = 0; b0 < p.B && *err == hipSuccess; ++sub) {
         // launches of `sb` entries; the last one takes what is left (its own plan: fewer entries may mean fewer tiles per wave)
         int take = p.B - b0 < sb ? p.B - b0 : sb;
-        while (take > 1 && !fused_plan_for(p, UH, ns_pref, take, pl)) --take;
-        if (!fused_plan_for(p, UH, ns_pref, take, pl)) { *err = hipErrorLaunchFailure; break; }      // (cannot happen: one entry fits)
+        while (take > 1 && !fused_plan_for(p, UH, ns_pref, take, pl, f16)) --take;
+        if (!fused_plan_for(p, UH, ns_pref, take, pl, f16)) { *err = hipErrorLaunchFailure; break; }      // (cannot happen: one entry fits)
         const dim3 grid(pl.nblk * UH / pl.NS, take);
         ProfScope ps_(K_FUSED, st);
-        fused_dispatch(p.D, pl.PERT, pl.NBV, pl.NS, [&](auto fl) {
+        fused_dispatch(p.D, pl.PERT, pl.NBV, pl.NS, f16, [&](auto fl) {
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
@@ -1175,7 +1196,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     return true;
 }
 
-static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl)
+static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl, bool f16)
 {
     // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
     pl.NBV = (int64_t)Bn * UH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
@@ -1206,7 +1227,7 @@ static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn,
     if (vwgs > FUSED_MAX_WGS) return false;
     pl.wgs = (int)(vwgs / pl.NS);
     bool resident = false;
-    if (!fused_dispatch(p.D, pl.PERT, pl.NBV, pl.NS, [&](auto fl) { resident = decltype(fl)::resident(pl.wgs); }) || !resident) return false;
+    if (!fused_dispatch(p.D, pl.PERT, pl.NBV, pl.NS, f16, [&](auto fl) { resident = decltype(fl)::resident(pl.wgs); }) || !resident) return false;
     return true;
 }
 

@@ -72,7 +72,7 @@ __global__ void prep_q_kernel(const uint16_t *__restrict__ q, int64_t qs_b, int6
 // nwaves, ...  The A operand (the head's 32 query rows, all D/2 k-steps) is loaded into registers once per wave; the
 // K rows of the next phase/tile are fetched into registers while the matrix pipe works on the current LDS slab.
 // Eight named 16-B registers (an indexed local array carried across the tile loop ends up in scratch memory).
-template <int D>
+template <int D, bool F16>
 __global__ void __launch_bounds__(256, 2) score_logits_mfma_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h,
                                                                 int64_t ks_s, const uint16_t *__restrict__ q, int64_t qs_b,
                                                                 int64_t qs_h, int64_t qs_s, int q_row0, int H, int Hkv, int S,
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256, 2) score_logits_mfma_kernel(const uint16_
                                                                 uint16_t *__restrict__ logits)
 {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][64 * ROWB];
-    __shared__ float As[(D / 2) * 64];                   // A operand of every k-step, shared by the 4 waves (same head)
+    __shared__ __attribute__((aligned(16))) float As[(D / 2) * 64];   // A operand of every k-step, shared by the 4 waves (same head)
     constexpr int NPH = D / DH;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = blockIdx.x % Hkv, blk = blockIdx.x / Hkv, nblk = gridDim.x / Hkv, b = blockIdx.y;
@@ -118,6 +118,10 @@ __global__ void __launch_bounds__(256, 2) score_logits_mfma_kernel(const uint16_
         for (int u = 0; u < QV; ++u) {
             const int item = u * 256 + threadIdx.x, rowl = item / (D / 8), ch = item - rowl * (D / 8);
             const bool live = pass * 32 + rowl < R;
+            if (F16) {                                          // contract "mfma16": fp16 A-operand fragments (mfma_tile.h mfma_phase_f16)
+                reinterpret_cast<uint4 *>(As)[(ch >> 1) * 64 + (ch & 1) * 32 + rowl] = live ? qv[u] : make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
             const uint32_t wds[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                       // fp16 pair (dims 2dp, 2dp+1), dp = ch*4 + e
@@ -161,7 +165,8 @@ __global__ void __launch_bounds__(256, 2) score_logits_mfma_kernel(const uint16_
                 else { k_commit(sB, lane, my); if (more) k_fetch(sB, kb, ks_s, nkey, S, nph, lane); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (tcount == 0 && ph < 2) FK_CYC_AT(3 + ph * 3);
-                mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
+                if (F16) mfma_phase_f16(acc0, acc1, my, reinterpret_cast<const f16x8 *>(As) + ph * 4 * 64 + lane, n31, hi);
+                else mfma_phase(acc0, acc1, my, As + ph * (DH / 2) * 64 + lane, n31, sh);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);              // ... and the next commit (which waits for them) stays behind the MFMAs
@@ -560,7 +565,8 @@ static hipError_t launch_logits(const fastkv_problem &p, const Layout &L, const 
 {
     const uint16_t *kp = (const uint16_t *)k;
     hipError_t e;
-    if (L.engine == ENGINE_MFMA) {
+    if (L.engine == ENGINE_MFMA || L.engine == ENGINE_MFMA16) {
+        const bool f16 = L.engine == ENGINE_MFMA16;
         ProfScope ps_(K_LOGITS, st);
         // persistent grid: 2 workgroups per CU (8 waves/CU at <=256 VGPRs), balanced over the 64-key wave tiles
         const int nwt = (p.S + 63) / 64;
@@ -570,13 +576,15 @@ static hipError_t launch_logits(const fastkv_problem &p, const Layout &L, const 
         const int per = (nwt + nblk * 4 - 1) / (nblk * 4);           // tiles per wave
         nblk = (nwt + per * 4 - 1) / (per * 4);                      // fewest workgroups with that many tiles per wave
         dim3 gridM(nblk * p.Hkv, p.B);
-#define FK_LAUNCH_MFMA(DV)                                                                                                     \
-    hipLaunchKernelGGL((score_logits_mfma_kernel<DV>), gridM, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], (const uint16_t *)q, \
+#define FK_LAUNCH_MFMA1(DV, FV)                                                                                                     \
+    hipLaunchKernelGGL((score_logits_mfma_kernel<DV, FV>), gridM, dim3(256), 0, st, kp, ks[0], ks[1], ks[2], (const uint16_t *)q, \
                        qs[0], qs[1], qs[2], q_row0, p.H, p.Hkv, p.S, p.window, L.R, L.passes, Sp, col_off, logits)
+#define FK_LAUNCH_MFMA(DV) do { if (f16) FK_LAUNCH_MFMA1(DV, true); else FK_LAUNCH_MFMA1(DV, false); } while (0)
         if (p.D == 64) FK_LAUNCH_MFMA(64);
         else if (p.D == 128) FK_LAUNCH_MFMA(128);
         else FK_LAUNCH_MFMA(256);
 #undef FK_LAUNCH_MFMA
+#undef FK_LAUNCH_MFMA1
         return hipGetLastError();
     }
     {

@@ -70,12 +70,16 @@ def set_no_wait_mode(on: bool) -> bool:
     return bool(load().fastkv_set_no_wait_mode(1 if on else 0))
 
 
-ENGINE = {"auto": 0, "valu": 1, "mfma": 2}
+# contraction engines.  Two arithmetic CONTRACTS (oracle/fastkv_oracle.c, "the contraction"): the fp32 fma chain ("valu", "mfma": the
+# fp32 matrix instruction; bit-identical) and "mfma16" (the gfx950 fp16 matrix instruction on the fp16 operands themselves).  "auto" =
+# the library's default contract (FASTKV_CONTRACTION=mfma16 | fmaf; mfma16 unless set)
+ENGINE = {"auto": 0, "valu": 1, "mfma": 2, "mfma16": 3}
 _engine = ENGINE[os.environ.get("FASTKV_SCORE_ENGINE", "auto")]
 
 
 def set_score_engine(name: str) -> None:
-    """Force the contraction engine of the scoring kernel ("auto" | "valu" | "mfma"); results are bit-identical."""
+    """Force the contraction engine of the scoring kernels ("auto" | "valu" | "mfma" | "mfma16"); "valu" and "mfma" are bit-identical
+    (the fp32 fma chain), "mfma16" is the other contract."""
     global _engine
     _engine = ENGINE[name]
 

@@ -382,6 +382,10 @@ int fastkv_decode_gemv_f16(int32_t B, int32_t K, const void *x, int64_t x_row_st
  * 5 fix_to_f32(bits(a)<<32|bits(b)), 6 a*b, 7 a+b, 8 scale_div(a, b), 9-11 packed twins of 0 / 3 / 8, 12 packed fp16 round trip) so tests can compare the GPU bit-for-bit with the CPU oracle.
  */
 int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream);
+/* Test hook of the "mfma16" contraction contract: the raw v_mfma_f32_32x32x16_f16, chained over dd / 16 chunks, on `ntiles` tiles
+ * a [32][dd] x bt [32][dd] (fp16 bit patterns, row-major) on top of c [32][32] fp32 (NULL: +0) -> out [32][32]; the tests hold the
+ * oracle's restatement of the instruction against it on the machine they run on. */
+int fastkv_debug_mfma16(const void *a, const void *bt, const float *c, float *out, int ntiles, int dd, void *stream);
 /* Test hook: `wgs` 256-thread workgroups that each hold `lds_bytes` of LDS for `usec` microseconds -- "another kernel is
  * holding compute units" for the residency tests of the in-launch hand-offs. */
 int fastkv_debug_occupy(int wgs, int lds_bytes, int64_t usec, void *stream);

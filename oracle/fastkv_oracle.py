@@ -68,6 +68,10 @@ def lib() -> ctypes.CDLL:
         L.fastkv_oracle_h2f.restype = ctypes.c_float
         L.fastkv_oracle_scale_logit.argtypes = [ctypes.c_uint16, ci]
         L.fastkv_oracle_scale_logit.restype = ctypes.c_uint16
+        L.fastkv_oracle_set_contraction.argtypes = [ci]
+        L.fastkv_oracle_get_contraction.restype = ci
+        L.fastkv_oracle_mfma16_tiles.argtypes = [vp, vp, vp, vp, ci, ci]
+        L.fastkv_oracle_mfma16_tiles.restype = ci
         L.fastkv_oracle_set_threads.argtypes = [ci]
         L.fastkv_oracle_get_threads.restype = ci
         _lib = L
@@ -86,6 +90,33 @@ def _strides(t: torch.Tensor):
 def _check(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"fastkv oracle: {what} failed with code {rc}")
+
+
+CONTRACTION = {"fmaf": 0, "mfma16": 1}
+
+
+def set_contraction(name: str) -> None:
+    """The arithmetic contract of the contraction (utils.py:94; fastkv_oracle.c "the contraction"): "mfma16" (default) = what the
+    gfx950 fp16 matrix instruction computes, "fmaf" = the fp32 fma chain.  The HIP side's twins: ops.set_score_engine("mfma16") /
+    ("mfma" | "valu"); "auto" there follows FASTKV_CONTRACTION."""
+    lib().fastkv_oracle_set_contraction(CONTRACTION[name])
+
+
+def get_contraction() -> str:
+    return {v: k for k, v in CONTRACTION.items()}[int(lib().fastkv_oracle_get_contraction())]
+
+
+def mfma16_tiles(a: torch.Tensor, bt: torch.Tensor, c: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The restated v_mfma_f32_32x32x16_f16 chain on tiles: a, bt [T,32,dd] fp16 (CPU, contiguous), c [T,32,32] fp32 or None (+0)
+    -> [T,32,32] fp32."""
+    assert a.dtype == torch.float16 and bt.dtype == torch.float16 and a.is_contiguous() and bt.is_contiguous() and a.shape == bt.shape
+    T, _, dd = a.shape
+    out = torch.empty(T, 32, 32, dtype=torch.float32)
+    if c is not None:
+        assert c.dtype == torch.float32 and c.is_contiguous() and c.shape == (T, 32, 32)
+    _check(lib().fastkv_oracle_mfma16_tiles(a.data_ptr(), bt.data_ptr(), c.data_ptr() if c is not None else None, out.data_ptr(), T, dd),
+           "mfma16_tiles")
+    return out
 
 
 def set_threads(n: int) -> None:
