@@ -189,6 +189,9 @@ def cpu_baseline(work: HotPathPrefill):
     from oracle import fastkv_oracle as O
     from oracle.fastkv_oracle import OracleFastKVCluster
     G = CFG["H"] // CFG["Hkv"]
+    # The CPU leg times the fp32-fma-chain contraction (what a CPU computes natively: AVX-512 FMAs), not the oracle's integer
+    # restatement of the gfx950 matrix instruction (the default contract, ~5x slower on a CPU and no CPU's native arithmetic)
+    O.set_contraction("fmaf")
     # pick the OpenMP thread count that is fastest on this host (hyper-threads / all 256 logical CPUs are slower)
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     q0, k0, v0 = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[0])
@@ -233,6 +236,7 @@ def cpu_baseline(work: HotPathPrefill):
     step_s = 15 * (sum(t_pre) / 2) + t_tsp + 16 * (sum(t_post) / 2) + t_g
     return {"value": round(CFG["S"] / step_s, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
             "ms_per_step": round(step_s * 1e3, 1),
+            "contraction": "fmaf (fp32 fma chain, the CPU's native arithmetic)",
             "sample": "oracle update_kv: layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, 1 warm-up + best of 3 timed "
                       f"each, scaled to 15+1+16 layers; OpenMP threads auto-picked from 16/32/64/128 on {ncpu} logical CPUs"}
 
@@ -526,7 +530,8 @@ def main():
                     "rank 0 prints a line with value null -- no GPU work, nothing measured")
     a = ap.parse_args()
 
-    if a.gpus > 1 and "RANK" not in os.environ and not a.leg:
+    one_rank_rccl = a.gpus == 1 and os.environ.get("BENCH_BACKEND") == "nccl"     # RCCL with the one rank a one-GPU box allows
+    if (a.gpus > 1 or one_rank_rccl) and "RANK" not in os.environ and not a.leg:
         # plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU and never will)
         return self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -542,7 +547,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or one_rank_rccl:
         import torch.distributed as dist
         backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo": several ranks on one GPU (test boxes with a single device)
         if backend == "nccl":
@@ -586,6 +591,9 @@ def main():
                                   "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
                       "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
            "ttft_hotpath_ms": round(ms_per_step, 4),
+           # the arithmetic contract of the contraction (utils.py:94) both sides run by default: "mfma16" = the gfx950 fp16 matrix
+           # instruction on the fp16 operands, restated bit for bit by the oracle; "fmaf" = the fp32 fma chain (FASTKV_CONTRACTION)
+           "contraction": "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16",
            "ranks_seen": dist.get_world_size() if dist is not None else 1,
            "backend": (dist.get_backend() if dist is not None else "none"),
            # the fused launches' own check of where their workgroups ran (include/fastkv_hip.h: fastkv_placement_violations): 0 = every
@@ -636,15 +644,18 @@ def main():
                                "traffic_static": True, "traffic_source": tsrc or "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                                "WRITE_SIZE passes, corrected per guide; NOT measured in this run)",
                                "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2),
-                               "note": "score_fused = logits (fp32 MFMA) + softmax (2 in-kernel reductions over the head's workgroups) + window-row "
-                                       "sum + pooling + head sum in one launch; logits stay in registers, row sums in LDS" if kname == "score_fused"
-                                       else "fp32 MFMA contraction; logits written as fp16"}
+                               "note": ("score_fused = logits (" + ("v_mfma_f32_32x32x16_f16 on the fp16 operands" if out["contraction"] == "mfma16" else "fp32 MFMA") +
+                                        ") + softmax (2 in-kernel reductions over the head's workgroups) + window-row "
+                                        "sum + pooling + head sum in one launch; logits stay in registers, row sums in LDS") if kname == "score_fused"
+                                       else "matrix-pipe contraction; logits written as fp16"}
             # The contraction must be an fp32 fma chain in ascending head-dim order (bit-exact parity with the CPU oracle), so it
             # runs on v_mfma_f32_32x32x2_f32 (32 flop per K byte): the FP32 pipe saturates long before HBM does.  Measured
             # (tools/probes/probe_overlap.hip): vector-ALU work does not overlap the fp32 MFMAs of a SIMD, the two add up.
+            pipe_peak = FP32_MATRIX_PEAK_TFLOPS if out["contraction"] == "fmaf" else 2500.0    # dense fp16 MFMA peak (MI355X_MICROARCH.md)
             out["fp32_pipe_view"] = {"kernel": kname, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
-                                     "peak_TFLOPs": FP32_MATRIX_PEAK_TFLOPS, "frac": round(flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                     "flop_per_launch": flops}
+                                     "peak_TFLOPs": pipe_peak, "frac": round(flops / (us * 1e-6) / 1e12 / pipe_peak, 4),
+                                     "flop_per_launch": flops,
+                                     "pipe": "fp32 matrix instruction" if out["contraction"] == "fmaf" else "fp16 matrix instruction (the contraction is ~2 % of its peak: the launch is bound by HBM and the vector work behind the contraction)"}
             if work.defer and kname == "score_fused":
                 # In the default (deferred) schedule the launch that dominates the step scores TWO 32k layers (score_fused_kernel<128,4,2,1>
                 # in the rocprofv3 trace): the headline prices that launch; the one-layer launch above stays beside it.
@@ -673,7 +684,7 @@ def main():
                                             "avg_launch_us": round(us2, 2)})
                     out["roofline_one_layer_launch"] = single
                     out["fp32_pipe_view"].update({"achieved_TFLOPs": round(2 * flops / (us2 * 1e-6) / 1e12, 2),
-                                                  "frac": round(2 * flops / (us2 * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                                  "frac": round(2 * flops / (us2 * 1e-6) / 1e12 / pipe_peak, 4),
                                                   "flop_per_launch": 2 * flops})
                 except Exception as e:   # noqa: BLE001 -- the one-layer figures stay in place
                     out["roofline"]["pair_launch_error"] = repr(e)[:160]
@@ -741,14 +752,56 @@ def main():
                               "per_layer_order": "score (the reference's row order: the product default); average over the step's "
                                                  "compaction launches (deferred schedule: 8 two-layer launches at 32k + one for the 16 post-TSP layers)",
                               "roofline_shape": compact_roofline_shape(lib, dev, 10)}
+            # the same (default, deferred) step under the OTHER contraction contract: the fp32 fma chain on v_mfma_f32_32x32x2_f32
+            # (rounds 1-3's only contract; FASTKV_CONTRACTION=fmaf makes it the default of the library)
+            other = "mfma" if out["contraction"] == "mfma16" else "mfma16"
+            ops.set_score_engine(other)
+            try:
+                for _ in range(2):
+                    work.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    work.step()
+                torch.cuda.synchronize()
+                ms_o = (time.perf_counter() - t0) / a.steps * 1e3
+            finally:
+                ops.set_score_engine("auto")
+            out["other_contract"] = {"engine": other, "contraction": "fmaf" if other == "mfma" else "mfma16", "ms_per_step": round(ms_o, 4),
+                                     "tokens_per_s": round(CFG["S"] / (ms_o * 1e-3), 1),
+                                     "note": "same schedule, the other arithmetic contract of the contraction (both bit-exact against the "
+                                             "oracle under the same contract)"}
+            # the quantities BASELINE.json names, at the top level
+            rs = out["compact"]["roofline_shape"]["score"]
+            out["kv_compact_GBps"] = rs["achieved_GBps"]
+            out["kv_compact_frac"] = rs["frac_of_8TBps"]
+            out["kv_compact_note"] = ("KV gather/compact kernel at the 541 MB roofline shape, rows in the reference's score order (the product "
+                                      "default; median over calls, HIP events); index order: compact.roofline_shape.index")
             if world == 1 and not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(work)
             if world == 1 and not a.no_ttft:
                 out["ttft"] = whole_model_ttft(work)
+                out["ttft_ms"] = out["ttft"].get("fastkv", {}).get("ttft_ms")
+            if world == 1 and dist is None and not a.no_legs:
+                # RCCL with the ONE rank this box allows: the sequence-sharded and the head-sharded operator in
+                # child processes that initialise torch.distributed with backend "nccl", world size 1 -- every collective of
+                # fastkv_amd/dist.py executes in RCCL on device tensors.  No scaling is claimed: one rank moves nothing over xGMI.
+                del_env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                           "BENCH_BACKEND": "nccl"}
+                saved = {k_: os.environ.get(k_) for k_ in del_env}
+                os.environ.update(del_env)
+                try:
+                    out["rccl_one_rank"] = {name: spawn_leg(name, i, 3, 0, timeout_s=120) for i, name in enumerate(("seq_sharded_weak", "tp"))}
+                finally:
+                    for k_, v_ in saved.items():
+                        if v_ is None:
+                            os.environ.pop(k_, None)
+                        else:
+                            os.environ[k_] = v_
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if world > 1 and not a.no_legs:
+    if (world > 1 or one_rank_rccl) and not a.no_legs:
         # The paths with a real exchange step, each in a freshly spawned child process per rank: a rank that
         # dies or hangs inside a collective costs that leg, never the contract line.  This process has released its process
         # group and its tensors; it only waits.

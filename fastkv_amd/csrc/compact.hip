@@ -74,8 +74,13 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
     // reads a clamped row; FASTKV_DEBUG_BOUNDS=1 in the environment (or a build with -DFK_DEBUG_BOUNDS) makes it loud instead
     if (bounds_flag && (srow < 0 || srow >= S)) __hip_atomic_store(bounds_flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // FASTKV_EBOUNDS
     srow = srow < 0 ? 0 : (srow >= S ? (int64_t)S - 1 : srow);
-    const uint4 kval = *reinterpret_cast<const uint4 *>(ksrc + srow * ks_s + sub * 8);
-    const uint4 vval = *reinterpret_cast<const uint4 *>(vsrc + srow * vs_s + sub * 8);
+    // Non-temporal on both sides: every source row is read once and every destination byte written once by this launch, nothing of
+    // either is read again before the launch ends.  Round 4, tools/probes/compact_probe2.hip at the 541 MB roofline shape on one box:
+    // plain 102.4 us (66 % of 8 TB/s), nt loads 97.8, nt stores 95.5, both 94.2 us (72 %) = a contiguous copy of the same bytes.
+    // (Round 3 had tried the builtins on HIP's uint4 class, which they do not accept, and recorded "no gain".)
+    typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+    const nt_u32x4 kval = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(ksrc + srow * ks_s + sub * 8));
+    const nt_u32x4 vval = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(vsrc + srow * vs_s + sub * 8));
     int d = rc;
     if (keys && keys_in_lds == 2) {
         // ORDER_SCORE with the slots already known (rank_group_kernel ran first: many heads): one 2-byte load per row
@@ -111,8 +116,8 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
         idx_sorted[(size_t)bg * kk + rc] = srow;               // identity selection in ascending order: the list itself
     }
     if (r < cap) {
-        *reinterpret_cast<uint4 *>(kdst + (int64_t)d * os_r + sub * 8) = kval;
-        *reinterpret_cast<uint4 *>(vdst + (int64_t)d * os_r + sub * 8) = vval;
+        __builtin_nontemporal_store(kval, reinterpret_cast<nt_u32x4 *>(kdst + (int64_t)d * os_r + sub * 8));
+        __builtin_nontemporal_store(vval, reinterpret_cast<nt_u32x4 *>(vdst + (int64_t)d * os_r + sub * 8));
     }
 }
 

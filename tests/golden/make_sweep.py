@@ -70,12 +70,17 @@ def bits(t):
     return t.contiguous().view(torch.int16).to(torch.int32)
 
 
-def main():
-    arrays, meta = {}, {"cases": {}, "note": "flips = indices of canonical_topk(oracle scores) that are not in canonical_topk(reference scores)"}
-    tot_rows = tot_straddle = tot_flip_rows = tot_flips = tot_mism = tot_el = tot_invalid = 0
+def sweep_one(contraction, refs, arrays):
+    """The oracle under one contraction contract against the reference runs in `refs`; fills `arrays` (reference-only data: the same
+    for every contraction) and returns {"cases": ..., "summary": ...}."""
+    O.set_contraction(contraction)
+    meta = {"cases": {}}
+    tot_rows = tot_straddle = tot_flip_rows = tot_flips = tot_mism = tot_el = tot_invalid = max_ulp = 0
     for name, case in SWEEP_CASES.items():
         q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
-        c_ref, t_ref = run_reference(q, k, v, case)
+        if name not in refs:
+            refs[name] = run_reference(q, k, v, case)
+        c_ref, t_ref = refs[name]
         _, _, idx_or, tsp_or, c_or, t_or = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"],
                                                        "index", return_scores=True)
         B, Hkv, n = c_ref.shape
@@ -119,6 +124,7 @@ def main():
                                    "flips": len(tflips), "flipped_positions": tflips,
                                    "valid_topk_of_reference_scores": bool(tvalid)}}
         meta["cases"][name] = m
+        max_ulp = max(max_ulp, int(d.max()), int(td.max()))
         tot_rows += len(rows) + 1
         tot_straddle += sum(1 for r in rows if r["straddling"]) + (1 if tnear.any() else 0)
         tot_flip_rows += sum(1 for r in rows if r["flips"]) + (1 if tflips else 0)
@@ -126,17 +132,27 @@ def main():
         tot_invalid += sum(1 for r in rows if not r["valid_topk_of_reference_scores"]) + (0 if tvalid else 1)
         tot_mism += int((d > 0).sum()) + int(tmm.sum())
         tot_el += int(d.numel()) + int(td.numel())
-        print(name, "mismatching", m["mismatching_scores"], "max ulp", m["max_ulp"], "straddling rows",
-              sum(1 for r in rows if r["straddling"]), "flipping rows", sum(1 for r in rows if r["flips"]), "tsp flips", len(tflips))
+        print(contraction, name, "mismatching", m["mismatching_scores"], "max ulp", m["max_ulp"], "straddling rows",
+              sum(1 for r in rows if r["straddling"]), "flipping rows", sum(1 for r in rows if r["flips"]), "tsp flips", len(tflips), flush=True)
     meta["summary"] = {"cases": len(SWEEP_CASES), "rows": tot_rows, "score_elements": tot_el, "mismatching_scores": tot_mism,
-                       "mismatch_rate": tot_mism / tot_el, "rows_with_a_straddling_mismatch": tot_straddle,
+                       "mismatch_rate": tot_mism / tot_el, "max_ulp": max_ulp, "rows_with_a_straddling_mismatch": tot_straddle,
                        "rows_that_flip": tot_flip_rows, "indices_flipped": tot_flips,
                        "row_flip_rate": tot_flip_rows / tot_rows,
                        "rows_whose_set_is_not_a_valid_topk_of_the_reference_scores": tot_invalid}
+    return meta
+
+
+def main():
+    arrays, refs = {}, {}
+    meta = {"note": "flips = indices of canonical_topk(oracle scores) that are not in canonical_topk(reference scores); one entry per "
+                    "contraction contract of the oracle (oracle/fastkv_oracle.c: the fp32 fma chain / the gfx950 fp16 matrix instruction)",
+            "contractions": {}}
+    for contraction in ("fmaf", "mfma16"):
+        meta["contractions"][contraction] = sweep_one(contraction, refs, arrays)
+        print(contraction, json.dumps(meta["contractions"][contraction]["summary"], indent=1))
     np.savez_compressed(os.path.join(HERE, "sweep32k.npz"), **arrays)
     with open(os.path.join(HERE, "sweep_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
-    print(json.dumps(meta["summary"], indent=1))
 
 
 if __name__ == "__main__":

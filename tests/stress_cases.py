@@ -20,6 +20,8 @@ def run_stress(N=200, seed=12345, entries_p=0.25, all_entries=False, only=-1, re
     rng = random.Random(seed)
     dev = torch.device("cuda:0")
     violations0 = int(_load().fastkv_placement_violations(0))          # (a running count of the process)
+    import os
+    default_contraction = "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16"
     t0 = time.time()
     st = dict(cases=0, mismatches=0, entries_runs=0, entries_refused=0, max_entry_rows=0, special=0, engines=set())
     main_stream = torch.cuda.current_stream()
@@ -58,7 +60,6 @@ def run_stress(N=200, seed=12345, entries_p=0.25, all_entries=False, only=-1, re
             got = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
         torch.cuda.synchronize()
         torch.cuda.set_stream(main_stream)
-        ops.set_score_engine("auto")
         ne, qwin = c["ne"], c["qwin"]
         if ne:
             # the same geometry as several SEPARATELY ALLOCATED entries in one launch sequence (fastkv_update_kv_ptrs_f16); refused
@@ -91,6 +92,7 @@ def run_stress(N=200, seed=12345, entries_p=0.25, all_entries=False, only=-1, re
                 if "unsupported" not in str(e).lower():
                     raise
                 st["entries_refused"] += 1
+        ops.set_score_engine("auto")
         if c["pre"] and not same16(c_only, want[4]):
             print("MISMATCH (scores-only entry point)", dict(it=c["tag"]["it"], engine=c["engine"], rep=rep), flush=True)
             bad += 1
@@ -165,12 +167,16 @@ def run_stress(N=200, seed=12345, entries_p=0.25, all_entries=False, only=-1, re
         st["special"] += int(special)
         st["engines"].add(case["engine"])
         case["ins"] = [(q, k, v)] + [make_qkv(9000 + it + 100000 * j, B, Hkv * G, Hkv, S, D, W, peaked=peaked) for j in range(1, ne)]
+        # the oracle under the contract the case's engine computes: "valu" / "mfma" = the fp32 fma chain, "auto" = the library default
+        # (the fp16 matrix instruction); the entries call of the case runs on the same engine
+        O.set_contraction("fmaf" if case["engine"] in ("valu", "mfma") else default_contraction)
         case["wants"] = [O.update_kv(q, k, v, W, ks, pooling, cap, tsp_len, order, return_scores=True)] + \
             [O.update_kv(qj, kj, vj, W, ks, pooling, cap, tsp_len, order) for qj, kj, vj in case["ins"][1:]]
         if ONLY >= 0:
             print("replaying", tag, {x: case[x] for x in ("engine", "stream_pick", "pre", "slab", "ne", "qwin")}, flush=True)
         for rep in range(REPEAT if ONLY >= 0 else 1):
             st["mismatches"] += run_case(case, rep)
+    O.set_contraction(default_contraction)
     st["violations"] = int(_load().fastkv_placement_violations(0)) - violations0
     st["seconds"] = time.time() - t0
     return st

@@ -30,12 +30,15 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(one(f"{tag}_trace/*/*_kernel_trace.csv"))):
     if "fk::" in r["Kernel_Name"]:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        agg[(name, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        # keyed on the WHOLE grid (x, y, z in work-items, as rocprofv3 reports them): the roofline-shape launch of compact_kv
+        # (grid 128 x 256 workgroups) must not be averaged with the 8-head launches that share its grid.x
+        agg[(name, int(r["Grid_Size_X"]), int(r.get("Grid_Size_Y", 1)), int(r.get("Grid_Size_Z", 1)), int(r["Workgroup_Size_X"]))].append(
+            int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(os.path.join(P, f"{tag}_fk_kernels_by_grid.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["Name", "GridSizeX", "WorkgroupSizeX", "Calls", "AverageNs", "MedianNs", "MinNs", "MaxNs"])
-    for (name, grid, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        w.writerow([name, grid, wg, len(v), round(st.mean(v), 1), st.median(v), min(v), max(v)])
+    w.writerow(["Name", "GridSizeX", "GridSizeY", "GridSizeZ", "WorkgroupSizeX", "Calls", "AverageNs", "MedianNs", "MinNs", "MaxNs"])
+    for (name, gx, gy, gz, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([name, gx, gy, gz, wg, len(v), round(st.mean(v), 1), st.median(v), min(v), max(v)])
 
 pmc = json.load(open(os.path.join(G, f"{tag}_pmc_summary.json")))
 
@@ -49,11 +52,24 @@ def kib(counter, prefix):
 fused = any(k.startswith("fk::score_fused") for k in pmc.get("FETCH_SIZE", {}))
 dom = "fk::score_fused" if fused else "fk::score_logits"
 # one 32k layer per launch: score_fused_kernel<128, 2, 2, 1>; two (the deferred schedule's pairs): <128, 4, 2, 1>
-one = "fk::score_fused_kernel<128, 2, 2, 1> grid=131072" if fused else dom
+def head():
+    import subprocess
+    try:
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip() or "unknown"
+    except Exception:   # noqa: BLE001
+        return "unknown"
+
+
+def first_key(prefix, contains=""):
+    ks = [k for k in pmc.get("FETCH_SIZE", {}) if k.startswith(prefix) and contains in k]
+    return max(ks, key=lambda k: pmc["FETCH_SIZE"][k]["median"]) if ks else prefix
+
+
+one = first_key("fk::score_fused_kernel<128, 2, 2, 1", "grid=131072") if fused else dom
 lf, lw = kib("FETCH_SIZE", one), kib("WRITE_SIZE", one)
 pair = {}
-if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1>") for k in pmc.get("FETCH_SIZE", {})):
-    pf, pw = kib("FETCH_SIZE", "fk::score_fused_kernel<128, 4, 2, 1>"), kib("WRITE_SIZE", "fk::score_fused_kernel<128, 4, 2, 1>")
+if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1") for k in pmc.get("FETCH_SIZE", {})):
+    pf, pw = kib("FETCH_SIZE", "fk::score_fused_kernel<128, 4, 2, 1"), kib("WRITE_SIZE", "fk::score_fused_kernel<128, 4, 2, 1")
     pair = {"score_fused_pair_hbm_bytes_per_launch": int((2 * pf + pw) * 1024), "score_fused_pair_fetch_kib_raw": pf,
             "score_fused_pair_write_kib": pw,
             "pair_note": "two 32k layers per launch (score_fused_kernel<128,4,2,1>): algorithmic 134.35 MB; no scratch traffic to speak of "
@@ -63,7 +79,8 @@ ckey = "fk::compact_kv_kernel<16> grid=524288" if any(k.startswith("fk::compact_
     else "fk::compact_kv_kernel<16>"
 cf, cw = kib("FETCH_SIZE", ckey), kib("WRITE_SIZE", ckey)
 json.dump({**pair, **{
-    "source": f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
+    "git_head_of_the_pmc_pass": head(),
+    "source": f"{tag} (git {head()}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
               "--no-extras`, medians over launches; counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide 16-B/lane "
               "reads, guides/MI355X_MICROARCH.md HBM section; the compact kernel calibrates it: 2*FETCH = its 8.39 MB of row reads)",
     dom[4:] + "_hbm_bytes_per_launch": int((2 * lf + lw) * 1024),
