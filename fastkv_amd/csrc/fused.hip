@@ -1095,7 +1095,7 @@ int fused_entries_per_launch(const fastkv_problem &p)
     static const int ns_pref_env = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
     const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4;
     const bool f16 = resolve_engine(p) == ENGINE_MFMA16;
-    const int ns_pref = f16 ? 1 : ns_pref_env;
+    const int ns_pref = f16 ? 1 : ns_pref_env;      // (two streams under the mfma16 contract: built and measured in round 4, 58 vs 42 us per one-layer launch: not instantiated)
     const bool engine_ok = f16 || (G < 4 ? (p.reserved & 3) != ENGINE_VALU : (p.reserved & 3) != ENGINE_VALU && G * p.window >= 24);
     if (disabled || !engine_ok || p.window != 8 || (G >= 4 && G % 4 != 0) || VH > 8 || p.kernel > 63 || !abort_flag_device()) return 0;
     FusedPlan pl;
@@ -1117,7 +1117,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     // spent on rows nobody reads, and the launch still beats the three staged kernels with their logits round trip
     const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4, HV = G < 4 ? G : 4;
     const bool f16 = L.engine == ENGINE_MFMA16;                  // contract "mfma16": the fp16 matrix instruction itself (mfma_tile.h)
-    const int ns_pref = f16 ? 1 : ns_pref_env;
+    const int ns_pref = f16 ? 1 : ns_pref_env;      // (two streams under the mfma16 contract: built and measured in round 4, 58 vs 42 us per one-layer launch: not instantiated)
     const bool engine_ok = f16 || (G < 4 ? (p.reserved & 3) != ENGINE_VALU : L.engine == ENGINE_MFMA);     // (tests force engines through `reserved`)
     if (disabled || !engine_ok || p.window != 8 || (G >= 4 && G % 4 != 0) || VH > 8 || p.kernel > 63) return false;
     uint32_t *host_flag = abort_flag_device();

@@ -47,6 +47,9 @@ def _workspace(nbytes: int, device: torch.device, kind: str = "op") -> torch.Ten
             check(load().fastkv_workspace_init(ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
                                                ctypes.c_void_p(_stream())), "workspace_init")
         _ws_cache[key] = ws
+        if kind == "op" and os.environ.get("FASTKV_SELFTEST", "0") == "1":
+            from . import selftest                                  # (once per process; runs on this device with its own workspaces)
+            selftest.maybe_run_at_load(device)
     return ws
 
 

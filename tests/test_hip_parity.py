@@ -1010,6 +1010,23 @@ def test_a_slow_entry_does_not_disturb_the_entries_beside_it(dev):
     assert load().fastkv_placement_violations(0) == 0                     # (the placement check of every launch so far in this process)
 
 
+def test_load_time_selftest_of_the_co_residency_fixes(dev):
+    """fastkv_amd/selftest.py (FASTKV_SELFTEST=1 runs it behind the first workspace initialisation): 16 entries with one slow
+    (NaN-window) entry, compressed together 100 times on the fp32 contract, against the same entries compressed one by one -- the
+    product checking itself for the round-3 damage without the oracle.  0 differing launches; and the env-gated hook runs it."""
+    from fastkv_amd import selftest
+    assert selftest.co_residency(100, dev) == 0
+    r = _child("""
+import torch, time
+from fastkv_amd import ops, selftest
+q = torch.randn(1, 600, 8, 128, device='cuda').half().transpose(1, 2); k = torch.randn(1, 600, 2, 128, device='cuda').half().transpose(1, 2)
+t0 = time.time(); ops.update_kv(q, k, k, 8, 7, 'avgpool', 64); torch.cuda.synchronize()
+assert selftest._ran, 'the self-test did not run at the first workspace initialisation'
+print('child ok', round(time.time() - t0, 2))
+""", {"FASTKV_SELFTEST": "1"})
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_operator_over_separately_allocated_entries(dev):
     """fastkv_update_kv_ptrs_f16 / ops.update_kv_entries: the batch entries are separate tensors (the layers of a model whose
     compression was deferred), addressed through device-side pointer tables, processed in ONE launch sequence.  Every entry's
