@@ -61,9 +61,14 @@ typedef struct fastkv_problem {
     int32_t capacity;  /* max_capacity_prompt after the proportional rule (utils.py:86-87); window < capacity <= S */
     int32_t tsp_len;   /* 0 = no TSP on this layer; else window < tsp_len < S (utils.py:126) */
     int32_t order;     /* FASTKV_ORDER_* for the K/V rows */
-    int32_t reserved;  /* 0; tests may set bits 0-1 to force the contraction engine of the scoring kernel:
-                          1 = vector ALU (v_pk_fma_f32), 2 = FP32 matrix pipe (v_mfma_f32_32x32x2_f32); both produce the
-                          same bits (an fp32 fma chain in ascending head-dim order) */
+    int32_t reserved;  /* 0 = the library's default contraction contract (FASTKV_CONTRACTION=mfma16 | fmaf at load; mfma16 unless
+                          set).  Bits 0-1 force an engine of the scoring kernels.  Two arithmetic CONTRACTS for the fp16 matmul
+                          of utils.py:94, whose accumulation order the reference leaves open (both restated bit for bit by
+                          oracle/fastkv_oracle.c, tested against each other's oracle):
+                            3 = "mfma16": v_mfma_f32_32x32x16_f16 on the fp16 operands, chained over ascending chunks of 16
+                                dims (the default; 16x the matrix rate; tools/probes/README.md has the instruction's arithmetic)
+                            1 = vector ALU, 2 = FP32 matrix pipe (v_mfma_f32_32x32x2_f32): "fmaf", the fp32 fma chain in
+                                ascending head-dim order; the two produce the same bits */
 } fastkv_problem;
 
 /* Bytes of scratch `fastkv_update_kv_f16` / `fastkv_score_f16` need for this problem. */
