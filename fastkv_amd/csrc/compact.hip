@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
 {
     // last kernel of the operator: advance the workspace epoch after a fused score launch (fused.hip)
     if (epoch_bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const uint32_t e = *epoch_bump + 1u;
-        *epoch_bump = e ? e : 1u;
+        const uint32_t e = *epoch_bump + (uint32_t)EPOCH_STRIDE;
+        *epoch_bump = e ? e : (uint32_t)EPOCH_STRIDE;
     }
     constexpr int RPB = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) uint16_t s_keys[];   // winner keys for the ranking (dynamic: 0 B when unused)

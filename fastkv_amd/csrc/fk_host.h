@@ -14,6 +14,8 @@ constexpr size_t CTRL_BYTES = 8192;  // control block at the start of every oper
                                      // u64 magic, u32 epoch, u32 abort word (token of a launch that gave up waiting)
 constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
 constexpr int FUSED_CU_SLOTS = 2048;  // {XCC_ID, SE, SH, CU} of HW_ID as an index: who ran on a compute unit in this launch (placement check of the fused kernel)
+constexpr int EPOCH_STRIDE = 64;     // the workspace epoch advances by this much per operator call: sub-launch s of a call (< EPOCH_STRIDE) uses epoch + s, so
+                                     // no two launches ever share a hand-off token (the xor-mixed sub index could alias another epoch's token)
 constexpr int FUSED_MAX_WGS = 1024;  // (unit, span) pairs of one fused score launch -- 512 workgroups (2 per CU) x up to 2 streams: sizes its hand-off records
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 

@@ -20,8 +20,9 @@
 //   * halo: the same granules, one-to-one between adjacent workgroups.
 //   The token is a mix of the epoch in the workspace control block (fastkv_workspace_init clears the workspace once; the
 //   compaction kernel of EVERY operator call advances the epoch, whichever scoring path ran: the split selection tags its
-//   counters with the same token), never a launch argument that a graph replay would freeze: a granule left by an earlier
-//   launch never matches.
+//   counters with the same token), never a launch argument that a graph replay would freeze.  The epoch advances by EPOCH_STRIDE per
+//   operator call and the s-th scoring launch of a call (a batch that does not fit one launch) uses epoch + s, s < EPOCH_STRIDE: the
+//   tokens of all launches are distinct values of one bijective mix, so a granule left by an earlier launch never matches.
 //
 // Which workgroup works for which (entry, unit, span): numbered unit by unit, span fastest -- a launch of up to one workgroup per
 // compute unit is dispatched unit after unit and gets through a partly occupied GPU.  With more workgroups than compute units,
@@ -231,8 +232,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         if (tix == 0) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
     }
-    uint32_t token = handoff_token(ctrl[2]) ^ (sub * 0x85EBCA6Bu);     // (sub 0: the operator call's token, shared with the selection)
-    token = token ? token : 0x6B43A9B5u;
+    // (sub 0: the operator call's token, shared with the selection; the epoch advances by EPOCH_STRIDE per call, sub < EPOCH_STRIDE:
+    // the tokens of all launches are distinct values of one bijective mix)
+    const uint32_t token = handoff_token(ctrl[2] + sub);
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (tix == 0) s_abort = 0;
     // Placement check.  The pairing above ASSUMES which workgroups share a compute unit; this notices when the assumption did not hold:
@@ -1131,6 +1133,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     for (int cand = p.B; cand >= 1; --cand)
         if (fused_plan_for(p, UH, ns_pref, cand, pl, f16)) { sb = cand; break; }
     if (!sb) return false;                                       // not even one entry fits: staged path
+    if ((p.B + sb - 1) / sb > EPOCH_STRIDE) return false;        // (more scoring launches than one call's share of hand-off tokens)
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);

@@ -618,8 +618,8 @@ static hipError_t launch_logits(const fastkv_problem &p, const Layout &L, const 
 // whole operator the compaction kernel does it; the stand-alone scoring entry point launches this single thread.
 __global__ void epoch_bump_kernel(uint32_t *epoch)
 {
-    const uint32_t e = *epoch + 1u;
-    *epoch = e ? e : 1u;
+    const uint32_t e = *epoch + (uint32_t)EPOCH_STRIDE;
+    *epoch = e ? e : (uint32_t)EPOCH_STRIDE;
 }
 
 hipError_t launch_epoch_bump(uint32_t *epoch, hipStream_t st)

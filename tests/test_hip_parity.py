@@ -906,8 +906,8 @@ def test_every_operator_call_spends_its_handoff_token(dev):
     4: no fused launch) still runs the split selection, whose counters are granules tagged with the workspace's current token,
     but it used to leave the epoch where it was -- the next call (fused path, hand-off areas at other, shape-dependent
     offsets) then found granules that already carried ITS token and took a pooling halo from them.  Now every call advances
-    the epoch.  Checked directly (the epoch word of the control block moves by one per call, whatever the path) and by the
-    original sequence (cases 48 -> 49 of `stress_parity.py 60 777`), repeated."""
+    the epoch.  Checked directly (the epoch word of the control block moves by one call's share of tokens -- EPOCH_STRIDE = 64: the
+    s-th scoring launch of a call uses epoch + s, csrc/fk_host.h -- per call, whatever the path) and by the original sequence (cases 48 -> 49 of `stress_parity.py 60 777`), repeated."""
     from fastkv_amd import ops
     from oracle import fastkv_oracle as O
     c48 = dict(B=1, H=16, Hkv=8, S=16384, D=128, W=4, ks=3, cap=256, tsp_len=10882, pooling="maxpool", order="score", seed=9048)
@@ -931,9 +931,9 @@ def test_every_operator_call_spends_its_handoff_token(dev):
     w48 = run(c48)
     e0 = epoch()
     run(c48, w48)
-    assert epoch() == e0 + 1                                      # staged scoring + split selection: the token is spent all the same
+    assert epoch() == e0 + 64                                     # staged scoring + split selection: the token is spent all the same
     w49 = run(c49)
-    assert epoch() == e0 + 2
+    assert epoch() == e0 + 128
     for _ in range(6):
         run(c48, w48)
         run(c49, w49)
