@@ -189,7 +189,7 @@ def make_attention_class(base_cls, modeling, extra_attn_kwargs):
                         # static decode over the slab: append + GQA attention through the HIP decode kernels, the length is a
                         # device-side counter -> no shape changes, the step is graph-capturable (fastkv_amd/cache.py)
                         ops.decode_append(slab.kslab, slab.vslab, key_states, value_states, slab.len_dev)
-                        attn_output = ops.decode_attention(query_states, slab.kslab, slab.vslab, slab.len_dev, self.scaling, workspace=slab.decode_ws)
+                        attn_output = ops.decode_attention(query_states, slab.kslab, slab.vslab, slab.len_dev, self.scaling, workspace=slab.attn_ws)
                         slab.host_step()
                         return self.o_proj(attn_output.view(*input_shape, -1)), None
                     key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)

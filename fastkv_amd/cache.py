@@ -27,7 +27,8 @@ class SlabLayer(DynamicLayer):
         self.static_decode = False
         self.len_dev = None
         self.step_counters = None
-        self.decode_ws = None
+        self.decode_ws = None       # slice records of the fused step kernel: tagged granules, paired with step_counters
+        self.attn_ws = None         # slice records of the separate decode_attention launches (plain fp32)
 
     def _alloc(self, B, H, rows, D, dtype, device):
         self.kslab = torch.empty(B, H, rows, D, dtype=dtype, device=device)
@@ -84,8 +85,8 @@ class SlabLayer(DynamicLayer):
 
     # ---- static decode: the length lives on the device, the kernels advance it
     def enable_static_decode(self, extra_rows: int, shared=None):
-        """`shared` = (arrival counters, slice-record workspace) of the cache this layer belongs to (the layers of one cache run
-        one after the other, so they share them); a stand-alone layer gets its own."""
+        """`shared` = (step counters, step records, decode_attention records) of the cache this layer belongs to (the layers of
+        one cache run one after the other, so they share them); a stand-alone layer gets its own."""
         assert self.kslab is not None and self.kslab.is_cuda, "static decode needs a prefilled slab on the GPU"
         if self.len + extra_rows > self.kslab.shape[2]:
             self._grow(self.len + extra_rows)
@@ -97,8 +98,8 @@ class SlabLayer(DynamicLayer):
         from . import ops
         if shared is None:
             B, Hkv, _, D = self.kslab.shape
-            shared = (ops.new_step_counters(self.kslab.device), ops.new_decode_workspace(self.kslab.device, B, Hkv * 8, D))
-        self.step_counters, self.decode_ws = shared
+            shared = _new_shared(self.kslab.device, B, Hkv, D)
+        self.step_counters, self.decode_ws, self.attn_ws = shared
 
     def rows_left(self) -> int:
         """Steps the slab still has room for (host mirror of the length; graph replays do not advance it -- see reserve_steps)."""
@@ -121,6 +122,12 @@ class SlabLayer(DynamicLayer):
             self._views()
 
 
+def _new_shared(device, B, Hkv, D):
+    from . import ops
+    return (ops.new_step_counters(device), ops.new_decode_workspace(device, B, Hkv * 8, D),
+            ops.new_decode_workspace(device, B, Hkv * 8, D, ops.DECODE_NSPLIT))
+
+
 class FastKVSlabCache(Cache):
     """`DynamicCache` stand-in made of `SlabLayer`s (one per decoder layer)."""
 
@@ -135,7 +142,7 @@ class FastKVSlabCache(Cache):
         from . import ops
         first = self.layers[0]
         B, Hkv, _, D = first.kslab.shape
-        shared = (ops.new_step_counters(first.kslab.device), ops.new_decode_workspace(first.kslab.device, B, Hkv * 8, D))
+        shared = _new_shared(first.kslab.device, B, Hkv, D)
         for l in self.layers:
             l.enable_static_decode(extra_rows, shared if l.kslab.device == first.kslab.device and l.kslab.shape[:2] == first.kslab.shape[:2]
                                    and l.kslab.shape[3] == D else None)

@@ -11,6 +11,8 @@
 // HBM bound by construction (every cache byte is read once: 2*Hkv*(len+1)*D*2 bytes per layer, 9.4 MB at budget 2048 + 256
 // decoded tokens), in practice latency bound at these sizes: the slices spread a layer over 8*nsplit workgroups.
 // fp32 softmax; the result is compared with PyTorch SDPA to fp16 tolerance (tests/test_decode_gpu.py), not bit for bit.
+// These are the step's SEPARATE launches (eager callers, tests); the captured step of benchmark/e2e.py runs the whole attention
+// part as one launch: decode_step.hip.
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
@@ -35,125 +37,32 @@ __global__ void __launch_bounds__(64) decode_append_kernel(const uint16_t *__res
     *reinterpret_cast<uint4 *>(vslab + b * s_b + h * s_h + (int64_t)len * s_r + sub * 8) = vv;
 }
 
-// What the fused step kernel (STEP) needs beyond the plain slice kernel: the step's raw projections, the rotary tables, the
-// arrival counters and the output.
-struct StepArgs {
-    const uint16_t *k_new; int64_t kn_b, kn_h;                   // [B,Hkv,1,D] raw k_proj output of the step
-    const uint16_t *v_new; int64_t vn_b, vn_h;
-    const uint16_t *cosv, *sinv; int64_t cs_b;                   // [B,1,D]
-    uint32_t *counters;                                          // [1 + B*Hkv], zero between launches
-    uint16_t *out; int H;                                        // [B,1,H*D]
-    uint32_t *host_flag;                                         // pinned status words of the process (capi.hip); [1] = slab overrun
-};
-
-// rotate-half RoPE of element d of a head row x[0..D): the stock fp16 sequence (see decode_rope_kernel)
-__device__ __forceinline__ uint16_t rope_elem(const uint16_t *x, const uint16_t *cosv, const uint16_t *sinv, int d, int D)
-{
-    const int h = D / 2;
-    const float c = h2f(cosv[d]), sn = h2f(sinv[d]);
-    const float xa = h2f(x[d]), xb = d < h ? -h2f(x[d + h]) : h2f(x[d - h]);
-    return f2h(h2f(f2h(xa * c)) + h2f(f2h(xb * sn)));
-}
-
 // part[b][h][c] = {m, l, o[D]} (fp32).  grid (nsplit, Hkv, B), 256 threads.
-// STEP = the whole attention part of a one-token step in ONE launch: q arrives raw and is rotated here; the step's K row is
-// rotated and written to slab row *len_dev together with the V row by the workgroup whose slice holds that row (which takes
-// both from LDS, not from the row it has just written); the workgroup that finishes LAST for its KV head merges the head's
-// slices and writes the fp16 output, the one that finishes last of all advances *len_dev.  Arrival is counted with device-scope
-// atomics behind write-through stores of the slice records (the counters are zero again when the launch ends: replayable).
-template <int D, int G, bool STEP>
+template <int D, int G>
 __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint16_t *__restrict__ q, int64_t q_b, int64_t q_h,
-                                                                   uint16_t *__restrict__ kslab,
-                                                                   uint16_t *__restrict__ vslab, int64_t s_b, int64_t s_h,
-                                                                   int64_t s_r, int rows, int32_t *__restrict__ len_dev,
-                                                                   float scaling, float *__restrict__ part, int nsplit, StepArgs sa)
+                                                                   const uint16_t *__restrict__ kslab,
+                                                                   const uint16_t *__restrict__ vslab, int64_t s_b, int64_t s_h,
+                                                                   int64_t s_r, int rows, const int32_t *__restrict__ len_dev,
+                                                                   float scaling, float *__restrict__ part, int nsplit)
 {
     constexpr int DPL = D / 64;                                  // head-dim elements per lane in the P.V product
     __shared__ float s_q[G][D];
     __shared__ float s_p[4][G][64];
     __shared__ float s_m[4][G], s_l[4][G];
     __shared__ float s_o[4][G][D];
-    __shared__ __attribute__((aligned(16))) uint16_t s_knew[STEP ? D : 8], s_vnew[STEP ? D : 8];
-    __shared__ float s_snew[G];
-    __shared__ int s_last;
     const int c = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int RB = DPL <= 2 ? 64 : 32;                       // V rows in flight per batch
     const uint16_t *kb = kslab + b * s_b + hk * s_h, *vb = vslab + b * s_b + hk * s_h;
-    // STEP: the slices partition the slab's CAPACITY, not its current length, so that a wave can request the K and V rows of
-    // its first tile before anything else -- the length, the query, the rotary tables and the new row arrive during the same
-    // memory round trip instead of in two earlier ones.  Rows at or beyond the length are in bounds, loaded and never used.
-    const int span = STEP ? rows : 0;
     uint4 kv[D / 8];
     uint32_t vv[RB][(DPL + 1) / 2];
-    bool loaded = false;
-    if (STEP) {
-        const int chunk_s = ((span + nsplit - 1) / nsplit + 63) / 64 * 64;
-        const int lo_s = c * chunk_s, hi_s = min(span, lo_s + chunk_s), t0 = lo_s + w * 64;
-        if (t0 < hi_s) {
-            const uint16_t *kr = kb + (int64_t)min(t0 + lane, hi_s - 1) * s_r;
-#pragma unroll
-            for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const uint16_t *vr = vb + (int64_t)min(t0 + u, hi_s - 1) * s_r + lane * DPL;
-                if (DPL == 1) vv[u][0] = *vr;
-                else if (DPL == 2) vv[u][0] = *reinterpret_cast<const uint32_t *>(vr);
-                else { const uint2 x = *reinterpret_cast<const uint2 *>(vr); vv[u][0] = x.x; vv[u][1] = x.y; }
-            }
-            loaded = true;
-        }
-    }
-    const int len_old = *len_dev;
-    int len = len_old + 1;                                       // the step's own row is row *len_dev
+    int len = *len_dev + 1;                                      // the step's own row is row *len_dev (decode_append wrote it)
     if (len > rows) len = rows;
-    const int jnew = len - 1;                                    // (a full slab overwrites its last row: the host sizes it)
-    const int chunk = (((STEP ? span : len) + nsplit - 1) / nsplit + 63) / 64 * 64;
+    const int chunk = ((len + nsplit - 1) / nsplit + 63) / 64 * 64;
     const int lo = c * chunk, hi = min(len, lo + chunk);
-    const bool owner = STEP && jnew >= lo && jnew < hi;          // this workgroup's slice holds the step's row
-    if (STEP) {
-        for (int i = threadIdx.x; i < G * D; i += DEC_THREADS) {
-            const int g = i / D, d = i - g * D;
-            s_q[g][d] = h2f(rope_elem(q + b * q_b + (int64_t)(hk * G + g) * q_h, sa.cosv + b * sa.cs_b, sa.sinv + b * sa.cs_b, d, D)) * scaling;
-        }
-        if (owner) {
-            if ((int)threadIdx.x < D) {
-                const int d = threadIdx.x;
-                s_knew[d] = rope_elem(sa.k_new + b * sa.kn_b + (int64_t)hk * sa.kn_h, sa.cosv + b * sa.cs_b, sa.sinv + b * sa.cs_b, d, D);
-                s_vnew[d] = sa.v_new[b * sa.vn_b + (int64_t)hk * sa.vn_h + d];
-            }
-        }
-        __syncthreads();
-        if (owner) {
-            // the row goes to the slab for the steps to come ...
-            if ((int)threadIdx.x < D / 8) {
-                const int u = threadIdx.x;
-                *reinterpret_cast<uint4 *>(kslab + b * s_b + hk * s_h + (int64_t)jnew * s_r + u * 8) = *reinterpret_cast<const uint4 *>(s_knew + u * 8);
-                *reinterpret_cast<uint4 *>(vslab + b * s_b + hk * s_h + (int64_t)jnew * s_r + u * 8) = *reinterpret_cast<const uint4 *>(s_vnew + u * 8);
-            }
-            // ... and its scores are taken from LDS
-            if (w < G) {
-                float a = 0.0f;
-                for (int d = lane; d < D; d += 64) a = __builtin_fmaf(s_q[w][d], h2f(s_knew[d]), a);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-                if (lane == 0) s_snew[w] = a;
-            }
-            if (G > 4 && w == 0) {
-                for (int g = 4; g < G; ++g) {
-                    float a = 0.0f;
-                    for (int d = lane; d < D; d += 64) a = __builtin_fmaf(s_q[g][d], h2f(s_knew[d]), a);
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-                    if (lane == 0) s_snew[g] = a;
-                }
-            }
-        }
-    } else {
-        for (int i = threadIdx.x; i < G * D; i += DEC_THREADS) {
-            const int g = i / D, d = i - g * D;
-            s_q[g][d] = h2f(q[b * q_b + (int64_t)(hk * G + g) * q_h + d]) * scaling;
-        }
+    for (int i = threadIdx.x; i < G * D; i += DEC_THREADS) {
+        const int g = i / D, d = i - g * D;
+        s_q[g][d] = h2f(q[b * q_b + (int64_t)(hk * G + g) * q_h + d]) * scaling;
     }
     __syncthreads();
     float m[G], l[G], o[G][DPL];
@@ -186,28 +95,19 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
                 else { const uint2 x = *reinterpret_cast<const uint2 *>(vr); vv[u][0] = x.x; vv[u][1] = x.y; }
             }
         };
-        {
-            if (!loaded) {                                       // the whole row in flight: one round trip per tile
 #pragma unroll
-                for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
-                load_v(0);
+        for (int u = 0; u < D / 8; ++u) kv[u] = *reinterpret_cast<const uint4 *>(kr + u * 8);
+        load_v(0);
+#pragma unroll
+        for (int u = 0; u < D / 8; ++u) {
+            const uint32_t wds[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float k0 = h2f((uint16_t)(wds[e] & 0xffffu)), k1 = h2f((uint16_t)(wds[e] >> 16));
+                const int d = u * 8 + e * 2;
+#pragma unroll
+                for (int g = 0; g < G; ++g) sc[g] = __builtin_fmaf(s_q[g][d + 1], k1, __builtin_fmaf(s_q[g][d], k0, sc[g]));
             }
-            loaded = false;
-#pragma unroll
-            for (int u = 0; u < D / 8; ++u) {
-                const uint32_t wds[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float k0 = h2f((uint16_t)(wds[e] & 0xffffu)), k1 = h2f((uint16_t)(wds[e] >> 16));
-                    const int d = u * 8 + e * 2;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sc[g] = __builtin_fmaf(s_q[g][d + 1], k1, __builtin_fmaf(s_q[g][d], k0, sc[g]));
-                }
-            }
-        }
-        if (STEP && owner && j == jnew) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) sc[g] = s_snew[g];
         }
         // ---- online softmax of the tile (wave-wide), probabilities to LDS
 #pragma unroll
@@ -234,21 +134,12 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 if (r0 + u < nrow) {
-                    uint32_t vw[(DPL + 1) / 2];
-#pragma unroll
-                    for (int e = 0; e < (DPL + 1) / 2; ++e) vw[e] = vv[u][e];
-                    if (STEP && owner && t0 + r0 + u == jnew) {   // (wave-uniform) the step's own V row: from LDS, not from the slab
-                        const uint16_t *vl = s_vnew + lane * DPL;
-                        if (DPL == 1) vw[0] = *vl;
-                        else if (DPL == 2) vw[0] = *reinterpret_cast<const uint32_t *>(vl);
-                        else { const uint2 x = *reinterpret_cast<const uint2 *>(vl); vw[0] = x.x; vw[(DPL + 1) / 2 - 1] = x.y; }
-                    }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float p = s_p[w][g][r0 + u];
 #pragma unroll
                         for (int e = 0; e < DPL; ++e) {
-                            const uint32_t wd = vw[e / 2];
+                            const uint32_t wd = vv[u][e / 2];
                             o[g][e] = __builtin_fmaf(p, h2f((uint16_t)((e & 1) ? wd >> 16 : wd & 0xffffu)), o[g][e]);
                         }
                     }
@@ -277,71 +168,8 @@ __global__ void __launch_bounds__(DEC_THREADS) decode_partial_kernel(const uint1
             O += s_o[ww][g][d] * f;
         }
         float *rec = part + (((size_t)b * gridDim.y * G + hk * G + g) * nsplit + c) * (D + 2);
-        if (STEP) {
-            __hip_atomic_store(rec + 2 + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 0) {
-                __hip_atomic_store(rec, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(rec + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            rec[2 + d] = O;
-            if (d == 0) { rec[0] = M; rec[1] = L; }
-        }
-    }
-    if (!STEP) return;
-    // ---- arrival: this slice's record has reached memory (write-through stores, drained) before the counter moves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint32_t *cnt_head = sa.counters + 1 + b * gridDim.y + hk;
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(cnt_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(nsplit - 1);
-    __syncthreads();
-    if (s_last) {
-        // every load of another workgroup's record is a device-scope (L2-bypassing) load: a thread requests the maxima, sums
-        // and its D-element of sixteen slices at once -- one memory round trip for the merge (nsplit <= 64: four at most)
-        const float *rec0 = part + (size_t)(b * gridDim.y + hk) * G * nsplit * (D + 2);
-        for (int i = threadIdx.x; i < G * D; i += DEC_THREADS) {
-            const int g = i / D, d = i - g * D;
-            const float *rec = rec0 + (size_t)g * nsplit * (D + 2);
-            float M = -INFINITY, L = 0.0f, O = 0.0f;
-            for (int c0 = 0; c0 < nsplit; c0 += 16) {
-                float mv[16], lv[16], ov[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const float *r1 = rec + (size_t)min(c0 + u, nsplit - 1) * (D + 2);
-                    mv[u] = __hip_atomic_load(r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lv[u] = __hip_atomic_load(r1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ov[u] = __hip_atomic_load(r1 + 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                float Mn = M;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (c0 + u < nsplit) Mn = fmaxf(Mn, mv[u]);
-                const float corr = M == -INFINITY ? 0.0f : __expf(M - Mn);
-                L *= corr;
-                O *= corr;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (c0 + u < nsplit) {
-                        const float f = mv[u] == -INFINITY ? 0.0f : __expf(mv[u] - Mn);
-                        L += lv[u] * f;
-                        O += ov[u] * f;
-                    }
-                }
-                M = Mn;
-            }
-            sa.out[((size_t)b * sa.H + hk * G + g) * D + d] = f2h(O / L);
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(cnt_head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the last workgroup of the launch advances the length: every workgroup has read the old one long ago
-    if (threadIdx.x == 0) {
-        const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
-        if (__hip_atomic_fetch_add(sa.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-            __hip_atomic_store(sa.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *len_dev = len_old + 1 < rows ? len_old + 1 : rows;
-            // a step into a FULL slab has overwritten the last cached row and the length stays where it is: wrong tokens from
-            // here on.  Reported, not silent: fastkv_last_status() / the next operator call return FASTKV_EOVERFLOW.
-            if (len_old >= rows && sa.host_flag) __hip_atomic_store(sa.host_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        rec[2 + d] = O;
+        if (d == 0) { rec[0] = M; rec[1] = L; }
     }
 }
 
@@ -453,12 +281,6 @@ using namespace fk;
 
 extern "C" {
 
-size_t fastkv_decode_workspace_bytes(int32_t B, int32_t H, int32_t D, int32_t nsplit)
-{
-    if (B < 1 || H < 1 || nsplit < 1) return 0;
-    return align_up((size_t)B * H * nsplit * (D + 2) * sizeof(float), 256);
-}
-
 int fastkv_decode_append_f16(int32_t B, int32_t Hkv, int32_t D, const void *k_new, const int64_t kn_strides[2], const void *v_new,
                              const int64_t vn_strides[2], void *kslab, void *vslab, const int64_t slab_strides[3], int32_t rows,
                              const int32_t *len_dev, void *stream)
@@ -501,9 +323,9 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
     {
         ProfScope ps_(K_DECODE, st);
 #define FK_PART(DV, GV)                                                                                                              \
-    hipLaunchKernelGGL((decode_partial_kernel<DV, GV, false>), grid, dim3(DEC_THREADS), 0, st, (const uint16_t *)q, q_strides[0], q_strides[1], \
-                       (uint16_t *)kslab, (uint16_t *)vslab, slab_strides[0], slab_strides[1], slab_strides[2], rows,     \
-                       len_dev, scaling, part, nsplit, StepArgs{})
+    hipLaunchKernelGGL((decode_partial_kernel<DV, GV>), grid, dim3(DEC_THREADS), 0, st, (const uint16_t *)q, q_strides[0], q_strides[1], \
+                       (const uint16_t *)kslab, (const uint16_t *)vslab, slab_strides[0], slab_strides[1], slab_strides[2], rows, \
+                       len_dev, scaling, part, nsplit)
 #define FK_PART_G(DV)                                                                                      \
     do {                                                                                                   \
         if (G == 1) FK_PART(DV, 1); else if (G == 2) FK_PART(DV, 2); else if (G == 4) FK_PART(DV, 4); else FK_PART(DV, 8); \
@@ -519,46 +341,6 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
     if (D == 64) hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(H, B), dim3(64), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows, abort_flag_device());
     else if (D == 128) hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(H, B), dim3(128), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows, abort_flag_device());
     else hipLaunchKernelGGL((decode_combine_kernel<256>), dim3(H, B), dim3(256), 0, st, part, nsplit, (uint16_t *)out, H, len_dev, rows, abort_flag_device());
-    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
-}
-
-int fastkv_decode_step_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, const void *q, const int64_t q_strides[2],
-                                     const void *k_new, const int64_t kn_strides[2], const void *v_new, const int64_t vn_strides[2],
-                                     const void *cosv, const void *sinv, int64_t cs_batch_stride, void *kslab, void *vslab,
-                                     const int64_t slab_strides[3], int32_t rows, int32_t *len_dev, float scaling, int32_t nsplit,
-                                     void *out, void *workspace, size_t workspace_bytes, void *counters, void *stream)
-{
-    if (B < 1 || Hkv < 1 || H < Hkv || (H % Hkv) || rows < 1 || nsplit < 1 || nsplit > 64 || (size_t)B * Hkv + 1 > 1024) return FASTKV_EINVAL;
-    if (!q || !k_new || !v_new || !cosv || !sinv || !kslab || !vslab || !len_dev || !out || !workspace || !counters || !q_strides ||
-        !kn_strides || !vn_strides || !slab_strides)
-        return FASTKV_EINVAL;
-    if (D != 64 && D != 128 && D != 256) return FASTKV_EUNSUPPORTED;
-    const int G = H / Hkv;
-    if (G != 1 && G != 2 && G != 4 && G != 8) return FASTKV_EUNSUPPORTED;
-    if (((uintptr_t)kslab | (uintptr_t)vslab) & 15) return FASTKV_EINVAL;
-    for (int i = 0; i < 3; ++i) if (slab_strides[i] & 7) return FASTKV_EINVAL;
-    if (workspace_bytes < fastkv_decode_workspace_bytes(B, H, D, nsplit)) return FASTKV_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    StepArgs sa;
-    sa.k_new = (const uint16_t *)k_new; sa.kn_b = kn_strides[0]; sa.kn_h = kn_strides[1];
-    sa.v_new = (const uint16_t *)v_new; sa.vn_b = vn_strides[0]; sa.vn_h = vn_strides[1];
-    sa.cosv = (const uint16_t *)cosv; sa.sinv = (const uint16_t *)sinv; sa.cs_b = cs_batch_stride;
-    sa.counters = (uint32_t *)counters; sa.out = (uint16_t *)out; sa.H = H; sa.host_flag = abort_flag_device();
-    dim3 grid(nsplit, Hkv, B);
-    ProfScope ps_(K_DECODE, st);
-#define FK_STEP(DV, GV)                                                                                                                 \
-    hipLaunchKernelGGL((decode_partial_kernel<DV, GV, true>), grid, dim3(DEC_THREADS), 0, st, (const uint16_t *)q, q_strides[0], q_strides[1], \
-                       (uint16_t *)kslab, (uint16_t *)vslab, slab_strides[0], slab_strides[1], slab_strides[2], rows, len_dev, scaling, \
-                       (float *)workspace, nsplit, sa)
-#define FK_STEP_G(DV)                                                                                      \
-    do {                                                                                                   \
-        if (G == 1) FK_STEP(DV, 1); else if (G == 2) FK_STEP(DV, 2); else if (G == 4) FK_STEP(DV, 4); else FK_STEP(DV, 8); \
-    } while (0)
-    if (D == 64) FK_STEP_G(64);
-    else if (D == 128) FK_STEP_G(128);
-    else FK_STEP_G(256);
-#undef FK_STEP_G
-#undef FK_STEP
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -389,60 +389,71 @@ def decode_gemv(x: torch.Tensor, weights, norm_weight: Optional[torch.Tensor] = 
 
 
 _step_counters = {}
+_step_ws = {}
+DECODE_STEP_NSPLIT = int(os.environ.get("FASTKV_DECODE_STEP_NSPLIT", "0"))     # 0: the library chooses (one 128-row tile per slice)
 
 
 def new_step_counters(device: torch.device) -> torch.Tensor:
-    """Arrival counters of the fused step kernel (zero between launches).  A cache slab owns its own set (allocated eagerly by
-    SlabLayer.enable_static_decode -- never for the first time inside a graph capture, where the allocation would live in the
-    graph's private pool and its zero-fill would be replayed with every step), so steps over different caches may run
-    concurrently and a capture only ever records launches."""
+    """State of the fused step kernel between launches: word 0 counts the workgroups that have read the cache length (zero between
+    launches), word 1 is the launch epoch that tags the slice records of `new_decode_workspace` (only ever advanced).  A cache slab owns
+    its own set (allocated eagerly by SlabLayer.enable_static_decode -- never for the first time inside a graph capture, where the
+    allocation would live in the graph's private pool and its zero-fill would be replayed with every step), so steps over different
+    caches may run concurrently and a capture only ever records launches."""
     return torch.zeros(1024, dtype=torch.int32, device=device)
 
 
 def new_decode_workspace(device: torch.device, B: int, H: int, D: int, nsplit: int = 0) -> torch.Tensor:
-    """Slice-record scratch of decode_attention / decode_step_attention for up to H query heads (uninitialised: every record is
-    written before it is read)."""
-    n = load().fastkv_decode_workspace_bytes(B, H, D, nsplit or DECODE_NSPLIT)
-    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+    """Slice-record scratch of decode_step_attention / decode_attention for up to H query heads.  ZERO-filled: the step kernel's records
+    are {launch token, value} granules that a reader accepts by their token (never 0), so the memory must not hold anything that
+    could pass for one -- it belongs to ONE set of step counters (whose epoch the tokens come from) for good."""
+    n = load().fastkv_decode_workspace_bytes(B, H, D, nsplit)
+    return torch.zeros(max(int(n), 256), dtype=torch.uint8, device=device)
 
 
-def _default_counters(device: torch.device) -> torch.Tensor:
-    # callers without a slab object (tests, tools): one set per (device, stream), allocated outside captures only
+def _default_step_state(device: torch.device, need: int):
+    # callers without a slab object (tests, tools): one {counters, records} pair per (device, stream), allocated outside captures only
     key = (device.index, _stream())
-    cnt = _step_counters.get(key)
-    if cnt is None:
+    cnt, ws = _step_counters.get(key), _step_ws.get(key)
+    if cnt is None or ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("fastkv_amd.decode_step_attention: pass `counters` (ops.new_step_counters, allocated before the "
-                               "capture) when the step is captured in a graph")
-        cnt = _step_counters[key] = new_step_counters(device)
-    return cnt
+            raise RuntimeError("fastkv_amd.decode_step_attention: pass `counters` and `workspace` (ops.new_step_counters / "
+                               "ops.new_decode_workspace, allocated before the capture) when the step is captured in a graph")
+        if cnt is None:
+            cnt = _step_counters[key] = new_step_counters(device)
+        if ws is None or ws.numel() < need:
+            ws = _step_ws[key] = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=device)
+    return cnt, ws
 
 
 def reset_decode_state(*counters: torch.Tensor) -> None:
-    """After a reported error (FASTKV_EABORTED, a killed kernel) arrival counters may be non-zero for good: zero them from the
-    host before the next step (the given ones, and every default set)."""
+    """After a reported error (FASTKV_EABORTED, a killed kernel) the arrival counter may be non-zero for good: zero it from the
+    host before the next step (the given sets, and every default set).  The epoch word stays: tokens are never reused."""
     for c in list(counters) + list(_step_counters.values()):
-        c.zero_()
+        c[:1].zero_()
 
 
 def decode_step_attention(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                           kslab: torch.Tensor, vslab: torch.Tensor, len_dev: torch.Tensor, scaling: float, nsplit: int = 0,
                           counters: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """RoPE + append + GQA attention + slice merge of a one-token step in ONE launch: q [B,H,1,D] / k_new, v_new [B,Hkv,1,D] are
-    the RAW projections, cos / sin [B,1,D] fp16; returns fp16 [B,1,H*D], the slab gains the row, len_dev is advanced."""
+    """RoPE + append + GQA attention + slice merge of a one-token step in ONE launch (csrc/decode_step.hip): q [B,H,1,D] / k_new,
+    v_new [B,Hkv,1,D] are the RAW projections, cos / sin [B,1,D] fp16; returns fp16 [B,1,H*D], the slab gains the row, len_dev is
+    advanced.  `counters` + `workspace` come as a pair (new_step_counters / new_decode_workspace); nsplit 0 = the library chooses."""
     _require_cuda(q, k_new, v_new, cos, sin, kslab, vslab, len_dev)
     B, H, one, D = q.shape
     Hkv, rows = kslab.shape[1], kslab.shape[2]
     assert one == 1 and q.stride(3) == 1 and k_new.shape == (B, Hkv, 1, D) and v_new.shape == k_new.shape and k_new.stride(3) == 1 \
         and v_new.stride(3) == 1 and cos.shape == (B, 1, D) and cos.stride(2) == 1 and sin.stride() == cos.stride() \
         and cos.dtype == torch.float16 and q.dtype == torch.float16 and kslab.stride() == vslab.stride() and len_dev.dtype == torch.int32
-    nsplit = nsplit or DECODE_NSPLIT
+    nsplit = nsplit or DECODE_STEP_NSPLIT
     L = load()
     out = torch.empty(B, 1, H * D, dtype=torch.float16, device=q.device)
     need = L.fastkv_decode_workspace_bytes(B, H, D, nsplit)
-    ws = workspace if workspace is not None and workspace.numel() >= need else _workspace(need, q.device, "decode")
-    cnt = counters if counters is not None else _default_counters(q.device)
-    assert cnt.dtype == torch.int32 and cnt.numel() >= 1 + B * Hkv and cnt.is_cuda
+    assert (counters is None) == (workspace is None), "counters and workspace of the step kernel come as a pair"
+    if counters is None:
+        cnt, ws = _default_step_state(q.device, need)
+    else:
+        cnt, ws = counters, workspace
+    assert cnt.dtype == torch.int32 and cnt.numel() >= 2 and cnt.is_cuda and ws.numel() >= need
     I2, I3 = ctypes.c_int64 * 2, ctypes.c_int64 * 3
     rc = L.fastkv_decode_step_attention_f16(B, H, Hkv, D, q.data_ptr(), I2(q.stride(0), q.stride(1)), k_new.data_ptr(),
                                             I2(k_new.stride(0), k_new.stride(1)), v_new.data_ptr(), I2(v_new.stride(0), v_new.stride(1)),

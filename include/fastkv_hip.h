@@ -352,11 +352,15 @@ int fastkv_decode_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, co
  *   rope      apply_rotary_pos_emb on q [B,H,1,D] and k [B,Hkv,1,D] IN PLACE (strides {batch, head}); cos / sin [B,1,D]
  *   silu_mul  act_fn(gate) * up of the MLP, n elements (multiple of 8)
  */
-/* The attention part of a one-token step in ONE launch (RoPE + append + attention + merge: what
+/* The attention part of a one-token step in ONE launch (csrc/decode_step.hip; RoPE + append + attention + merge: what
  * fastkv_decode_rope_f16 + fastkv_decode_append_f16 + fastkv_decode_attention_f16 do in four): q / k_new / v_new are the RAW
  * projections of the step, cos / sin [B,1,D] the rotary tables of its position; the rotated K row and the V row are written to
- * slab row *len_dev, the output is fp16 [B,1,H*D], *len_dev is advanced.  `counters`: 1024 uint32 of device memory, zeroed
- * ONCE by the caller; the launch leaves them zero (graph-replayable). */
+ * slab row *len_dev, the output is fp16 [B,1,H*D], *len_dev is advanced.  nsplit: slices per KV head, <= 0 = the library
+ * chooses (one 128-row tile per slice).  `counters`: 1024 uint32 of device memory, zeroed ONCE by the caller -- word 0 (arrivals)
+ * is zero again when a launch ends, word 1 is the launch epoch and only ever grows; `workspace`
+ * (fastkv_decode_workspace_bytes; nsplit <= 0 there = room for every choice) holds the slices' records as {epoch token, value}
+ * granules: ZERO it once, give it to ONE counters block for good, let nothing else write to it.  Graph-replayable.
+ * B*Hkv <= 65535. */
 int fastkv_decode_step_attention_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, const void *q, const int64_t q_strides[2],
                                      const void *k_new, const int64_t kn_strides[2], const void *v_new, const int64_t vn_strides[2],
                                      const void *cosv, const void *sinv, int64_t cs_batch_stride, void *kslab, void *vslab,
