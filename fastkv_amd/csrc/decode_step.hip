@@ -122,20 +122,38 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
     if (lane == 0) g_dstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 2048 * 16 + 13] = __builtin_amdgcn_s_getreg(63508) | ((uint64_t)__builtin_amdgcn_s_getreg(63492) << 32);
 #endif
 
-    // ---- everything the step needs from memory is requested NOW, in one round trip: the raw q rows / new K row with their rotary
-    //      factors (16-B pieces: thread = 8 dims of the lower half of a row and the 8 dims they rotate with), the new V row, the
-    //      length, the records' epoch, and the wave's first K / V tile (rows at or beyond the length are in bounds, loaded and never used)
-    const bool rope_item = !merger && tid < NR, v_item = !merger && tid >= NR && tid < NR + D / 8;
-    uint4 x1 = make_uint4(0, 0, 0, 0), x2 = x1, c1 = x1, c2 = x1, s1 = x1, s2 = x1, vn = x1;
-    const int ritem = tid < NQ ? tid / DB : G, d0 = (tid < NQ ? tid - ritem * DB : tid - NQ) * 8;
-    if (rope_item) {
-        const uint16_t *xr = tid < NQ ? q + b * q_b + (int64_t)(hk * G + ritem) * q_h : sa.k_new + b * sa.kn_b + (int64_t)hk * sa.kn_h;
-        const uint16_t *cs = sa.cosv + b * sa.cs_b, *sn = sa.sinv + b * sa.cs_b;
-        x1 = *reinterpret_cast<const uint4 *>(xr + d0);  x2 = *reinterpret_cast<const uint4 *>(xr + d0 + D / 2);
-        c1 = *reinterpret_cast<const uint4 *>(cs + d0);  c2 = *reinterpret_cast<const uint4 *>(cs + d0 + D / 2);
-        s1 = *reinterpret_cast<const uint4 *>(sn + d0);  s2 = *reinterpret_cast<const uint4 *>(sn + d0 + D / 2);
-    }
-    if (v_item) vn = *reinterpret_cast<const uint4 *>(sa.v_new + b * sa.vn_b + (int64_t)hk * sa.vn_h + (tid - NR) * 8);
+    // ---- the length is advanced by the workgroup that is the LAST to report that it has read it (and the records' epoch with it)
+    auto report_length_read = [&](int len_old, uint32_t epoch) {
+        if (tid == 0) {
+            uint32_t inc = 1;
+            asm volatile("" : "+v"(inc) : "v"(len_old), "v"(epoch));  // (the increment depends on both loads: the atomic cannot overtake them)
+            const uint32_t arrive = __hip_atomic_fetch_add(sa.counters, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrive == gridDim.x * gridDim.y - 1) {
+                __hip_atomic_store(sa.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sa.counters[1] = epoch + 1u;
+                *len_dev = len_old + 1 < rows ? len_old + 1 : rows;
+                // a step into a FULL slab has overwritten the last cached row and the length stays where it is: wrong tokens from
+                // here on.  Reported, not silent: fastkv_last_status() / the next operator call return FASTKV_EOVERFLOW.
+                if (len_old >= rows && sa.host_flag) __hip_atomic_store(sa.host_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    uint64_t *rec_head = rec + (size_t)hb * nsplit * G * (D + 2);
+    if (!merger) {
+    // ---- everything the step needs from memory is requested NOW, in one round trip and in straight-line code (the compiler's wait
+    //      counts are exact only then: the rotation below waits for ITS loads, not for the tile): the raw q rows / new K row with
+    //      their rotary factors (16-B pieces: thread = 8 dims of the lower half of a row and the 8 dims they rotate with; threads
+    //      beyond the work items repeat the last one), the new V row, the length, the records' epoch, and the wave's first K / V
+    //      tile (rows at or beyond the length, or the slab, are clamped / in bounds, loaded and never used)
+    const bool rope_item = tid < NR, v_item = tid >= NR && tid < NR + D / 8;
+    const int rt = tid < NR ? tid : NR - 1;
+    const int ritem = rt < NQ ? rt / DB : G, d0 = (rt < NQ ? rt - ritem * DB : rt - NQ) * 8;
+    const uint16_t *xr = rt < NQ ? q + b * q_b + (int64_t)(hk * G + ritem) * q_h : sa.k_new + b * sa.kn_b + (int64_t)hk * sa.kn_h;
+    const uint16_t *cs = sa.cosv + b * sa.cs_b, *sn = sa.sinv + b * sa.cs_b;
+    const uint4 x1 = *reinterpret_cast<const uint4 *>(xr + d0), x2 = *reinterpret_cast<const uint4 *>(xr + d0 + D / 2);
+    const uint4 c1 = *reinterpret_cast<const uint4 *>(cs + d0), c2 = *reinterpret_cast<const uint4 *>(cs + d0 + D / 2);
+    const uint4 s1 = *reinterpret_cast<const uint4 *>(sn + d0), s2 = *reinterpret_cast<const uint4 *>(sn + d0 + D / 2);
+    const uint4 vn = *reinterpret_cast<const uint4 *>(sa.v_new + b * sa.vn_b + (int64_t)hk * sa.vn_h + ((tid >= NR ? tid - NR : tid) % (D / 8)) * 8);
     const int len_old = *len_dev;
     const uint32_t epoch = sa.counters[1];
     uint4 kf[KB][NC];
@@ -165,22 +183,14 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
             }
         }
     };
-    bool loaded = false;
-    if (!merger && lo + w * ST_TILE < min(rows, lo + chunk)) { load_tile(lo + w * ST_TILE); loaded = true; }
-
-    // ---- "I have read the length": reported as soon as the read has returned, looked at when the workgroup ends
-    uint32_t arrive = 0;
-    if (tid == 0) {
-        uint32_t inc = 1;
-        asm volatile("" : "+v"(inc) : "v"(len_old), "v"(epoch));  // (the increment depends on both loads: the atomic cannot overtake them)
-        arrive = __hip_atomic_fetch_add(sa.counters, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __builtin_amdgcn_sched_barrier(0);                           // (the scheduler would issue the tile's loads first: in-order return, the rotation would wait for them)
+    load_tile(lo + w * ST_TILE);
+    bool loaded = true;
     FKD_STAMP(1);
     const uint32_t token = handoff_token(epoch);
     const int jnew = min(len_old, rows - 1);                     // the step's own row (a full slab overwrites its last row: reported below)
-    const bool owner = !merger && jnew >= lo && jnew < lo + chunk;
-    const bool live = !merger && lo <= jnew;
-    uint64_t *rec_head = rec + (size_t)hb * nsplit * G * (D + 2);
+    const bool owner = jnew >= lo && jnew < lo + chunk;
+    const bool live = lo <= jnew;
 
     if (live) {
         // rotate-half RoPE, the stock fp16 sequence rounding for rounding (decode.hip decode_rope_kernel): x*cos -> fp16,
@@ -335,7 +345,16 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
             }
         }
         FKD_STAMP(5);
-    } else if (merger) {
+    }
+    // "I have read the length": a producer says so when it is done (the answer costs a trip to memory that nothing here should wait for)
+    report_length_read(len_old, epoch);
+    FKD_STAMP(12);
+    } else {
+        const int len_old = *len_dev;
+        const uint32_t epoch = sa.counters[1];
+        report_length_read(len_old, epoch);                      // (the merger has nothing else to do yet)
+        const uint32_t token = handoff_token(epoch);
+        const int jnew = min(len_old, rows - 1);
         // ---- the head's records.  A poll IS the read: every thread requests its share of ALL records of a batch of slices at once (16-B
         //      agent-scope loads of two granules: past this compute unit's L1, which another unit's stores never refresh) and repeats the
         //      whole request until every token is this launch's -- one round trip after the last record has landed.  Wave w owns values
@@ -402,20 +421,6 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
         if (dead && sa.host_flag) __hip_atomic_store(sa.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
-    // ---- the last workgroup to have read the length advances it (and the records' epoch)
-    FKD_STAMP(11);
-    if (tid == 0) {
-        const uint32_t total = gridDim.x * gridDim.y;
-        if (arrive == total - 1) {
-            __hip_atomic_store(sa.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sa.counters[1] = epoch + 1u;
-            *len_dev = len_old + 1 < rows ? len_old + 1 : rows;
-            // a step into a FULL slab has overwritten the last cached row and the length stays where it is: wrong tokens from
-            // here on.  Reported, not silent: fastkv_last_status() / the next operator call return FASTKV_EOVERFLOW.
-            if (len_old >= rows && sa.host_flag) __hip_atomic_store(sa.host_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        FKD_STAMP(12);
-    }
 }
 
 }  // namespace fk
