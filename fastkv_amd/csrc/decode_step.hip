@@ -388,31 +388,29 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
                     if (__builtin_amdgcn_s_memrealtime() > deadline) { dead = true; break; }
                 }
                 FKD_STAMP(6 + (c0 / ST_BATCH < 3 ? c0 / ST_BATCH : 3));
-                // this lane's slice: its maximum, then (the batch maximum known) its weight and weighted sum
+                // This lane's slice: its maximum; then, the batch maximum known, its weight and weighted sum.  Slices beyond the batch
+                // weigh nothing (their loads repeat the last slice): the sums below run over all ST_BATCH slots without a branch --
+                // a wave alone on its SIMD issues an instruction every 4-8 cycles, what this costs is its instruction count.
                 const float mym = msl < nb ? bits_f32(mlv[0]) : -INFINITY;
                 float bm = mym;                                  // maximum over the batch, per query head of the wave (NG halves of the wave)
 #pragma unroll
                 for (int off = 1; off < 64 / NG; off <<= 1) bm = fmaxf(bm, __shfl_xor(bm, off, 64));
-                float Mn_l = bm;                                 // (this lane's pair may belong to the other head of the wave: fetch the own head's)
-                const float Mn_mine = fmaxf(M, NG == 1 ? Mn_l : __shfl(Mn_l, (gg - ((w * 128) / D) % GP) * (64 / NG), 64));
-                // weights are computed by the lane that holds the pair, against ITS head's running maximum
-                const float Mrun_pair = NG == 1 ? M : __shfl(M, gsel * (64 / NG), 64);     // running maximum of the pair's head (lane 0 / 32 of the wave works on it)
-                const float Mn_pair = fmaxf(Mrun_pair, bm);
-                const float wgt = mym == -INFINITY ? 0.0f : __expf(mym - Mn_pair);
-                const float wl = msl < nb ? bits_f32(mlv[2]) * wgt : 0.0f;
-                const float corr = M == -INFINITY ? 0.0f : __expf(M - Mn_mine);
-                L *= corr; O0 *= corr; O1 *= corr;
-                const int lbase = NG == 1 ? 0 : (gg - ((w * 128) / D) % GP) * (64 / NG);
+                const float Mn = fmaxf(M, bm);                   // (a lane's pair and its values belong to the same head: its half of the wave)
+                const float wgt = mym == -INFINITY ? 0.0f : __expf(mym - Mn);
+                float wl = msl < nb ? bits_f32(mlv[2]) * wgt : 0.0f;
+#pragma unroll
+                for (int off = 1; off < 64 / NG; off <<= 1) wl += __shfl_xor(wl, off, 64);
+                const float corr = M == -INFINITY ? 0.0f : __expf(M - Mn);
+                L = L * corr + wl; O0 *= corr; O1 *= corr;
 #pragma unroll
                 for (int u = 0; u < ST_BATCH; ++u) {
-                    if (u < nb) {
-                        float f, fl;
-                        if (NG == 1) { f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wgt), u)); fl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), u)); }
-                        else { f = __shfl(wgt, lbase + u, 64); fl = __shfl(wl, lbase + u, 64); }
-                        L += fl; O0 += bits_f32(ov[u][0]) * f; O1 += bits_f32(ov[u][2]) * f;
-                    }
+                    float f;
+                    if (NG == 1) f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wgt), u));
+                    else f = __shfl(wgt, (lane & ~(64 / NG - 1)) + u, 64);
+                    O0 = __builtin_fmaf(bits_f32(ov[u][0]), f, O0);
+                    O1 = __builtin_fmaf(bits_f32(ov[u][2]), f, O1);
                 }
-                M = Mn_mine;
+                M = Mn;
             }
             if (i2 < PD) *reinterpret_cast<uint32_t *>(sa.out + ((size_t)b * sa.H + hk * G + g) * D + d) = (uint32_t)f2h(O0 / L) | ((uint32_t)f2h(O1 / L) << 16);
         }
