@@ -63,6 +63,12 @@ def set_placement_policy(name: str) -> None:
     check(load().fastkv_set_placement_policy(PLACEMENT_POLICY[name]), "set_placement_policy")
 
 
+def set_fused_rolling(on: bool) -> bool:
+    """Turn the rolling launch of the fused scoring kernel on / off (include/fastkv_hip.h fastkv_set_fused_rolling: three or more
+    32k-class entries scored by ONE launch, two entries on the chip at a time and out of step); returns the previous setting."""
+    return bool(load().fastkv_set_fused_rolling(1 if on else 0))
+
+
 def no_wait_mode() -> bool:
     """True when the library launches no kernel with an in-launch wait (FASTKV_FUSED=0, or the fail-safe switch)."""
     return bool(load().fastkv_no_wait_mode())

@@ -1,0 +1,97 @@
+"""The rolling launch of the fused scoring kernel (csrc/fused.hip launch_score_fused; include/fastkv_hip.h fastkv_set_fused_rolling):
+three or more 32k-class entries in ONE launch, two entries on the chip at a time and out of step.  It must change nothing but the
+time: every output of the operator -- scores, per-head indices, TSP index, compacted K / V -- bit for bit what the regular
+launches (two entries each, in step) produce, and what the ORACLE computes (reference: FastKVCluster.update_kv,
+/root/reference/baselines/fastkv/utils.py:93-132, one call per entry)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused_launches(lib):
+    """Scoring launches since the last read (the library's own per-kernel counters: include/fastkv_hip.h fastkv_profile_read)."""
+    n = lib.fastkv_profile_kernels()
+    counts, ms = (ctypes.c_int64 * n)(), (ctypes.c_double * n)()
+    assert lib.fastkv_profile_read(counts, ms) == 0
+    return sum(int(counts[i]) for i in range(n) if lib.fastkv_profile_kernel_name(i).decode() == "score_fused")
+
+
+def _inputs(B, H, Hkv, S, D, seed, dev, poison=False):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    q = torch.randn(B, S, H, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+    k = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+    v = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+    if poison:                                                   # one entry with NaN / Inf keys and a NaN query row: the NaN paths of every phase
+        k[1, 2, 77] = float("nan")
+        k[1, 5, S // 2, 3] = float("inf")
+        q[1, 9, S - 3] = float("nan")
+    return q, k, v
+
+
+@pytest.mark.parametrize("B,S,ks,pooling,tsp_len,order,poison", [
+    (3, 32768, 7, "avgpool", 0, "index", False),
+    (5, 32768, 7, "maxpool", 2048, "score", True),
+    (8, 24001, 5, "avgpool", 0, "score", False),                # ragged last tiles, rows that are not a multiple of anything
+    (9, 32768, 7, "avgpool", 2048, "index", False),             # the record areas rotate over four entries more than twice
+])
+def test_rolling_launch_changes_nothing(B, S, ks, pooling, tsp_len, order, poison):
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    H, Hkv, D, W, cap = 32, 8, 128, 8, 2048
+    q, k, v = _inputs(B, H, Hkv, S, D, 1000 + B, dev, poison)
+    outs = {}
+    lib = ops.load()
+    prev = ops.set_fused_rolling(True)
+    lib.fastkv_profile_enable(1)
+    try:
+        _fused_launches(lib)
+        for rolling in (True, False, True):
+            ops.set_fused_rolling(rolling)
+            got = ops.update_kv(q, k, v, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
+            torch.cuda.synchronize()
+            outs.setdefault(rolling, []).append(got)
+            # the rolling launch is ONE launch for all entries; the regular schedule holds two of these entries per launch
+            assert _fused_launches(lib) == (1 if rolling else (B + 1) // 2), rolling
+    finally:
+        lib.fastkv_profile_enable(0)
+        ops.set_fused_rolling(prev)
+    ref = outs[False][0]
+    for got in outs[True]:
+        for a, b, what in zip(got, ref, ("k_out", "v_out", "tsp_idx", "idx", "scores")):
+            if a is None or b is None:
+                assert a is None and b is None, what
+            elif a.dtype == torch.float16:
+                assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (what, "rolling and regular launches differ")
+            else:
+                assert torch.equal(a, b), (what, "rolling and regular launches differ")
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted()
+    assert ops.load().fastkv_placement_violations(0) == 0
+
+
+def test_rolling_launch_matches_the_oracle():
+    """Three 32k entries (one of them poisoned) through the rolling launch against the oracle, entry by entry."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    from helpers import default_contraction
+    dev = torch.device("cuda:0")
+    B, H, Hkv, S, D, W, ks, cap = 3, 32, 8, 32768, 128, 8, 7, 2048
+    O.set_contraction(default_contraction())
+    qd, kd, vd = _inputs(B, H, Hkv, S, D, 4242, dev, poison=True)
+    q, k, v = qd.cpu(), kd.cpu(), vd.cpu()
+    prev = ops.set_fused_rolling(True)
+    try:
+        gko, gvo, gtsp, gidx, gc = ops.update_kv(qd, kd, vd, W, ks, "avgpool", cap, 2048, "index", return_indices=True,
+                                                 return_scores=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_fused_rolling(prev)
+    for b in range(B):
+        ko, vo, idx, tsp, c, t = O.update_kv(q[b:b + 1], k[b:b + 1], v[b:b + 1], W, ks, "avgpool", cap, 2048, "index", return_scores=True)
+        assert torch.equal(gc[b:b + 1].cpu().view(torch.int16), c.view(torch.int16)), (b, "scores")
+        assert torch.equal(gidx[b:b + 1].cpu(), idx), (b, "indices")
+        assert torch.equal(gtsp[b:b + 1].cpu(), tsp), (b, "tsp index")
+        assert torch.equal(gko[b:b + 1].cpu().view(torch.int16), ko.view(torch.int16)) and torch.equal(gvo[b:b + 1].cpu().view(torch.int16), vo.view(torch.int16)), (b, "K/V")

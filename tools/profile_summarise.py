@@ -68,8 +68,19 @@ def first_key(prefix, contains=""):
 one = first_key("fk::score_fused_kernel<128, 2, 2, 1", "grid=131072") if fused else dom
 lf, lw = kib("FETCH_SIZE", one), kib("WRITE_SIZE", one)
 pair = {}
-if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1") for k in pmc.get("FETCH_SIZE", {})):
-    pf, pw = kib("FETCH_SIZE", "fk::score_fused_kernel<128, 4, 2, 1"), kib("WRITE_SIZE", "fk::score_fused_kernel<128, 4, 2, 1")
+# the rolling launch of a group (round 4): the same kernel with grid 65536 x entries (Grid_Size = 65536 * entries threads)
+grp_keys = [k for k in pmc.get("FETCH_SIZE", {}) if k.startswith("fk::score_fused_kernel<128, 4, 2, 1") and "grid=" in k and int(k.split("grid=")[1]) > 131072]
+group = {}
+if grp_keys:
+    gk = max(grp_keys, key=lambda k: pmc["FETCH_SIZE"][k]["n"])
+    gf = pmc["FETCH_SIZE"][gk]["median"]
+    gw = pmc.get("WRITE_SIZE", {}).get(gk, {"median": 0.0})["median"]
+    group = {"score_fused_group_entries": int(gk.split("grid=")[1]) // 65536, "score_fused_group_hbm_bytes_per_launch": int((2 * gf + gw) * 1024),
+             "score_fused_group_fetch_kib_raw": gf, "score_fused_group_write_kib": gw,
+             "group_note": "the rolling launch: all 32k layers of a group in one grid (score_fused_kernel<128,4,2,1>, grid 65536 x entries), algorithmic 67.17 MB per entry"}
+if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1") and k.endswith("grid=131072") for k in pmc.get("FETCH_SIZE", {})):
+    pk = [k for k in pmc["FETCH_SIZE"] if k.startswith("fk::score_fused_kernel<128, 4, 2, 1") and k.endswith("grid=131072")][0]
+    pf, pw = pmc["FETCH_SIZE"][pk]["median"], pmc.get("WRITE_SIZE", {}).get(pk, {"median": 0.0})["median"]
     pair = {"score_fused_pair_hbm_bytes_per_launch": int((2 * pf + pw) * 1024), "score_fused_pair_fetch_kib_raw": pf,
             "score_fused_pair_write_kib": pw,
             "pair_note": "two 32k layers per launch (score_fused_kernel<128,4,2,1>): algorithmic 134.35 MB; no scratch traffic to speak of "
@@ -78,7 +89,7 @@ if any(k.startswith("fk::score_fused_kernel<128, 4, 2, 1") for k in pmc.get("FET
 ckey = "fk::compact_kv_kernel<16> grid=524288" if any(k.startswith("fk::compact_kv_kernel<16> grid=524288") for k in pmc.get("FETCH_SIZE", {})) \
     else "fk::compact_kv_kernel<16>"
 cf, cw = kib("FETCH_SIZE", ckey), kib("WRITE_SIZE", ckey)
-json.dump({**pair, **{
+json.dump({**pair, **group, **{
     "git_head_of_the_pmc_pass": head(),
     "source": f"{tag} (git {head()}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1 "
               "--no-extras`, medians over launches; counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide 16-B/lane "
