@@ -170,6 +170,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         blk = l - unit * nblk;
         yb = unit / UH;
         hvp = unit - yb * UH;
+    } else if (rolling) {
+        // unit-major inside the entry, like the numbering above: on a chip that another kernel occupies in part the units of an entry
+        // complete one after the other instead of all waiting for workgroups that have no place yet
+        hvp = blockIdx.x / nblk; blk = blockIdx.x - hvp * nblk; yb = blockIdx.y;
     } else {
         hvp = blockIdx.x % UP; blk = blockIdx.x / UP; yb = blockIdx.y;
     }

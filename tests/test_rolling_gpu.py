@@ -95,3 +95,50 @@ def test_rolling_launch_matches_the_oracle():
         assert torch.equal(gidx[b:b + 1].cpu(), idx), (b, "indices")
         assert torch.equal(gtsp[b:b + 1].cpu(), tsp), (b, "tsp index")
         assert torch.equal(gko[b:b + 1].cpu().view(torch.int16), ko.view(torch.int16)) and torch.equal(gvo[b:b + 1].cpu().view(torch.int16), vo.view(torch.int16)), (b, "K/V")
+
+
+_HELD_CHILD = """
+import sys, time, torch
+sys.path.insert(0, 'tests')
+from fastkv_amd import ops
+from fastkv_amd._lib import load
+L = load()
+dev = torch.device('cuda:0')
+B, H, Hkv, S, D = 5, 32, 8, 32768, 128
+g = torch.Generator(device=dev).manual_seed(99)
+q = torch.randn(B, S, H, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+k = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+v = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+def run():
+    out = ops.update_kv(q, k, v, 8, 7, 'avgpool', 2048, 2048, 'score', return_indices=True, return_scores=True)
+    torch.cuda.current_stream().synchronize()                               # this stream only: not the holding kernel's
+    return out
+want = run()
+assert L.fastkv_last_status() == 0
+side = torch.cuda.Stream()
+# another kernel holds 200 of the 256 compute units for 300 ms: 112 places are left for an entry of 256 workgroups
+assert L.fastkv_debug_occupy(200, 128 * 1024, 300 * 1000, side.cuda_stream) == 0
+time.sleep(0.02)
+t0 = time.perf_counter()
+got = run()
+dt = (time.perf_counter() - t0) * 1e3
+print('held call took %.1f ms' % dt)
+assert L.fastkv_last_status() == 0
+for a, b in zip(got, want):
+    assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
+torch.cuda.synchronize()
+print('child ok')
+"""
+
+
+def test_rolling_launch_on_a_chip_that_is_mostly_taken():
+    """A long-running kernel on another stream holds 200 of the 256 compute units.  The rolling launch numbers its workgroups
+    unit-major inside an entry and entries in grid order, so the units that have a place complete and make room for the next: the
+    call is slower, not stuck and not wrong -- same bits as on the idle chip, nothing reported."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FASTKV_STRICT_PLACEMENT="0", FASTKV_FUSED_ROLLING="1")
+    r = subprocess.run([sys.executable, "-c", _HELD_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
