@@ -27,7 +27,6 @@ namespace fk {
 
 constexpr int ST_THREADS = 256;
 // slab rows per wave tile: KB 16-row blocks of the matrix instruction (template parameter: 2; 1 is a measurement variant, see step_tile_rows)
-constexpr int ST_SETS = 16;                                      // partial sets of a workgroup: 4 waves x 4 row groups
 constexpr int ST_PASS = 512;                                     // (query head, head_dim) values merged per pass through LDS
 
 // Measurement build (-DFK_STAMP): per-wave wall-clock stamps (100 MHz) of the step kernel's stages, read by tools/stamp_decode_step.py
@@ -43,6 +42,7 @@ __device__ unsigned long long g_dstamps[2048 * 16];
 typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
 typedef float st_f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t st_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int ST_BATCH = 24;                                     // slices whose records a merger thread has in flight at once
 
 struct StepArgs {
@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
     constexpr int NG = D >= 128 ? 1 : 128 / D;                   // query heads a wave of the merger works on (its 128 values of a pass)
     __shared__ __attribute__((aligned(16))) uint16_t s_qh[G * D];
     __shared__ __attribute__((aligned(16))) uint16_t s_knew[D], s_vnew[D];
-    __shared__ float s_m[(ST_SETS + 1) * G], s_l[(ST_SETS + 1) * G];
-    __shared__ __attribute__((aligned(16))) float s_o[ST_SETS * ST_PASS];
+    __shared__ float s_m[5 * G], s_l[4 * G];                     // the four waves' sets (+ the step's own row: its score)
+    __shared__ __attribute__((aligned(16))) float s_o[4 * G * D];
     const int hb = blockIdx.x, c = blockIdx.y, b = hb / sa.Hkv, hk = hb - b * sa.Hkv;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, x = lane & 15, qd = lane >> 4;
     const bool merger = nsplit > 1 && c == nsplit;
@@ -287,60 +287,79 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
                 }
         }
         FKD_STAMP(4);
-        // ---- the workgroup's 16 partial sets (+ the step's own row) -> one record of the slice, GP query heads per pass
-        const int set = w * 4 + qd;
-        if (x < G) { s_m[set * G + x] = m; s_l[set * G + x] = l; }
-        if (owner && w == 0) {
+        // ---- the wave's four row groups -> ONE set per wave, in registers: the common maximum (two swap-and-max steps), every group's
+        //      values scaled to it, then a transposing reduction -- v_permlane32_swap / v_permlane16_swap exchange half of one register
+        //      with half of another, so one swap + one add folds TWO registers into one: G*DL registers of per-group partial sums
+        //      become G*DL/4 registers of wave totals, row r of register i holding what register 4 i + {0, 2, 1, 3}[r] held.
+        //      (A wave alone on its SIMD issues an instruction every 4-8 cycles: 16 sets through LDS cost 1.3 us, this costs 0.x.)
+        constexpr int N = G * DL;
+        float mw = m;
+        { const st_u32x2 r = __builtin_amdgcn_permlane16_swap(f32_bits(mw), f32_bits(mw), false, false); mw = fmaxf(bits_f32(r[0]), bits_f32(r[1])); }
+        { const st_u32x2 r = __builtin_amdgcn_permlane32_swap(f32_bits(mw), f32_bits(mw), false, false); mw = fmaxf(bits_f32(r[0]), bits_f32(r[1])); }
+        const float fsc = m == -INFINITY ? 0.0f : __expf(m - mw);
+        float lw = l * fsc;
+        { const st_u32x2 r = __builtin_amdgcn_permlane16_swap(f32_bits(lw), f32_bits(lw), false, false); lw = bits_f32(r[0]) + bits_f32(r[1]); }
+        { const st_u32x2 r = __builtin_amdgcn_permlane32_swap(f32_bits(lw), f32_bits(lw), false, false); lw = bits_f32(r[0]) + bits_f32(r[1]); }
+        scale_rows<G, DL>(o, fsc);
+        float S[N / 2], T[N / 4];
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) {
+            const st_u32x2 r = __builtin_amdgcn_permlane32_swap(f32_bits(o[(2 * j) / DL][(2 * j) % DL]), f32_bits(o[(2 * j + 1) / DL][(2 * j + 1) % DL]), false, false);
+            S[j] = bits_f32(r[0]) + bits_f32(r[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const st_u32x2 r = __builtin_amdgcn_permlane16_swap(f32_bits(S[2 * i]), f32_bits(S[2 * i + 1]), false, false);
+            T[i] = bits_f32(r[0]) + bits_f32(r[1]);
+        }
+        const int pr = qd == 1 ? 2 : qd == 2 ? 1 : qd;
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const int n = 4 * i + pr, g = n / DL, e = n - g * DL;
+            s_o[w * (G * D) + g * D + x * DL + e] = T[i];
+        }
+        if (x < G && qd == 0) { s_m[w * G + x] = mw; s_l[w * G + x] = lw; }
+        if (owner && w == 0) {                                   // the step's own row: a fifth set {its score, 1, its V row}
             for (int g = 0; g < G; ++g) {
                 float a = 0.0f;
                 for (int d = lane; d < D; d += 64) a = __builtin_fmaf(h2f(s_qh[g * D + d]), h2f(s_knew[d]), a);
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-                if (lane == 0) { s_m[ST_SETS * G + g] = a * scaling; s_l[ST_SETS * G + g] = 1.0f; }
+                if (lane == 0) s_m[4 * G + g] = a * scaling;
             }
         }
+        __syncthreads();
+        // ---- the four waves' sets (+ the step's own row) -> one record of the slice
+        for (int i2 = tid * 2; i2 < G * D; i2 += 2 * ST_THREADS) {
+            const int g = i2 / D, d = i2 - g * D;
+            float M = owner ? s_m[4 * G + g] : -INFINITY;
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            if (ps) __syncthreads();
+            for (int u = 0; u < 4; ++u) M = fmaxf(M, s_m[u * G + g]);
+            float L = 0.0f, O0 = 0.0f, O1 = 0.0f;
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-                for (int e = 0; e < DL; e += 4)
-                    *reinterpret_cast<float4 *>(s_o + set * ST_PASS + gg * D + x * DL + e) =
-                        make_float4(o[ps * GP + gg][e], o[ps * GP + gg][e + 1], o[ps * GP + gg][e + 2], o[ps * GP + gg][e + 3]);
-            __syncthreads();
-            const int i2 = tid * 2;
-            if (i2 < PD) {
-                const int gg = i2 / D, d = i2 - gg * D, g = ps * GP + gg;
-                float M = owner ? s_m[ST_SETS * G + g] : -INFINITY;
-#pragma unroll
-                for (int u = 0; u < ST_SETS; ++u) M = fmaxf(M, s_m[u * G + g]);
-                float L = 0.0f, O0 = 0.0f, O1 = 0.0f;
-#pragma unroll
-                for (int u = 0; u < ST_SETS; ++u) {
-                    const float mu = s_m[u * G + g], f = mu == -INFINITY ? 0.0f : __expf(mu - M);
-                    const float2 ov = *reinterpret_cast<const float2 *>(s_o + u * ST_PASS + gg * D + d);
-                    L += s_l[u * G + g] * f;
-                    O0 += ov.x * f;
-                    O1 += ov.y * f;
-                }
-                if (owner) {
-                    const float f = __expf(s_m[ST_SETS * G + g] - M);
-                    L += f;
-                    O0 += h2f(s_vnew[d]) * f;
-                    O1 += h2f(s_vnew[d + 1]) * f;
-                }
-                if (nsplit == 1) {
-                    *reinterpret_cast<uint32_t *>(sa.out + ((size_t)b * sa.H + hk * G + g) * D + d) = (uint32_t)f2h(O0 / L) | ((uint32_t)f2h(O1 / L) << 16);
-                } else {
-                    // agent-scope stores: through the XCD's L2 (where a merger on the same XCD finds them) to memory (where any merger does)
-                    uint64_t *r = rec_head + ((size_t)c * G + g) * (D + 2);
-                    __hip_atomic_store(r + 2 + d, step_granule(token, O0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(r + 3 + d, step_granule(token, O1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (d == 0) {
-                        __hip_atomic_store(r, step_granule(token, M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(r + 1, step_granule(token, L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+            for (int u = 0; u < 4; ++u) {
+                const float mu = s_m[u * G + g], f = mu == -INFINITY ? 0.0f : __expf(mu - M);
+                const float2 ov = *reinterpret_cast<const float2 *>(s_o + u * (G * D) + g * D + d);
+                L += s_l[u * G + g] * f;
+                O0 += ov.x * f;
+                O1 += ov.y * f;
+            }
+            if (owner) {
+                const float f = __expf(s_m[4 * G + g] - M);
+                L += f;
+                O0 += h2f(s_vnew[d]) * f;
+                O1 += h2f(s_vnew[d + 1]) * f;
+            }
+            if (nsplit == 1) {
+                *reinterpret_cast<uint32_t *>(sa.out + ((size_t)b * sa.H + hk * G + g) * D + d) = (uint32_t)f2h(O0 / L) | ((uint32_t)f2h(O1 / L) << 16);
+            } else {
+                // agent-scope stores: through the XCD's L2 (where a merger on the same XCD finds them) to memory (where any merger does)
+                uint64_t *r = rec_head + ((size_t)c * G + g) * (D + 2);
+                __hip_atomic_store(r + 2 + d, step_granule(token, O0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(r + 3 + d, step_granule(token, O1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == 0) {
+                    __hip_atomic_store(r, step_granule(token, M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(r + 1, step_granule(token, L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
