@@ -143,3 +143,22 @@ def test_shipped_code_object_holds_no_packed_fp32_arithmetic(tmp_path):
     assert len(re.findall(r"v_mfma_f32_32x32x2_f32", asm)) > 1000 and "v_mfma_f32_32x32x16_f16" in asm
     packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
     assert not packed, f"{len(packed)} packed-fp32 instructions in the shipped code object"
+
+
+def test_process_wide_switches_and_decode_workspace_sizes_without_a_gpu():
+    """Pure host functions of the C ABI (include/fastkv_hip.h): the rolling-launch switch returns the previous setting; the decode
+    workspace holds {token, value} granules -- 8 bytes per value, D + 2 values per (query head, slice) -- and `nsplit <= 0` ("the
+    library chooses") sizes it for every choice the library can make (64 slices)."""
+    from fastkv_amd._lib import load
+    L = load()
+    prev = L.fastkv_set_fused_rolling(0)
+    try:
+        assert prev in (0, 1)
+        assert L.fastkv_set_fused_rolling(1) == 0 and L.fastkv_set_fused_rolling(1) == 1
+    finally:
+        L.fastkv_set_fused_rolling(prev)
+    B, H, D = 2, 32, 128
+    per_slice = B * H * (D + 2) * 8
+    assert L.fastkv_decode_workspace_bytes(B, H, D, 5) == (5 * per_slice + 255) // 256 * 256
+    assert L.fastkv_decode_workspace_bytes(B, H, D, 0) == L.fastkv_decode_workspace_bytes(B, H, D, 64) >= 64 * per_slice
+    assert L.fastkv_decode_workspace_bytes(0, H, D, 4) == 0
