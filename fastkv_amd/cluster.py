@@ -109,8 +109,9 @@ class DeferredCompression:
     The reference compresses layer by layer inside the attention forward (llama_model.py:136-142), but nothing reads a
     layer's compressed cache before decode -- only the TSP layer's index is needed while the prompt is still in flight.  An
     attention module hands a layer's q / k / v over with `add`; layers of one geometry are then compressed together through
-    `ops.update_kv_entries` (device-side pointer tables: no stacking copies; the library scores them in as many fused launches as
-    the chip's residency asks for -- two 32k layers per launch -- and selects / copies ALL of them with one launch each).
+    `ops.update_kv_entries` (device-side pointer tables: no stacking copies; the library scores three or more 32k layers with ONE
+    rolling launch -- the layers follow each other over the chip two at a time and out of step, csrc/fused.hip launch_score_fused --, fewer or
+    smaller ones in as many launches as the chip's residency asks for, and selects / copies ALL of them with one launch each).
     A waiting layer keeps its q / k / v alive (400 MiB at 32k); with `q_window` (FASTKV_DEFER_QWINDOW=1) only K, V and a 64 KiB copy of
     the query WINDOW rows -- the only query rows the operator reads (utils.py:93) -- at the price of one small copy launch per layer.
     Two regimes:
