@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
             s_o[w * (G * D) + g * D + x * DL + e] = T[i];
         }
         if (x < G && qd == 0) { s_m[w * G + x] = mw; s_l[w * G + x] = lw; }
-        if (owner && w == 0) {                                   // the step's own row: a fifth set {its score, 1, its V row}
-            for (int g = 0; g < G; ++g) {
+        if (owner) {                                             // the step's own row: a fifth set {its score, 1, its V row}; wave w scores heads w, w + 4
+            for (int g = w; g < G; g += 4) {
                 float a = 0.0f;
                 for (int d = lane; d < D; d += 64) a = __builtin_fmaf(h2f(s_qh[g * D + d]), h2f(s_knew[d]), a);
 #pragma unroll

@@ -76,3 +76,8 @@ for rep in range(12):
             if m[15]:
                 out.append(f"head {h} wave {wv}: {int(m[15])} lanes gave up, stale mask {int(m[14]) & 0xffffffff:08x}")
     print(f"replay {rep}: " + ("; ".join(out) if out else "all mergers fast"))
+
+# which workgroups store their record last? (slice index of the ten latest "record stored" stamps of the last launch read above)
+rs = [(float(full[(sl * nh + h) * 4 + wv, 5] - t0) / 100.0, sl, h, wv) for sl in range(ns - 1) for h in range(nh) for wv in range(4) if full[(sl * nh + h) * 4 + wv, 5] > 0]
+rs.sort(reverse=True)
+print("latest records (us, slice, head, wave):", [(round(a, 2), b, c, d) for a, b, c, d in rs[:10]], " owner slice =", (L0 + 20 + 12 + 1) // 128)
