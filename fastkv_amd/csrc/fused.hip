@@ -1227,7 +1227,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), placement_buffer(), (uint64_t *)nullptr, 1, stagger_ticks);
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, 1, stagger_ticks);
             });
             *err = hipGetLastError();
             return true;
@@ -1255,6 +1255,8 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 
 static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl, bool f16, int max_wgs)
 {
+    static const int cap_env = []() { const char *e = getenv("FASTKV_FUSED_MAX_WGS"); return e ? atoi(e) : 0; }();     // measurement aid
+    if (cap_env > 0 && cap_env < max_wgs && (int64_t)Bn * UH <= cap_env) max_wgs = cap_env;
     // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
     pl.NBV = (int64_t)Bn * UH * ((p.S + 63) / 64) <= 512 ? 1 : 2;
     const int TKV = 32 * pl.NBV;
