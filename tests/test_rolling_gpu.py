@@ -142,3 +142,36 @@ def test_rolling_launch_on_a_chip_that_is_mostly_taken():
     env = dict(os.environ, FASTKV_STRICT_PLACEMENT="0", FASTKV_FUSED_ROLLING="1")
     r = subprocess.run([sys.executable, "-c", _HELD_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def test_rolling_launch_replayed_from_a_graph():
+    """The operator over four 32k entries captured in a HIP graph and replayed on new data: the rolling launch is ONE kernel whose
+    tokens come from the epoch in the workspace (not from launch arguments, which a replay would freeze) -- every replay equals the
+    eager result."""
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, Hkv, S, D, W = 4, 32, 8, 32768, 128, 8
+    qs, ks, vs = _inputs(B, H, Hkv, S, D, 500, dev)
+    prev = ops.set_fused_rolling(True)
+    try:
+        warm = ops.update_kv(qs, ks, vs, W, 7, "avgpool", 2048, 2048, "score", return_indices=True)      # (workspaces exist before the capture)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                out = ops.update_kv(qs, ks, vs, W, 7, "avgpool", 2048, 2048, "score", return_indices=True)
+        for seed in (501, 502, 501):
+            q, k, v = _inputs(B, H, Hkv, S, D, seed, dev)
+            qs.copy_(q); ks.copy_(k); vs.copy_(v)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            want = ops.update_kv(q, k, v, W, 7, "avgpool", 2048, 2048, "score", return_indices=True)
+            torch.cuda.synchronize()
+            for a, b in zip(out, want):
+                assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b), seed
+    finally:
+        ops.set_fused_rolling(prev)
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted()
