@@ -140,9 +140,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #endif
     const unsigned tix = threadIdx.x;
     const int lane = tix & 63, w = __builtin_amdgcn_readfirstlane(tix >> 6);
-    // Entry 1 of a rolling launch (launch_score_fused) starts late ON PURPOSE: two entries that begin together stay in step -- both
-    // stream K, then both do arithmetic -- and gain nothing from sharing the chip.
-    if (rolling && start_delay > 0 && blockIdx.y == 1) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
+    // Entries 1 .. F-1 of a rolling launch (launch_score_fused; `rolling` = F, the entries the chip holds at a time) start late ON
+    // PURPOSE, one K-streaming time apart: entries that begin together stay in step -- all stream K, then all do arithmetic -- and
+    // gain nothing from sharing the chip.
+    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
@@ -194,9 +195,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         g_s[s] = hv / VH;
         vh_s[s] = hv - g_s[s] * VH;
         bg_s[s] = b * Hkv + g_s[s];
-        // hand-off records are per virtual head of THIS launch (a rolling launch: of the four entries that can be on the chip or
-        // about to be; the entry's own token tells its records from those of entry - 4)
-        bgv_s[s] = ((rolling ? (yb & 3) : yb) * Hkv + g_s[s]) * VH + vh_s[s];
+        // hand-off records are per virtual head of THIS launch (a rolling launch: of the 2 F entries that can be on the chip or
+        // about to be; the entry's own token tells its records from those of entry - 2 F)
+        bgv_s[s] = ((rolling ? yb % (2 * rolling) : yb) * Hkv + g_s[s]) * VH + vh_s[s];
         kb_s[s] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[s] * ks_h;   // (per-entry base: fk_host.h PtrTables)
     }
     const int n = S - W;
@@ -1199,14 +1200,14 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         }
     }
     *err = hipSuccess;
-    // ---- The rolling launch (mfma16 contract, three or more large entries).  ONE launch holds ALL entries, 256 workgroups each (one per
-    // compute unit): the chip has room for two entries at a time, the hardware starts the workgroups of entry e + 2 as those of entry
-    // e leave, and entry 1 starts late on purpose (start_delay) -- so at any time two entries share the chip OUT OF STEP: while one
-    // streams its K rows (memory bound, the vector units idle) the other runs its softmax / pooling phases (vector bound, the memory
-    // idle).  Measured: beside a partner that is a phase ahead a 32k layer takes 48 us, two of them in step (the pair launch) 59 us --
+    // ---- The rolling launch (mfma16 contract, more entries than the chip holds at a time).  ONE launch holds ALL entries, each at its
+    // smallest size (four tiles per wave: 256 workgroups for a 32k layer, one per compute unit): the chip has room for F of them (2 at
+    // 32k, 4 at 16k, 8 at 8k), the hardware starts the workgroups of entry e + F as those of entry e leave, and entries 1 .. F-1 start
+    // late on purpose (start_delay each) -- so at any time F entries share the chip OUT OF STEP: while one streams its K rows (memory
+    // bound, the vector units idle) another runs its softmax / pooling phases (vector bound, the memory idle).  Measured: beside a partner that is a phase ahead a 32k layer takes 48 us, two of them in step (the pair launch) 59 us --
     // 24 us per layer against 29.5 (tools/exp_stagger.py, tools/trace_interleave.sh).  What it rests on: workgroups are dispatched in
-    // grid order (entry e is complete on the chip before any workgroup of entry e + 2 starts: it takes the place of one of entry
-    // e), every entry has its own token (epoch + sub + entry) and the record areas rotate over four entries.  The compute-unit pairing
+    // grid order (entry e is complete on the chip before any workgroup of entry e + F starts: it takes the place of one of entry
+    // e), every entry has its own token (epoch + sub + entry) and the record areas rotate over 2 F entries.  The compute-unit pairing
     // rule of the fp32 contract (a partner must be the adjacent span of the same head) does not apply: the matrix phase it protects
     // does not exist under this contract and the library holds no packed-fp32 instruction (tools/probes/README.md, erratum note);
     // the placement check is not armed for this launch.
@@ -1217,17 +1218,22 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         static const int stagger_env = []() { const char *e = getenv("FASTKV_FUSED_STAGGER_US"); return e ? atoi(e) : -1; }();
         const int stagger_ticks = stagger_env >= 0 ? stagger_env * 100 : (int)((double)p.Hkv * p.S * p.D * 2.0 / 5.0e12 * 1.0e8);
         FusedPlan ph;
-        // (entries so large that a regular launch holds at most two of them: smaller ones go many to a launch, which is cheaper still)
+        // F = entries on the chip at a time: as many as fit with four tiles per wave (the smallest entry the kernel is built for).  32k
+        // layers: 2 (256 workgroups each); 16k: 4 (128 each); 12k: 5 (96 each); 8k: 8.  The record areas rotate over 2 F entries.
+        // (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
+        static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
+        int F = 0;
+        for (int f = f_cap; f >= 2 && !F; --f)
+            if (fused_plan_for(p, UH, 1, 1, ph, f16, 512 / f) && ph.PERT == 4 && (size_t)2 * f * UH * ph.nblk <= FUSED_MAX_WGS) F = f;
         // (VH == 1: the head-sum chain of models with more than four query heads per KV head has room for two entries' spans only)
-        if (rolling_on && f16 && VH == 1 && sb <= 2 && p.B >= 3 && p.B <= EPOCH_STRIDE && fused_plan_for(p, UH, 1, 1, ph, f16, 256) &&
-            (size_t)4 * UH * ph.nblk <= FUSED_MAX_WGS) {
+        if (rolling_on && f16 && VH == 1 && F && sb <= F && p.B > F && p.B <= EPOCH_STRIDE && fused_plan_for(p, UH, 1, 1, ph, f16, 512 / F)) {
             const dim3 grid(ph.nblk * UH, p.B);
             ProfScope ps_(K_FUSED, st);
             fused_dispatch(p.D, ph.PERT, ph.NBV, 1, f16, [&](auto fl) {
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, 1, stagger_ticks);
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks);
             });
             *err = hipGetLastError();
             return true;

@@ -133,9 +133,9 @@ int fastkv_set_placement_policy(int policy);
 /* The no-wait switch itself: fastkv_set_no_wait_mode(on) returns the previous setting (FASTKV_FUSED=0 cannot be undone by it);
  * fastkv_no_wait_mode() = 1 when no kernel with an in-launch wait will be launched (the environment variable or the switch). */
 int fastkv_set_no_wait_mode(int on);
-/* The rolling launch of the fused scoring kernel (csrc/fused.hip launch_score_fused): a call with three or more entries of which a
- * regular launch would hold two at most (32k-token layers) scores ALL of them in one launch whose entries follow each other over
- * the chip two at a time and out of step.  Same results bit for bit; on by default (FASTKV_FUSED_ROLLING=0 turns it off for the
+/* The rolling launch of the fused scoring kernel (csrc/fused.hip launch_score_fused): a call with more entries than the chip holds
+ * at a time (8k - 32k token layers: 8 - 2 of them) scores ALL of them in one launch whose entries follow each other over the chip
+ * out of step.  Same results bit for bit; on by default (FASTKV_FUSED_ROLLING=0 turns it off for the
  * process); returns the previous setting.  For A/B measurements and tests. */
 int fastkv_set_fused_rolling(int on);
 int fastkv_no_wait_mode(void);

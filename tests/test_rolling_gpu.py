@@ -36,6 +36,9 @@ def _inputs(B, H, Hkv, S, D, seed, dev, poison=False):
     (5, 32768, 7, "maxpool", 2048, "score", True),
     (8, 24001, 5, "avgpool", 0, "score", False),                # ragged last tiles, rows that are not a multiple of anything
     (9, 32768, 7, "avgpool", 2048, "index", False),             # the record areas rotate over four entries more than twice
+    (11, 16384, 7, "avgpool", 2048, "score", True),             # four entries on the chip at a time (128 workgroups each), areas rotate over eight
+    (13, 12000, 3, "maxpool", 0, "score", False),               # five at a time (96 workgroups each), ragged
+    (20, 8192, 7, "avgpool", 0, "index", False),                # eight at a time (64 workgroups each)
 ])
 def test_rolling_launch_changes_nothing(B, S, ks, pooling, tsp_len, order, poison):
     from fastkv_amd import ops
@@ -53,8 +56,9 @@ def test_rolling_launch_changes_nothing(B, S, ks, pooling, tsp_len, order, poiso
             got = ops.update_kv(q, k, v, W, ks, pooling, cap, tsp_len, order, return_indices=True, return_scores=True)
             torch.cuda.synchronize()
             outs.setdefault(rolling, []).append(got)
-            # the rolling launch is ONE launch for all entries; the regular schedule holds two of these entries per launch
-            assert _fused_launches(lib) == (1 if rolling else (B + 1) // 2), rolling
+            # the rolling launch is ONE launch for all entries; the regular schedule holds `per` of these entries per launch
+            per = ops.fused_entries(H, Hkv, S, D, W, ks)
+            assert _fused_launches(lib) == (1 if rolling else (B + per - 1) // per), (rolling, per)
     finally:
         lib.fastkv_profile_enable(0)
         ops.set_fused_rolling(prev)
@@ -72,13 +76,14 @@ def test_rolling_launch_changes_nothing(B, S, ks, pooling, tsp_len, order, poiso
     assert ops.load().fastkv_placement_violations(0) == 0
 
 
-def test_rolling_launch_matches_the_oracle():
-    """Three 32k entries (one of them poisoned) through the rolling launch against the oracle, entry by entry."""
+@pytest.mark.parametrize("B,S", [(3, 32768), (6, 16384)])
+def test_rolling_launch_matches_the_oracle(B, S):
+    """Three 32k entries / six 16k entries (one of them poisoned) through the rolling launch against the oracle, entry by entry."""
     from fastkv_amd import ops
     from oracle import fastkv_oracle as O
     from helpers import default_contraction
     dev = torch.device("cuda:0")
-    B, H, Hkv, S, D, W, ks, cap = 3, 32, 8, 32768, 128, 8, 7, 2048
+    H, Hkv, D, W, ks, cap = 32, 8, 128, 8, 7, 2048
     O.set_contraction(default_contraction())
     qd, kd, vd = _inputs(B, H, Hkv, S, D, 4242, dev, poison=True)
     q, k, v = qd.cpu(), kd.cpu(), vd.cpu()

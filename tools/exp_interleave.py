@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from fastkv_amd import ops
 dev = torch.device("cuda:0")
-H, Hkv, D, W, S = 32, 8, 128, 8, 32768
+H, Hkv, D, W, S = 32, 8, 128, 8, int(os.environ.get("EXP_S", "32768"))
 for B in (2, 3, 4, 8, 16):
     nset = max(2, 16 // B)
     sets = [(torch.randn(B, S, H, D, device=dev, dtype=torch.float16).transpose(1, 2), torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)) for _ in range(nset)]

@@ -1,4 +1,4 @@
-"""Soak of the rolling launch (csrc/fused.hip launch_score_fused): random groups of 3-12 large entries, ragged lengths, both poolings, NaN / Inf
+"""Soak of the rolling launch (csrc/fused.hip launch_score_fused): random groups of 3-20 entries of 8k-32k tokens (two to eight entries on the chip at a time), ragged lengths, both poolings, NaN / Inf
 sprinkles, now and then a foreign kernel holding some compute units -- every output of `ops.update_kv` with the rolling launch ON must equal the
 run with it OFF (launches of two entries, in step) bit for bit, and nothing may be reported.  Usage: soak_rolling.py [seconds] [seed]."""
 import os, random, sys, time
@@ -12,7 +12,7 @@ budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda:0")
 L = load()
-H, Hkv, D, W, SMAX, BMAX = 32, 8, 128, 8, 32768, 12
+H, Hkv, D, W, SMAX, BMAX = 32, 8, 128, 8, 32768, 20
 g = torch.Generator(device=dev).manual_seed(7)
 Q = torch.randn(BMAX, SMAX, H, D, generator=g, device=dev, dtype=torch.float16)
 K = torch.randn(BMAX, SMAX, Hkv, D, generator=g, device=dev, dtype=torch.float16)
@@ -22,7 +22,7 @@ t0, it, bad, held = time.time(), 0, 0, 0
 prev = ops.set_fused_rolling(True)
 while time.time() - t0 < budget_s:
     B = rng.randint(3, BMAX)
-    S = rng.choice([SMAX, rng.randint(22000, SMAX), rng.randint(22000, SMAX) // 64 * 64])
+    S = rng.choice([SMAX, rng.randint(22000, SMAX), rng.randint(8192, SMAX), rng.randint(8192, SMAX) // 64 * 64, 16384, 8192])
     ks, pooling = rng.choice([1, 3, 5, 7, 13]), rng.choice(["avgpool", "maxpool"])
     cap, tsp, order = rng.choice([512, 2048, 3000]), rng.choice([0, 2048]), rng.choice(["score", "index"])
     b0 = rng.randint(0, BMAX - B)
