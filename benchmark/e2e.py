@@ -38,8 +38,19 @@ def graph_decode(model, pkv, tok, steps, timed):
     out_tok = torch.zeros(steps, dtype=torch.int64, device=dev)
     step_no = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    # greedy sampling + the step's bookkeeping (next token, positions, token log) in ONE launch (csrc/decode.hip decode_greedy_kernel)
+    # instead of torch's argmax reduction and four small kernels; FASTKV_DECODE_GREEDY=0 keeps the torch sequence
+    fused_tail = os.environ.get("FASTKV_DECODE_GREEDY", "1") != "0" and dev.type == "cuda"
+    greedy_scratch = None
+    if fused_tail:
+        from fastkv_amd import ops as _ops
+        greedy_scratch = _ops.new_greedy_scratch(dev, tok.shape[0])
+
     def step():
         out = model(input_ids=tok_buf, past_key_values=pkv, position_ids=pos_buf)
+        if fused_tail and out.logits.dtype == torch.float16 and out.logits.shape[-1] % 8 == 0:
+            _ops.decode_greedy(out.logits, greedy_scratch, tok_buf, pos_buf, out_tok, step_no)
+            return
         nxt = out.logits[:, -1, :].argmax(dim=-1, keepdim=True)
         tok_buf.copy_(nxt)
         pos_buf.add_(1)

@@ -275,6 +275,59 @@ __global__ void __launch_bounds__(256) decode_silu_mul_kernel(const uint16_t *__
     *reinterpret_cast<uint4 *>(out + i) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
 }
 
+
+// Greedy sampling of a step, one launch: argmax over the vocabulary row of every batch entry (torch.argmax's rule: the FIRST maximal
+// value; NaN counts as maximal), the new token written to tok[b] (the next step's input), appended to the log and the positions
+// advanced -- what `logits.argmax(-1)` + four bookkeeping kernels do in benchmark/e2e.py's captured step.  Every workgroup folds its
+// share into a 64-bit key {order-preserving value : 16, ~index : 32} and does ONE atomic max per batch entry; the last workgroup
+// to arrive writes the results and leaves the scratch words as it found them (graph-replayable).
+// grid (nwg, B), 256 threads; scratch: B + 1 uint64 words, zero between launches.
+__global__ void __launch_bounds__(256) decode_greedy_kernel(const uint16_t *__restrict__ logits, int64_t row_stride, int V,
+                                                           unsigned long long *__restrict__ scratch, int64_t *__restrict__ tok,
+                                                           int64_t *__restrict__ pos, int64_t *__restrict__ log, int64_t *__restrict__ log_index,
+                                                           int log_cap)
+{
+    __shared__ unsigned long long s_best[4];
+    const int b = blockIdx.y, B = gridDim.y, nwg = gridDim.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint16_t *row = logits + (int64_t)b * row_stride;
+    unsigned long long best = 0;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 8; i < V; i += nwg * 256 * 8) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(row + i);          // (V is a multiple of 8, rows 16-B aligned: checked by the host)
+        const uint32_t wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t h = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+            const uint32_t key = (h & 0x7fffu) > 0x7c00u ? 0xffffu : mono16(h);           // NaN: maximal
+            const unsigned long long k = ((unsigned long long)key << 32) | (uint32_t)~(uint32_t)(i + e);
+            best = k > best ? k : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)best, o, 64); best = other > best ? other : best; }
+    if (lane == 0) s_best[w] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) best = s_best[i] > best ? s_best[i] : best;
+        __hip_atomic_fetch_max(scratch + 1 + b, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned long long arrived = __hip_atomic_fetch_add(scratch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (unsigned long long)nwg * B - 1) {                   // the last workgroup of the launch: every maximum is in
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            int64_t li = log_index ? *log_index : 0;
+            for (int bb = 0; bb < B; ++bb) {
+                const unsigned long long k = __hip_atomic_load(scratch + 1 + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int64_t t = (int64_t)(uint32_t)~(uint32_t)k;
+                tok[bb] = t;
+                if (pos) pos[bb] += 1;
+                __hip_atomic_store(scratch + 1 + bb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bb == 0 && log && li < log_cap) log[li] = t;            // (the log follows batch entry 0, as the driver's token list does)
+            }
+            if (log_index) *log_index = li + 1;
+            __hip_atomic_store(scratch, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace fk
 
 using namespace fk;
@@ -363,6 +416,19 @@ int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q
     ProfScope ps_(K_DECODE, (hipStream_t)stream);
     hipLaunchKernelGGL(decode_rope_kernel, dim3(H + Hkv, B), dim3(128), 0, (hipStream_t)stream, (uint16_t *)q, q_strides[0], q_strides[1], H,
                        (uint16_t *)k, k_strides[0], k_strides[1], Hkv, (const uint16_t *)cosv, (const uint16_t *)sinv, cs_batch_stride, D);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_decode_greedy_f16(int32_t B, int32_t V, const void *logits, int64_t row_stride, void *scratch, int64_t *tok, int64_t *pos,
+                             int64_t *log, int64_t *log_index, int32_t log_cap, void *stream)
+{
+    if (B < 1 || B > 1024 || V < 8 || (V & 7) || !logits || !scratch || !tok || (row_stride & 7) || row_stride < V) return FASTKV_EINVAL;
+    if (((uintptr_t)logits & 15) || ((uintptr_t)scratch & 7) || (log && (!log_index || log_cap < 1))) return FASTKV_EINVAL;
+    int nwg = (V / 8 + 255) / 256;                               // one 16-B piece per thread where the vocabulary allows: 63 workgroups at 128k
+    if (nwg > 256) nwg = 256;
+    ProfScope ps_(K_DECODE, (hipStream_t)stream);
+    hipLaunchKernelGGL(decode_greedy_kernel, dim3((unsigned)nwg, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)logits, row_stride, V,
+                       (unsigned long long *)scratch, tok, pos, log, log_index, log_cap);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -366,6 +366,30 @@ def decode_silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def new_greedy_scratch(device: torch.device, B: int) -> torch.Tensor:
+    """Scratch of `decode_greedy` (zero between launches; allocate it before a capture)."""
+    return torch.zeros(B + 1, dtype=torch.int64, device=device)
+
+
+def decode_greedy(logits: torch.Tensor, scratch: torch.Tensor, tok: torch.Tensor, pos: Optional[torch.Tensor] = None,
+                  log: Optional[torch.Tensor] = None, log_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Greedy sampling of a step in ONE launch (csrc/decode.hip decode_greedy_kernel): tok[b, 0] = argmax of logits[b, -1, :]
+    (torch.argmax's rule), optionally pos[b, 0] += 1, log[log_index[0]] = tok[0, 0], log_index[0] += 1 -- the tail of
+    benchmark/e2e.py's captured step.  logits [B, T, V] fp16; tok / pos [B, 1] int64; log [n] int64; log_index [1] int64."""
+    _require_cuda(logits, scratch, tok)
+    B, T, V = logits.shape
+    row = logits[:, -1, :]
+    assert logits.dtype == torch.float16 and row.stride(1) == 1 and tok.dtype == torch.int64 and tok.shape == (B, 1) and tok.is_contiguous()
+    assert scratch.dtype == torch.int64 and scratch.numel() >= B + 1 and (B == 1 or row.stride(0) % 8 == 0)
+    assert pos is None or (pos.dtype == torch.int64 and pos.shape == (B, 1) and pos.is_contiguous())
+    assert (log is None) == (log_index is None) and (log is None or (log.dtype == torch.int64 and log.is_contiguous() and log_index.dtype == torch.int64))
+    check(load().fastkv_decode_greedy_f16(B, V, row.data_ptr(), row.stride(0) if B > 1 else V, scratch.data_ptr(), tok.data_ptr(),
+                                          pos.data_ptr() if pos is not None else None, log.data_ptr() if log is not None else None,
+                                          log_index.data_ptr() if log_index is not None else None, log.numel() if log is not None else 0,
+                                          _stream()), "decode_greedy")
+    return tok
+
+
 def decode_gemv(x: torch.Tensor, weights, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0, glu: bool = False,
                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The projections of a one-token step in ONE launch (csrc/gemv.hip): x [B,1,K] fp16 times up to three `nn.Linear` weights

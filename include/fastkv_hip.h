@@ -376,6 +376,12 @@ int fastkv_decode_rmsnorm_f16(const void *x, int64_t rows, int64_t x_row_stride,
 int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q, const int64_t q_strides[2], void *k,
                            const int64_t k_strides[2], const void *cosv, const void *sinv, int64_t cs_batch_stride, void *stream);
 int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void *out, void *stream);
+/* Greedy sampling of a step in ONE launch (the reference's loop: `out.logits[:, -1].argmax(-1)`, /root/reference/benchmark/e2e.py:72-93):
+ * tok[b] = argmax of logits row b ([B rows of V fp16 values], row stride in elements; torch.argmax's rule: the first maximal value,
+ * NaN counts as maximal); optional bookkeeping of a captured step: pos[b] += 1, log[*log_index] = tok[0] (while *log_index <
+ * log_cap), *log_index += 1.  `scratch`: B + 1 uint64 of device memory, zeroed ONCE by the caller; the launch leaves them zero. */
+int fastkv_decode_greedy_f16(int32_t B, int32_t V, const void *logits, int64_t row_stride, void *scratch, int64_t *tok, int64_t *pos,
+                             int64_t *log, int64_t *log_index, int32_t log_cap, void *stream);
 
 /* Weight-streaming GEMV of the decode step (csrc/gemv.hip): out[b, :] = W x[b, :] for ONE input row per batch element
  * (B = 1, 2 or 4; K % 512 == 0, B*K*2 <= 64 KiB - 256), fp16 in / fp32 accumulate / fp16 out.  Replaces the q/k/v/o and MLP

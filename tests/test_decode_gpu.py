@@ -254,3 +254,37 @@ def test_fused_step_attention_matches_the_separate_kernels_and_fp32(B, H, Hkv, D
         assert float((out.float() - ref).abs().max()) <= tol, (step, float((out.float() - ref).abs().max()), tol)
     cnt = ops._step_counters[(dev.index, ops._stream())]
     assert int(cnt[0]) == 0 and int(cnt[2:].abs().sum()) == 0          # arrivals back at zero; word 1 is the launch epoch
+
+
+@pytest.mark.parametrize("B,V", [(1, 128256), (2, 32000), (4, 4096), (1, 8)])
+def test_greedy_step_tail_matches_torch_argmax(B, V):
+    """ops.decode_greedy (argmax + next token + positions + token log in one launch) against torch.argmax on the same logits,
+    incl. ties (the first maximal value wins), -inf rows, NaN (counts as maximal, as in torch); scratch words back at zero; several
+    steps through one scratch / log."""
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(V + B)
+    scratch = ops.new_greedy_scratch(dev, B)
+    tok = torch.zeros(B, 1, dtype=torch.int64, device=dev)
+    pos = torch.full((B, 1), 100, dtype=torch.int64, device=dev)
+    log = torch.full((8,), -1, dtype=torch.int64, device=dev)
+    log_index = torch.zeros(1, dtype=torch.int64, device=dev)
+    want_log = []
+    for step in range(6):
+        logits = torch.randn(B, 3, V, generator=g, device=dev, dtype=torch.float16)
+        if step == 1:
+            logits[:, -1, :] = logits[:, -1, :].round()                       # many ties
+        if step == 2:
+            logits[0, -1, :] = float("-inf")
+        if step == 3 and V > 8:
+            logits[-1, -1, V // 2] = float("nan")
+            logits[-1, -1, V // 2 + 5] = float("nan")
+        if step == 4:
+            logits[0, -1, V - 1] = 100.0                                      # the last element
+        ref = logits[:, -1, :].argmax(dim=-1, keepdim=True)
+        ops.decode_greedy(logits, scratch, tok, pos, log, log_index)
+        torch.cuda.synchronize()
+        assert torch.equal(tok, ref), (step, tok.tolist(), ref.tolist())
+        want_log.append(int(ref[0, 0]))
+        assert int(pos[0, 0]) == 101 + step and int(log_index) == step + 1 and int(scratch.abs().sum()) == 0
+    assert log[:6].tolist() == want_log and int(log[6]) == -1
