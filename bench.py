@@ -15,8 +15,9 @@ cache-resident across layers), inputs already in HBM.  `value` = prompt tokens /
 N>1: every rank runs its own prompt (independent prompts shard with no exchange) -> weak scaling.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel (score_fused / score_logits): fp32-MFMA flops and algorithmic bytes (K once + Q window) / average launch duration
-                measured with HIP events on the launch stream during an instrumented replay of the same steps.
+  roofline      dominant launch = the scoring of a group of `FASTKV_DEFER_HOLD` (8) 32k layers in ONE rolling launch of score_fused (csrc/fused.hip):
+                algorithmic bytes (K once + Q window per layer) / average launch duration, measured with HIP events on the launch stream on
+                rotating layer sets; `roofline_pair_launch` / `roofline_one_layer_launch`: the launches of two layers / one layer beside it.
   kernels       every kernel: launches per step, average microseconds (same instrumented replay).
   compact       the KV gather/compact kernel: per-layer latency at this config and GB/s at the "roofline shape"
                 (same row geometry, 32 layers' worth in one launch, beyond the 256 MiB Infinity Cache).
