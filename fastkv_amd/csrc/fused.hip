@@ -99,7 +99,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts)
 {
 #if defined(FK_DBG_DELAY) && !defined(FK_DBG_WHO)
 #define FK_DBG_WHO (yb == 0)
@@ -158,8 +158,11 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // hand-offs keep them in step -- neither can be a phase ahead of the other (maxima, sums and halo all need the partner's record).
     // Why that matters: a workgroup that runs its later phases beside one still in phase A (another entry's, held up by the NaN redo
     // or anything else) was measured to produce wrong row sums / window-row sums now and then (tools/repro_nan_mate.py).
-    const int nblk = gridDim.x / UP;
-    int hvp, blk, yb;
+    // (a rolling launch may split a batch row's units over `parts` entries -- prompts so long that the units of one row do not fit
+    // half of the chip: an entry is then UP / parts units of a row, the rows' parts follow each other in grid order)
+    const int UPE = rolling ? UP / parts : UP;                   // units per entry of this launch
+    const int nblk = gridDim.x / UPE;
+    int hvp, blk, yb, ent = 0, part_base = 0;
 #ifdef FK_OLD_NUMBERING                                          // (measurement builds of the hunt in DESIGN.md section 8 only)
     if (false) {
 #else
@@ -174,7 +177,11 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     } else if (rolling) {
         // unit-major inside the entry, like the numbering above: on a chip that another kernel occupies in part the units of an entry
         // complete one after the other instead of all waiting for workgroups that have no place yet
-        hvp = blockIdx.x / nblk; blk = blockIdx.x - hvp * nblk; yb = blockIdx.y;
+        ent = blockIdx.y;
+        yb = ent / parts;
+        part_base = (ent - yb * parts) * UPE;
+        hvp = blockIdx.x / nblk; blk = blockIdx.x - hvp * nblk;
+        hvp += part_base;
     } else {
         hvp = blockIdx.x % UP; blk = blockIdx.x / UP; yb = blockIdx.y;
     }
@@ -197,7 +204,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         bg_s[s] = b * Hkv + g_s[s];
         // hand-off records are per virtual head of THIS launch (a rolling launch: of the 2 F entries that can be on the chip or
         // about to be; the entry's own token tells its records from those of entry - 2 F)
-        bgv_s[s] = ((rolling ? yb % (2 * rolling) : yb) * Hkv + g_s[s]) * VH + vh_s[s];
+        bgv_s[s] = rolling ? (ent % (2 * rolling)) * UPE + (hv - part_base) : (yb * Hkv + g_s[s]) * VH + vh_s[s];
         kb_s[s] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[s] * ks_h;   // (per-entry base: fk_host.h PtrTables)
     }
     const int n = S - W;
@@ -245,7 +252,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     }
     // (sub 0: the operator call's token, shared with the selection; the epoch advances by EPOCH_STRIDE per call, sub < EPOCH_STRIDE:
     // the tokens of all launches are distinct values of one bijective mix)
-    const uint32_t token = handoff_token(ctrl[2] + sub + (rolling ? (uint32_t)yb : 0u));
+    const uint32_t token = handoff_token(ctrl[2] + sub + (rolling ? (uint32_t)ent : 0u));
     const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (tix == 0) s_abort = 0;
     // Placement check.  The pairing above ASSUMES which workgroups share a compute unit; this notices when the assumption did not hold:
@@ -1029,11 +1036,11 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts)
 {
     (void)score_fused_body<D, PER, NB, NS, F16>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1150,8 +1157,9 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     int sb = 0;
     for (int cand = p.B; cand >= 1; --cand)
         if (fused_plan_for(p, UH, ns_pref, cand, pl, f16)) { sb = cand; break; }
-    if (!sb) return false;                                       // not even one entry fits: staged path
-    if ((p.B + sb - 1) / sb > EPOCH_STRIDE) return false;        // (more scoring launches than one call's share of hand-off tokens)
+    // (sb == 0: not even one entry fits a regular launch -- prompts beyond 64k tokens at this geometry; the rolling launch below can
+    // still take them, a part of a row's units at a time; without it: the staged path)
+    if (sb && (p.B + sb - 1) / sb > EPOCH_STRIDE) return false;  // (more scoring launches than one call's share of hand-off tokens)
     const float sqrtD = (float)sqrt((double)p.D);
     uint64_t *pmax = reinterpret_cast<uint64_t *>(ws + L.off_fpart);
     uint64_t *psum = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 8);
@@ -1220,25 +1228,32 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         FusedPlan ph;
         // F = entries on the chip at a time: as many as fit with four tiles per wave (the smallest entry the kernel is built for).  32k
         // layers: 2 (256 workgroups each); 16k: 4 (128 each); 12k: 5 (96 each); 8k: 8.  The record areas rotate over 2 F entries.
-        // (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
+        // Prompts whose rows do not fit half of the chip even then (beyond 32k tokens at 8 KV heads) are split: an entry is 1 / parts of a
+        // row's units (4 heads at 64k, 2 at 128k, 1 at 256k), the parts of a row follow each other like entries do -- the units of a row
+        // share nothing but the row's inputs.  (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
         static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
-        int F = 0;
-        for (int f = f_cap; f >= 2 && !F; --f)
-            if (fused_plan_for(p, UH, 1, 1, ph, f16, 512 / f) && ph.PERT == 4 && (size_t)2 * f * UH * ph.nblk <= FUSED_MAX_WGS) F = f;
+        int F = 0, parts = 1;
+        for (int pp = 1; pp <= 8 && pp <= UH && !F; pp *= 2) {
+            if (UH % pp) break;
+            for (int f = f_cap; f >= 2 && !F; --f)
+                if (fused_plan_for(p, UH / pp, 1, 1, ph, f16, 512 / f) && ph.PERT == 4 && (size_t)2 * f * (UH / pp) * ph.nblk <= FUSED_MAX_WGS) { F = f; parts = pp; }
+        }
+        const int entries = p.B * parts;
         // (VH == 1: the head-sum chain of models with more than four query heads per KV head has room for two entries' spans only)
-        if (rolling_on && f16 && VH == 1 && F && sb <= F && p.B > F && p.B <= EPOCH_STRIDE && fused_plan_for(p, UH, 1, 1, ph, f16, 512 / F)) {
-            const dim3 grid(ph.nblk * UH, p.B);
+        if (rolling_on && f16 && VH == 1 && F && sb * parts <= F && entries > F && entries <= EPOCH_STRIDE && fused_plan_for(p, UH / parts, 1, 1, ph, f16, 512 / F)) {
+            const dim3 grid(ph.nblk * (UH / parts), entries);
             ProfScope ps_(K_FUSED, st);
             fused_dispatch(p.D, ph.PERT, ph.NBV, 1, f16, [&](auto fl) {
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks);
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts, parts);
             });
             *err = hipGetLastError();
             return true;
         }
     }
+    if (!sb) return false;                                       // not even one entry fits a regular launch: staged path
     uint32_t sub = 0;
     for (int b0 = 0; b0 < p.B && *err == hipSuccess; ++sub) {
         // launches of `sb` entries; the last one takes what is left (its own plan: fewer entries may mean fewer tiles per wave)
@@ -1251,7 +1266,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), cu_slots, 0, 0);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), cu_slots, 0, 0, 1);
         });
         *err = hipGetLastError();
         b0 += take;

@@ -135,7 +135,7 @@ int fastkv_set_placement_policy(int policy);
 int fastkv_set_no_wait_mode(int on);
 /* The rolling launch of the fused scoring kernel (csrc/fused.hip launch_score_fused): a call with more entries than the chip holds
  * at a time (8k - 32k token layers: 8 - 2 of them) scores ALL of them in one launch whose entries follow each other over the chip
- * out of step.  Same results bit for bit; on by default (FASTKV_FUSED_ROLLING=0 turns it off for the
+ * out of step; a layer of more than 64k tokens (no regular fused launch holds it) is taken in parts of its KV heads the same way.  Same results bit for bit; on by default (FASTKV_FUSED_ROLLING=0 turns it off for the
  * process); returns the previous setting.  For A/B measurements and tests. */
 int fastkv_set_fused_rolling(int on);
 int fastkv_no_wait_mode(void);

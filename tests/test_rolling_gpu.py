@@ -180,3 +180,40 @@ def test_rolling_launch_replayed_from_a_graph():
         ops.set_fused_rolling(prev)
     from fastkv_amd._lib import raise_if_aborted
     raise_if_aborted()
+
+
+@pytest.mark.parametrize("B,S,ks,pooling", [(1, 131072, 7, "avgpool"), (3, 65536, 5, "maxpool"), (1, 100003, 7, "avgpool")])
+def test_long_prompts_take_the_rolling_launch_in_parts(B, S, ks, pooling):
+    """Prompts beyond what a regular fused launch holds (64k tokens at 8 KV heads): the rolling launch takes a row's KV heads in parts
+    (4 heads per entry at 64k, 2 at 128k) -- ONE scoring launch instead of the three staged kernels -- and the operator's outputs equal
+    the ORACLE's bit for bit, and the staged kernels' (rolling off)."""
+    from fastkv_amd import ops
+    from oracle import fastkv_oracle as O
+    from helpers import default_contraction
+    dev = torch.device("cuda:0")
+    H, Hkv, D, W, cap = 32, 8, 128, 8, 2048
+    O.set_contraction(default_contraction())
+    qd, kd, vd = _inputs(B, H, Hkv, S, D, 31 + B, dev, poison=B > 1)
+    lib = ops.load()
+    prev = ops.set_fused_rolling(True)
+    lib.fastkv_profile_enable(1)
+    try:
+        _fused_launches(lib)
+        got = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, 2048, "score", return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        assert _fused_launches(lib) == 1
+        ops.set_fused_rolling(False)
+        other = ops.update_kv(qd, kd, vd, W, ks, pooling, cap, 2048, "score", return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.fastkv_profile_enable(0)
+        ops.set_fused_rolling(prev)
+    for a, b in zip(got, other):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
+    q, k, v = qd[:1].cpu(), kd[:1].cpu(), vd[:1].cpu()
+    ko, vo, idx, tsp, c, t = O.update_kv(q, k, v, W, ks, pooling, cap, 2048, "score", return_scores=True)
+    gko, gvo, gtsp, gidx, gc = got
+    assert torch.equal(gc[:1].cpu().view(torch.int16), c.view(torch.int16)) and torch.equal(gidx[:1].cpu(), idx) and torch.equal(gtsp[:1].cpu(), tsp)
+    assert torch.equal(gko[:1].cpu().view(torch.int16), ko.view(torch.int16)) and torch.equal(gvo[:1].cpu().view(torch.int16), vo.view(torch.int16))
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted()

@@ -12,7 +12,8 @@ budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda:0")
 L = load()
-H, Hkv, D, W, SMAX, BMAX = 32, 8, 128, 8, 32768, 20
+H, Hkv, D, W = 32, 8, 128, 8
+SMAX, BMAX, SMIN = int(os.environ.get("SOAK_SMAX", "32768")), int(os.environ.get("SOAK_BMAX", "20")), int(os.environ.get("SOAK_SMIN", "8192"))     # e.g. SOAK_SMAX=131072 SOAK_BMAX=6 SOAK_SMIN=40000: long prompts, rows taken in parts
 g = torch.Generator(device=dev).manual_seed(7)
 Q = torch.randn(BMAX, SMAX, H, D, generator=g, device=dev, dtype=torch.float16)
 K = torch.randn(BMAX, SMAX, Hkv, D, generator=g, device=dev, dtype=torch.float16)
@@ -21,8 +22,8 @@ side = torch.cuda.Stream()
 t0, it, bad, held = time.time(), 0, 0, 0
 prev = ops.set_fused_rolling(True)
 while time.time() - t0 < budget_s:
-    B = rng.randint(3, BMAX)
-    S = rng.choice([SMAX, rng.randint(22000, SMAX), rng.randint(8192, SMAX), rng.randint(8192, SMAX) // 64 * 64, 16384, 8192])
+    B = rng.randint(1 if SMIN > 32768 else 3, BMAX)
+    S = rng.choice([SMAX, rng.randint(max(SMIN, min(22000, SMAX)), SMAX), rng.randint(SMIN, SMAX), rng.randint(SMIN, SMAX) // 64 * 64, max(SMIN, 16384), SMIN])
     ks, pooling = rng.choice([1, 3, 5, 7, 13]), rng.choice(["avgpool", "maxpool"])
     cap, tsp, order = rng.choice([512, 2048, 3000]), rng.choice([0, 2048]), rng.choice(["score", "index"])
     b0 = rng.randint(0, BMAX - B)
