@@ -1114,6 +1114,20 @@ static std::atomic<int> &rolling_flag()
 struct FusedPlan { int NBV, PERT, NS, nblk, wgs; };
 static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl, bool f16, int max_wgs = 2 * 256);
 
+// The rolling launch's geometry (launch_score_fused): F entries on the chip at a time, each 1 / parts of a batch row's units at its
+// smallest size (four tiles per wave).  false: no such plan (short prompts: many entries fit a regular launch anyway).
+static bool rolling_plan_for(const fastkv_problem &p, int UH, bool f16, int &F, int &parts, FusedPlan &ph)
+{
+    static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
+    F = 0; parts = 1;
+    for (int pp = 1; pp <= 8 && pp <= UH && !F; pp *= 2) {
+        if (UH % pp) break;
+        for (int f = f_cap; f >= 2 && !F; --f)
+            if (fused_plan_for(p, UH / pp, 1, 1, ph, f16, 512 / f) && ph.PERT == 4 && (size_t)2 * f * (UH / pp) * ph.nblk <= FUSED_MAX_WGS) { F = f; parts = pp; }
+    }
+    return F != 0 && fused_plan_for(p, UH / parts, 1, 1, ph, f16, 512 / F);
+}
+
 // Largest number of batch entries ONE fused scoring launch holds for this geometry (p.B is ignored), 0 = the geometry is off the
 // fused path.  What a caller that batches entries itself wants to know up front (fastkv_amd.cluster.DeferredCompression).
 int fused_entries_per_launch(const fastkv_problem &p)
@@ -1129,6 +1143,11 @@ int fused_entries_per_launch(const fastkv_problem &p)
     int best = 0;
     for (int cand = 1; cand <= 64; ++cand)
         if (fused_plan_for(p, p.Hkv * VH, ns_pref, cand, pl, f16)) best = cand;
+    if (!best && f16 && VH == 1 && rolling_flag().load(std::memory_order_relaxed)) {
+        // a row too long for a regular launch: the rolling launch takes it in parts, EPOCH_STRIDE entries (= parts) per call at most
+        int F = 0, parts = 1;
+        if (rolling_plan_for(p, p.Hkv * VH, f16, F, parts, pl) && parts > F) best = EPOCH_STRIDE / parts;
+    }
     return best;
 }
 
@@ -1231,16 +1250,11 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         // Prompts whose rows do not fit half of the chip even then (beyond 32k tokens at 8 KV heads) are split: an entry is 1 / parts of a
         // row's units (4 heads at 64k, 2 at 128k, 1 at 256k), the parts of a row follow each other like entries do -- the units of a row
         // share nothing but the row's inputs.  (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
-        static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
         int F = 0, parts = 1;
-        for (int pp = 1; pp <= 8 && pp <= UH && !F; pp *= 2) {
-            if (UH % pp) break;
-            for (int f = f_cap; f >= 2 && !F; --f)
-                if (fused_plan_for(p, UH / pp, 1, 1, ph, f16, 512 / f) && ph.PERT == 4 && (size_t)2 * f * (UH / pp) * ph.nblk <= FUSED_MAX_WGS) { F = f; parts = pp; }
-        }
+        const bool have_plan = rolling_plan_for(p, UH, f16, F, parts, ph);
         const int entries = p.B * parts;
         // (VH == 1: the head-sum chain of models with more than four query heads per KV head has room for two entries' spans only)
-        if (rolling_on && f16 && VH == 1 && F && sb * parts <= F && entries > F && entries <= EPOCH_STRIDE && fused_plan_for(p, UH / parts, 1, 1, ph, f16, 512 / F)) {
+        if (rolling_on && f16 && VH == 1 && have_plan && sb * parts <= F && entries > F && entries <= EPOCH_STRIDE) {
             const dim3 grid(ph.nblk * (UH / parts), entries);
             ProfScope ps_(K_FUSED, st);
             fused_dispatch(p.D, ph.PERT, ph.NBV, 1, f16, [&](auto fl) {

@@ -217,3 +217,30 @@ def test_long_prompts_take_the_rolling_launch_in_parts(B, S, ks, pooling):
     assert torch.equal(gko[:1].cpu().view(torch.int16), ko.view(torch.int16)) and torch.equal(gvo[:1].cpu().view(torch.int16), vo.view(torch.int16))
     from fastkv_amd._lib import raise_if_aborted
     raise_if_aborted()
+
+
+def test_a_group_of_long_layers_through_the_entries_call():
+    """Three separately allocated 131,072-token layers compressed together (`ops.update_kv_entries`, what DeferredCompression does with
+    layers of one geometry: `ops.fused_entries` reports 16 such entries per call) -- one rolling launch of 12 entries (3 rows x 4 parts)
+    -- against the same layers one by one."""
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    H, Hkv, S, D, W, cap = 32, 8, 131072, 128, 8, 2048
+    assert ops.fused_entries(H, Hkv, S, D, W, 7) >= 3
+    layers = [_inputs(1, H, Hkv, S, D, 70 + i, dev) for i in range(3)]
+    lib = ops.load()
+    lib.fastkv_profile_enable(1)
+    try:
+        _fused_launches(lib)
+        ko, vo, tsp, idx = ops.update_kv_entries([l[0] for l in layers], [l[1] for l in layers], [l[2] for l in layers], W, 7, "avgpool", cap, 2048,
+                                                 "score", return_indices=True)
+        torch.cuda.synchronize()
+        assert _fused_launches(lib) == 1
+    finally:
+        lib.fastkv_profile_enable(0)
+    for i, (q, k, v) in enumerate(layers):
+        k1, v1, t1, i1 = ops.update_kv(q, k, v, W, 7, "avgpool", cap, 2048, "score", return_indices=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ko[i], k1) and torch.equal(vo[i], v1) and torch.equal(tsp[i:i + 1], t1) and torch.equal(idx[i:i + 1], i1), i
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted()
