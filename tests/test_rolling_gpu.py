@@ -25,9 +25,9 @@ def _inputs(B, H, Hkv, S, D, seed, dev, poison=False):
     k = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
     v = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
     if poison:                                                   # one entry with NaN / Inf keys and a NaN query row: the NaN paths of every phase
-        k[1, 2, 77] = float("nan")
-        k[1, 5, S // 2, 3] = float("inf")
-        q[1, 9, S - 3] = float("nan")
+        k[1, 2 % Hkv, 77] = float("nan")
+        k[1, 5 % Hkv, S // 2, 3] = float("inf")
+        q[1, 9 % H, S - 3] = float("nan")
     return q, k, v
 
 
@@ -242,5 +242,35 @@ def test_a_group_of_long_layers_through_the_entries_call():
         k1, v1, t1, i1 = ops.update_kv(q, k, v, W, 7, "avgpool", cap, 2048, "score", return_indices=True)
         torch.cuda.synchronize()
         assert torch.equal(ko[i], k1) and torch.equal(vo[i], v1) and torch.equal(tsp[i:i + 1], t1) and torch.equal(idx[i:i + 1], i1), i
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted()
+
+
+@pytest.mark.parametrize("H,Hkv,D,S,B", [(32, 8, 64, 32768, 5), (16, 4, 256, 32768, 6), (8, 8, 128, 32768, 4), (24, 8, 128, 20000, 7)])
+def test_rolling_launch_at_other_geometries(H, Hkv, D, S, B):
+    """Head dims 64 / 256, MHA (one query head per KV head), three query heads per KV head: rolling == regular launches, bit for bit,
+    and one scoring launch per call."""
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    W, cap = 8, 2048
+    q, k, v = _inputs(B, H, Hkv, S, D, 7 * D + B, dev, poison=True)
+    lib = ops.load()
+    prev = ops.set_fused_rolling(True)
+    lib.fastkv_profile_enable(1)
+    try:
+        _fused_launches(lib)
+        got = ops.update_kv(q, k, v, W, 7, "maxpool", cap, 2048, "score", return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        n_roll = _fused_launches(lib)
+        ops.set_fused_rolling(False)
+        ref = ops.update_kv(q, k, v, W, 7, "maxpool", cap, 2048, "score", return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        n_reg = _fused_launches(lib)
+    finally:
+        lib.fastkv_profile_enable(0)
+        ops.set_fused_rolling(prev)
+    assert n_roll == 1 and n_reg >= 1, (n_roll, n_reg)
+    for a, b in zip(got, ref):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
     from fastkv_amd._lib import raise_if_aborted
     raise_if_aborted()
