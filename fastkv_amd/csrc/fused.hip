@@ -1261,7 +1261,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts, parts);
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts * 2 / F, parts);     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
             });
             *err = hipGetLastError();
             return true;
