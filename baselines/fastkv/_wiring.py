@@ -53,6 +53,21 @@ def _mlp(module, hidden_states, static):
     return module(hidden_states)
 
 
+def _step_rotary(rotary_emb, hidden_states, position_ids, past_key_values):
+    """The rotary tables: the stock module, or -- for the one-token step over the static slab cache, default rope, fp16, on the GPU --
+    ONE launch with the module's arithmetic (`ops.decode_rotary`; the stock module runs ten small launches per step).  FASTKV_DECODE_ROTARY=0
+    keeps the module."""
+    if (hidden_states.shape[1] == 1 and hidden_states.is_cuda and hidden_states.dtype == torch.float16
+            and getattr(past_key_values, "static_decode", False) and os.environ.get("FASTKV_DECODE_ROTARY", "1") != "0"
+            and getattr(rotary_emb, "rope_type", "default") in ("default", "llama3") and position_ids.dtype == torch.int64
+            and position_ids.shape == (hidden_states.shape[0], 1) and position_ids.is_contiguous()
+            and rotary_emb.inv_freq.dtype == torch.float32 and rotary_emb.inv_freq.is_cuda and rotary_emb.inv_freq.is_contiguous()
+            and rotary_emb.inv_freq.numel() * 2 <= 256):
+        from fastkv_amd import ops
+        return ops.decode_rotary(rotary_emb.inv_freq, position_ids, float(rotary_emb.attention_scaling), 2 * rotary_emb.inv_freq.numel())
+    return rotary_emb(hidden_states, position_ids=position_ids)
+
+
 def _gemv_ok(*linears) -> bool:
     # plain fp16 `nn.Linear` without bias -- and without hooks: the fused step reads the weights directly, a hook on the module
     # (an adapter, a profiler) would silently not run
@@ -332,7 +347,7 @@ def make_model_forward(modeling, mask_fn_for):
             causal_mask = mask_fn_for(self.config)(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
                                                    past_key_values=past_key_values, position_ids=position_ids)
         hidden_states = inputs_embeds
-        position_embeddings = self.rotary_emb(hidden_states, position_ids=position_ids)
+        position_embeddings = _step_rotary(self.rotary_emb, hidden_states, position_ids, past_key_values)
         # Prefill: layers whose compressed cache is not needed while the prompt is in flight (all but the TSP layer) are compressed
         # together with their peers -- the <= 4096-token layers behind the TSP layer after the last layer, the long ones in front of
         # it in groups of up to FASTKV_DEFER_HOLD (default 8: up to seven more layers' q / k / v alive, 0.4 GB each per batch row at

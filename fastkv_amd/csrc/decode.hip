@@ -328,6 +328,21 @@ __global__ void __launch_bounds__(256) decode_greedy_kernel(const uint16_t *__re
     }
 }
 
+
+// Rotary tables of a one-token step, one launch: cos / sin [B,1,D] fp16 = LlamaRotaryEmbedding.forward / MistralRotaryEmbedding.forward
+// for ONE position per batch entry (transformers: freqs = inv_freq (fp32) x position (as fp32) -- one fp32 product --, emb = cat(freqs,
+// freqs), cos(emb) * attention_scaling -> fp16; the same device cosf / sinf).  grid B, D/2 threads.
+__global__ void __launch_bounds__(128) decode_rotary_kernel(const float *__restrict__ inv_freq, const int64_t *__restrict__ pos, float scaling,
+                                                           uint16_t *__restrict__ cosv, uint16_t *__restrict__ sinv, int half)
+{
+    const int b = blockIdx.x, d = threadIdx.x;
+    if (d >= half) return;
+    const float f = inv_freq[d] * (float)pos[b];
+    const uint16_t c = f2h(cosf(f) * scaling), sn = f2h(sinf(f) * scaling);
+    cosv[(size_t)b * 2 * half + d] = c;  cosv[(size_t)b * 2 * half + half + d] = c;
+    sinv[(size_t)b * 2 * half + d] = sn; sinv[(size_t)b * 2 * half + half + d] = sn;
+}
+
 }  // namespace fk
 
 using namespace fk;
@@ -416,6 +431,14 @@ int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q
     ProfScope ps_(K_DECODE, (hipStream_t)stream);
     hipLaunchKernelGGL(decode_rope_kernel, dim3(H + Hkv, B), dim3(128), 0, (hipStream_t)stream, (uint16_t *)q, q_strides[0], q_strides[1], H,
                        (uint16_t *)k, k_strides[0], k_strides[1], Hkv, (const uint16_t *)cosv, (const uint16_t *)sinv, cs_batch_stride, D);
+    return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
+int fastkv_decode_rotary_f16(int32_t B, int32_t D, const float *inv_freq, const int64_t *pos, float scaling, void *cosv, void *sinv, void *stream)
+{
+    if (B < 1 || D < 2 || (D & 1) || D > 256 || !inv_freq || !pos || !cosv || !sinv) return FASTKV_EINVAL;
+    ProfScope ps_(K_DECODE, (hipStream_t)stream);
+    hipLaunchKernelGGL(decode_rotary_kernel, dim3((unsigned)B), dim3(128), 0, (hipStream_t)stream, inv_freq, pos, scaling, (uint16_t *)cosv, (uint16_t *)sinv, D / 2);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 

@@ -366,6 +366,20 @@ def decode_silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def decode_rotary(inv_freq: torch.Tensor, position_ids: torch.Tensor, scaling: float, D: int):
+    """cos / sin [B,1,D] fp16 of a one-token step in ONE launch: LlamaRotaryEmbedding.forward(x, position_ids [B,1]) for fp16 `x`
+    (csrc/decode.hip decode_rotary_kernel; the stock module runs ten small launches)."""
+    _require_cuda(inv_freq, position_ids)
+    B = position_ids.shape[0]
+    assert position_ids.shape == (B, 1) and position_ids.dtype == torch.int64 and position_ids.is_contiguous()
+    assert inv_freq.dtype == torch.float32 and inv_freq.is_contiguous() and inv_freq.numel() == D // 2
+    cos = torch.empty(B, 1, D, dtype=torch.float16, device=position_ids.device)
+    sin = torch.empty_like(cos)
+    check(load().fastkv_decode_rotary_f16(B, D, inv_freq.data_ptr(), position_ids.data_ptr(), ctypes.c_float(scaling), cos.data_ptr(),
+                                          sin.data_ptr(), _stream()), "decode_rotary")
+    return cos, sin
+
+
 def new_greedy_scratch(device: torch.device, B: int) -> torch.Tensor:
     """Scratch of `decode_greedy` (zero between launches; allocate it before a capture)."""
     return torch.zeros(B + 1, dtype=torch.int64, device=device)

@@ -376,6 +376,9 @@ int fastkv_decode_rmsnorm_f16(const void *x, int64_t rows, int64_t x_row_stride,
 int fastkv_decode_rope_f16(int32_t B, int32_t H, int32_t Hkv, int32_t D, void *q, const int64_t q_strides[2], void *k,
                            const int64_t k_strides[2], const void *cosv, const void *sinv, int64_t cs_batch_stride, void *stream);
 int fastkv_decode_silu_mul_f16(const void *gate, const void *up, int64_t n, void *out, void *stream);
+/* Rotary tables of a one-token step in ONE launch: cos / sin [B,1,D] fp16 for position pos[b] (int64), the arithmetic of transformers'
+ * LlamaRotaryEmbedding.forward (fp32 product inv_freq x position, cosf / sinf, x attention_scaling, -> fp16; the stock module: ten launches). */
+int fastkv_decode_rotary_f16(int32_t B, int32_t D, const float *inv_freq, const int64_t *pos, float scaling, void *cosv, void *sinv, void *stream);
 /* Greedy sampling of a step in ONE launch (the reference's loop: `out.logits[:, -1].argmax(-1)`, /root/reference/benchmark/e2e.py:72-93):
  * tok[b] = argmax of logits row b ([B rows of V fp16 values], row stride in elements; torch.argmax's rule: the first maximal value,
  * NaN counts as maximal); optional bookkeeping of a captured step: pos[b] += 1, log[*log_index] = tok[0] (while *log_index <

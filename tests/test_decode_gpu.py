@@ -288,3 +288,25 @@ def test_greedy_step_tail_matches_torch_argmax(B, V):
         want_log.append(int(ref[0, 0]))
         assert int(pos[0, 0]) == 101 + step and int(log_index) == step + 1 and int(scratch.abs().sum()) == 0
     assert log[:6].tolist() == want_log and int(log[6]) == -1
+
+
+@pytest.mark.parametrize("B,D,theta,rope", [(1, 128, 500000.0, "llama3"), (2, 64, 10000.0, "default"), (4, 128, 1000000.0, "default")])
+def test_step_rotary_tables_match_the_stock_module(B, D, theta, rope):
+    """ops.decode_rotary (one launch) against transformers' LlamaRotaryEmbedding.forward for one position per batch entry, bit for
+    bit, at small and very large positions (llama3 rope scaling changes inv_freq only; the tables' arithmetic is the same)."""
+    from transformers import LlamaConfig
+    from transformers.models.llama import modeling_llama as ML
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(hidden_size=D * 4, num_attention_heads=4, num_key_value_heads=2, head_dim=D, max_position_embeddings=131072, rope_theta=theta)
+    if rope == "llama3":
+        cfg.rope_parameters = {"rope_type": "llama3", "rope_theta": theta, "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                               "original_max_position_embeddings": 8192}
+    mod = ML.LlamaRotaryEmbedding(cfg).to(dev)
+    x = torch.zeros(B, 1, D * 4, dtype=torch.float16, device=dev)
+    for base in (0, 1, 2047, 32768, 131071, 1048575):
+        pos = (torch.arange(B, device=dev, dtype=torch.int64) * 7 + base).view(B, 1).contiguous()
+        cos, sin = mod(x, pos)
+        gc, gs = ops.decode_rotary(mod.inv_freq, pos, float(mod.attention_scaling), D)
+        torch.cuda.synchronize()
+        assert torch.equal(gc.view(torch.int16), cos.view(torch.int16)) and torch.equal(gs.view(torch.int16), sin.view(torch.int16)), base
