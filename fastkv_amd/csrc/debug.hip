@@ -96,3 +96,14 @@ extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, flo
     hipLaunchKernelGGL(fk::debug_contract_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, out64, n);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
+
+// Test hook (host only): where a problem's token-tagged hand-off areas lie in its workspace -- {fused score records, head-sum chain,
+// split-selection tables} -- and the workspace size.  tests/test_host_logic.py: the offsets do not depend on the problem's shape.
+extern "C" int fastkv_debug_granule_areas(const fastkv_problem *p, size_t out[4])
+{
+    if (!p || !out) return FASTKV_EINVAL;
+    const fk::Layout L = fk::make_layout(*p);
+    out[0] = L.off_fpart; out[1] = L.off_fchain; out[2] = L.off_seltab; out[3] = L.total;
+    return FASTKV_OK;
+}
+

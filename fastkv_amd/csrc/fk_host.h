@@ -17,6 +17,7 @@ constexpr int FUSED_CU_SLOTS = 2048;  // {XCC_ID, SE, SH, CU} of HW_ID as an ind
 constexpr int EPOCH_STRIDE = 64;     // the workspace epoch advances by this much per operator call: sub-launch s of a call (< EPOCH_STRIDE) uses epoch + s, so
                                      // no two launches ever share a hand-off token (the xor-mixed sub index could alias another epoch's token)
 constexpr int FUSED_MAX_WGS = 1024;  // (unit, span) pairs of one fused score launch -- 512 workgroups (2 per CU) x up to 2 streams: sizes its hand-off records
+constexpr size_t SELTAB_FIXED_BYTES = (size_t)16 << 20;   // fixed area of the split selection's granule tables (rows x 2048-key chunks x 256 B: 65,536 of them)
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -76,7 +77,17 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.Sp = (p.S + 7) / 8 * 8;
     L.n_pad = (L.n + 7) / 8 * 8;
     L.ntA = (p.S + TKA - 1) / TKA;
+    // Token-tagged hand-off granules live at FIXED offsets right behind the control block, in areas of fixed size that never hold
+    // anything else: a reader accepts a granule by its 32-bit token, and memory that other data of ANOTHER call's layout has passed
+    // through (fp16 scores, logits, indices: arbitrary bit patterns) carries the current token once in 2^32 words -- found by
+    // tools/soak_rolling.py, one wrong call in 500,000 when the shapes change from call to call and the areas moved with them.
+    // Here an area only ever holds granules of earlier launches (older tokens) or the zeros of fastkv_workspace_init.
     size_t o = CTRL_BYTES;
+    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + FUSED_CU_SLOTS * 8, 256);   // fused score: row max / row sum / halo granules + one {token, unit} granule per compute unit
+    L.off_fchain = o; o += align_up((size_t)512 * 1024 * 8, 256);               // fused score, more than 4 query heads per KV head: [unit span][positions]: 512 Ki head-sum granules at most
+    const size_t seltab_bytes = align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 256, 256);   // split select: 32 8-byte granules per chunk
+    L.off_seltab = o; o += SELTAB_FIXED_BYTES;
+    const bool seltab_fits = seltab_bytes <= SELTAB_FIXED_BYTES;                 // (a call beyond that: its table lies behind the other areas, as in rounds 1-3)
     L.off_qf = o;     o += align_up((size_t)p.B * p.Hkv * L.R_alloc * p.D * 4, 256);
     L.off_logits = o; o += align_up((size_t)p.B * p.H * p.window * L.Sp * 2, 256);
     L.off_gmax = o;   o += align_up((size_t)p.B * p.H * p.window * 4, 256);
@@ -87,10 +98,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_thist = o;  o += (size_t)p.B * HIST12 * 4;                            // ... and of the TSP rows (adjacent: zeroed together)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
-    L.off_seltab = o; o += align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 256, 256);   // ... and 32 8-byte granules per chunk
-    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + FUSED_CU_SLOTS * 8, 256);   // fused score: row max / row sum / halo granules + one {token, unit} granule per compute unit
-    // fused score with more than 4 query heads per KV head: per-position head-sum granules between virtual heads
-    L.off_fchain = o; o += (p.H / p.Hkv > 4) ? align_up((size_t)512 * 1024 * 8, 256) : 0;          // [unit span][positions]: 512 Ki granules at most
+    if (!seltab_fits) { L.off_seltab = o; o += seltab_bytes; }
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {

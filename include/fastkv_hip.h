@@ -408,6 +408,9 @@ int fastkv_debug_contract(int op, const float *a, const float *b, float *out, ui
 /* Test hook of the "mfma16" contraction contract: the raw v_mfma_f32_32x32x16_f16, chained over dd / 16 chunks, on `ntiles` tiles
  * a [32][dd] x bt [32][dd] (fp16 bit patterns, row-major) on top of c [32][32] fp32 (NULL: +0) -> out [32][32]; the tests hold the
  * oracle's restatement of the instruction against it on the machine they run on. */
+/* (test hook, host only) offsets of a problem's token-tagged hand-off areas in its workspace {fused score records, head-sum chain,
+ * split-selection tables} and the workspace size: the areas lie at FIXED offsets whatever the problem's shape. */
+int fastkv_debug_granule_areas(const fastkv_problem *p, size_t out[4]);
 int fastkv_debug_mfma16(const void *a, const void *bt, const float *c, float *out, int ntiles, int dd, void *stream);
 /* Test hook: `wgs` 256-thread workgroups that each hold `lds_bytes` of LDS for `usec` microseconds -- "another kernel is
  * holding compute units" for the residency tests of the in-launch hand-offs. */

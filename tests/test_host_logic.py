@@ -162,3 +162,24 @@ def test_process_wide_switches_and_decode_workspace_sizes_without_a_gpu():
     assert L.fastkv_decode_workspace_bytes(B, H, D, 5) == (5 * per_slice + 255) // 256 * 256
     assert L.fastkv_decode_workspace_bytes(B, H, D, 0) == L.fastkv_decode_workspace_bytes(B, H, D, 64) >= 64 * per_slice
     assert L.fastkv_decode_workspace_bytes(0, H, D, 4) == 0
+
+
+def test_hand_off_areas_lie_at_fixed_offsets_of_the_workspace():
+    """A reader accepts a hand-off granule by its 32-bit token, so the areas that hold granules must never hold anything else: they lie
+    at FIXED offsets behind the control block (csrc/fk_host.h make_layout), whatever the problem's shape -- with shape-dependent offsets
+    another call's scores / logits / indices passed through them, and one call in 500,000 of a soak with changing shapes met a word
+    that carried its token (tools/soak_rolling.py).  Host-only check of the layout."""
+    import ctypes
+    from fastkv_amd._lib import load, Problem
+    L = load()
+    L.fastkv_debug_granule_areas.argtypes = [ctypes.POINTER(Problem), ctypes.POINTER(ctypes.c_size_t)]
+    L.fastkv_debug_granule_areas.restype = ctypes.c_int
+    seen = set()
+    for B, H, Hkv, S, D, cap in ((1, 32, 8, 32768, 128, 2048), (16, 32, 8, 2048, 128, 2048), (2, 64, 8, 156355, 128, 512), (1, 8, 8, 60000, 64, 2048),
+                                 (3, 16, 4, 262144, 256, 3000), (64, 32, 8, 4096, 128, 512)):
+        p = Problem(B=B, H=H, Hkv=Hkv, S=S, D=D, window=8, kernel=7, pooling=0, capacity=cap, tsp_len=0, order=1, reserved=0)
+        out = (ctypes.c_size_t * 4)()
+        assert L.fastkv_debug_granule_areas(ctypes.byref(p), out) == 0
+        assert out[3] == L.fastkv_workspace_bytes(ctypes.byref(p)) and out[0] < out[1] < out[2] < out[3]
+        seen.add((out[0], out[1], out[2]))
+    assert len(seen) == 1, seen

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 S, LAYERS, TSP_IDX, BUDGET, TSP_LEN, W = 32768, 17, 15, 2048, 2048, 8
 
 
-def _build(family, monkeypatch, defer, extra=()):
+def _build(family, monkeypatch, defer, extra=(), S=S, LAYERS=LAYERS, TSP_IDX=TSP_IDX):
     from baselines.monkeypatch import replace_llama, replace_mistral, set_model
     from benchmark import prefill
     monkeypatch.setenv("FASTKV_DEFER", defer)
@@ -59,11 +59,22 @@ def _full_q(q_win, S_):
 @pytest.mark.parametrize("defer", ["1", "0"])
 @pytest.mark.parametrize("family", ["llama", "mistral"])
 def test_32k_prefill_every_layer_against_the_oracle(family, defer, monkeypatch):
+    _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, [8, 8, 1])
+
+
+def test_70k_prefill_every_layer_against_the_oracle(monkeypatch):
+    """A prompt beyond what a regular fused scoring launch holds (70,000 tokens): the three layers in front of and including the TSP
+    layer are compressed TOGETHER -- one rolling launch whose entries are halves of a layer's KV heads (csrc/fused.hip) -- and every
+    layer's cache equals the oracle's."""
+    _prefill_against_the_oracle("llama", "1", monkeypatch, 70000, 4, 2, [3, 1])
+
+
+def _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, deferred_calls):
     from fastkv_amd import cluster as C
     from fastkv_amd import ops
     from oracle.fastkv_oracle import OracleFastKVCluster
 
-    model, a = _build(family, monkeypatch, defer)
+    model, a = _build(family, monkeypatch, defer, S=S, LAYERS=LAYERS, TSP_IDX=TSP_IDX)
     captured = {}
 
     def grab(layer_idx, cl, k, q, v):
@@ -103,7 +114,7 @@ def test_32k_prefill_every_layer_against_the_oracle(family, defer, monkeypatch):
     for h in hooks:
         h.remove()
     # the schedule under test really ran: two groups of eight (the TSP layer closing the second) + the post-TSP layer at the end
-    assert entry_calls == ([8, 8, 1] if defer == "1" else []), entry_calls
+    assert entry_calls == (deferred_calls if defer == "1" else []), entry_calls
     assert sorted(captured) == list(range(LAYERS))
     assert [captured[i][1].shape[2] for i in range(LAYERS)] == [S] * (TSP_IDX + 1) + [TSP_LEN] * (LAYERS - TSP_IDX - 1)
     assert seen == [S] * TSP_IDX + [TSP_LEN] * (LAYERS - TSP_IDX)            # the TSP layer's OUTPUT is already gathered

@@ -20,6 +20,7 @@ K = torch.randn(BMAX, SMAX, Hkv, D, generator=g, device=dev, dtype=torch.float16
 V = torch.randn(BMAX, SMAX, Hkv, D, generator=g, device=dev, dtype=torch.float16)
 side = torch.cuda.Stream()
 t0, it, bad, held = time.time(), 0, 0, 0
+history = []
 prev = ops.set_fused_rolling(True)
 while time.time() - t0 < budget_s:
     B = rng.randint(1 if SMIN > 32768 else 3, BMAX)
@@ -40,8 +41,10 @@ while time.time() - t0 < budget_s:
             saved.append((q, (e, h, r), q[e, h, r].clone()))
             q[e, h, r, 0] = float("nan")
     outs = {}
+    history.append(dict(B=B, S=S, ks=ks, pooling=pooling, cap=cap, tsp=tsp, order=order, poisoned=bool(saved), b0=b0))
+    del history[:-4]
     for rolling in (True, False):
-        ops.set_fused_rolling(rolling)
+        ops.set_fused_rolling(rolling and os.environ.get("SOAK_NO_ROLLING", "0") != "1")      # (SOAK_NO_ROLLING=1: the regular launches against themselves)
         if rolling and rng.random() < 0.25:                      # a foreign kernel takes 16-96 compute units for a few hundred microseconds
             assert L.fastkv_debug_occupy(rng.choice([16, 48, 96]), 128 * 1024, rng.choice([200, 600, 1500]), side.cuda_stream) == 0
             held += 1
@@ -57,7 +60,16 @@ while time.time() - t0 < budget_s:
             same = same and bool(torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b))
     if not same:
         bad += 1
-        print("MISMATCH", dict(it=it, B=B, S=S, ks=ks, pooling=pooling, cap=cap, tsp=tsp, order=order, poisoned=bool(saved)), flush=True)
+        which = [nm for nm, a, b in zip(("k_out", "v_out", "tsp_idx", "idx", "scores"), outs[True], outs[False])
+                 if a is not None and not torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)]
+        print("MISMATCH", dict(it=it, B=B, S=S, ks=ks, pooling=pooling, cap=cap, tsp=tsp, order=order, poisoned=bool(saved), b0=b0, differs=which), "previous groups:", history[-3:], flush=True)
+        # which of the two was wrong?  a third run on the idle chip, regular launches
+        torch.cuda.synchronize()
+        ops.set_fused_rolling(False)
+        third = ops.update_kv(q, k, v, W, ks, pooling, cap, tsp, order, return_indices=True, return_scores=True)
+        torch.cuda.synchronize()
+        agree = [all(a is None or torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b) for a, b in zip(outs[r], third)) for r in (True, False)]
+        print("   a third run (regular, idle) agrees with: first run", agree[0], ", second run", agree[1], flush=True)
     try:
         raise_if_aborted()
     except Exception as ex:   # noqa: BLE001
