@@ -71,7 +71,9 @@ typedef struct fastkv_problem {
                                 ascending head-dim order; the two produce the same bits */
 } fastkv_problem;
 
-/* Bytes of scratch `fastkv_update_kv_f16` / `fastkv_score_f16` need for this problem. */
+/* Bytes of scratch `fastkv_update_kv_f16` / `fastkv_score_f16` need for this problem (>= ~23 MiB: the hand-off records of the fused
+ * scoring kernel and of the split selection lie in fixed-size areas at fixed offsets behind the control block, whatever the shape, so
+ * that calls of DIFFERENT shapes can share one workspace: an area that holds token-tagged records never holds anything else). */
 size_t fastkv_workspace_bytes(const fastkv_problem *p);
 
 /*
