@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.environ.get("FASTKV_BUILD_DIR") or os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfastkv_hip.so")
 SOURCES = ["score.hip", "fused.hip", "select.hip", "compact.hip", "sp.hip", "decode.hip", "decode_step.hip", "gemv.hip", "capi.hip", "debug.hip", "prof.hip"]
-HEADERS = ["fk_device.h", "fk_host.h", "prof.h", "rank.h", "mfma_tile.h", os.path.join("..", "..", "include", "fastkv_hip.h")]
+HEADERS = ["fk_device.h", "fk_hunt.h", "fk_host.h", "prof.h", "rank.h", "mfma_tile.h", os.path.join("..", "..", "include", "fastkv_hip.h")]
 # -ffp-contract=off: the arithmetic contract (csrc/fk_device.h) spells every fma out; nothing may be fused or split
 # `-target-feature -packed-fp32-ops`: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code (the same IEEE operations per
 # component, issued one by one: +1.4 us on the 77.5 us two-layer scoring launch in the trace, inside the noise of the step).  Why: a workgroup of the fused scoring kernel that

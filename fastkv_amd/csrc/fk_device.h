@@ -11,34 +11,7 @@
 
 #define FK_WAVE 64
 
-#ifdef FK_DBG_VALU_SHFL
-// Hunt: every __shfl_xor of this translation unit without the LDS crossbar -- v_permlane32_swap / v_permlane16_swap
-// (gfx950) for the masks 32 / 16, DPP for 8 / 4 / 2 / 1.  Measurement builds only.
-namespace fk {
-__device__ __forceinline__ uint32_t dbg_xor_u32(uint32_t v, int mask)
-{
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (mask == 32) { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
-    if (mask == 16) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
-    if (mask == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);                 // row_ror:8
-    if (mask == 4) {
-        const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);               // row_shr:4: lane i <- i - 4
-        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);               // row_shl:4: lane i <- i + 4
-        return (lane & 4) ? a : b;
-    }
-    if (mask == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, true);                  // quad_perm [2,3,0,1]
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);                                 // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ float dbg_shfl_xor(float v, int m, int) { return __builtin_bit_cast(float, dbg_xor_u32(__builtin_bit_cast(uint32_t, v), m)); }
-__device__ __forceinline__ int dbg_shfl_xor(int v, int m, int) { return (int)dbg_xor_u32((uint32_t)v, m); }
-__device__ __forceinline__ uint32_t dbg_shfl_xor(uint32_t v, int m, int) { return dbg_xor_u32(v, m); }
-__device__ __forceinline__ uint64_t dbg_shfl_xor(uint64_t v, int m, int)
-{
-    return ((uint64_t)dbg_xor_u32((uint32_t)(v >> 32), m) << 32) | dbg_xor_u32((uint32_t)v, m);
-}
-}  // namespace fk
-#define __shfl_xor(v, m, w) fk::dbg_shfl_xor((v), (m), (w))
-#endif
+#include "fk_hunt.h"   // measurement switches of the round-3 hunt: every macro is empty unless the build defines FK_HUNT
 
 namespace fk {
 

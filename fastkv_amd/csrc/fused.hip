@@ -51,9 +51,7 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 // order {HW_ID, XCC_ID, unit, span}.  The pairing of workgroups that share a compute unit (see the kernel) rests on the dispatch order
 // of the GPU: tests/test_hip_parity.py reads this back and checks it on the machine it runs on.
 __device__ uint32_t g_placement[1024 * 4];
-#ifdef FK_DBG_DELAY
-__device__ int g_dbg_delay_ticks = 1500;                         // 100 MHz ticks per delay of the measurement builds (fastkv_debug_set_delay)
-#endif
+FKH_GLOBALS                                                      // (hunt builds only: csrc/fk_hunt.h)
 constexpr int FUSED_PARTS = 8;      // 256 threads = 32 rows x 8 slices of the nblk partial records
 
 // Hand-off records are 8-byte {token, 32-bit value} granules, written by ONE write-through (sc1) store each: the data is
@@ -69,9 +67,7 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
         for (int l = lane; l < nblk; l += 64)
             ok = ok && ((uint32_t)(__hip_atomic_load(rec + (size_t)l * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token);
         if (__all(ok)) break;
-#ifndef FK_DBG_NOSLEEP
-        __builtin_amdgcn_s_sleep(8);
-#endif
+        FKH_POLL_SLEEP();
         if (__builtin_amdgcn_readfirstlane((int)spin_failed(sp))) return false;     // a partner never arrived: give up, loudly (host flag)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: every load of handed-over bytes is an sc1 load
@@ -101,9 +97,6 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
                                                              const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts)
 {
-#if defined(FK_DBG_DELAY) && !defined(FK_DBG_WHO)
-#define FK_DBG_WHO (yb == 0)
-#endif
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
     static_assert(PER % NS == 0, "tiles split evenly over the streams");
@@ -135,9 +128,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     __shared__ uint32_t s_rb[FUSED_PARTS][32];
     __shared__ float s_gm[NS][32], s_ri[NS][32];               // row maxima / reciprocal row sums of the streams' heads
     __shared__ uint32_t s_abort;
-#ifdef FK_DBG_SYNCAND
-    __shared__ uint32_t s_dbg_flag;
-#endif
+    FKH_SHARED
     const unsigned tix = threadIdx.x;
     const int lane = tix & 63, w = __builtin_amdgcn_readfirstlane(tix >> 6);
     // Entries 1 .. F-1 of a rolling launch (launch_score_fused; `rolling` = F, the entries the chip holds at a time) start late ON
@@ -163,11 +154,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     const int UPE = rolling ? UP / parts : UP;                   // units per entry of this launch
     const int nblk = gridDim.x / UPE;
     int hvp, blk, yb, ent = 0, part_base = 0;
-#ifdef FK_OLD_NUMBERING                                          // (measurement builds of the hunt in DESIGN.md section 8 only)
-    if (false) {
-#else
-    if (NS == 1 && !rolling) {                                   // (a rolling launch: entry = blockIdx.y, one workgroup per compute unit and entry)
-#endif
+    if (NS == 1 && !rolling && !FKH_OLD_NUMBERING) {             // (a rolling launch: entry = blockIdx.y, one workgroup per compute unit and entry)
         const int T = gridDim.x * gridDim.y, p = blockIdx.y * gridDim.x + blockIdx.x, P = T > ncu ? T - ncu : 0;
         const int l = p >= ncu ? 2 * (p - ncu) + 1 : (p < P ? 2 * p : 2 * P + (p - P));     // logical index: unit-major, span fastest
         const int unit = l / nblk;
@@ -268,9 +255,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                         __HIP_MEMORY_SCOPE_AGENT);
     }
     FKF_STAMP(0);
-#if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 8
-    if (FK_DBG_WHO) { const uint64_t t_end = wall_clock64() + g_dbg_delay_ticks; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }   // (fastkv_debug_set_delay; default 15 us)
-#endif
+    FKH_DELAY_AT_START();
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
     // is published, so passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of
@@ -360,38 +345,11 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     const bool more = nt < PER && tile_wt(nt) < nwt;
                     const uint16_t *nkb = kb_s[(nt / PS) % NS];
                     const int nkey = tile_key0(nt);
-#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_NOLDS)          // hunt: the delayed workgroups stage no K (no LDS writes, no loads)
-                    if (FK_DBG_WHO) { }
-                    else
-#endif
+                    FKH_MATE_NO_STAGING
                     if (useA) { k_commit<NB>(sA, lane, my); if (more) k_fetch<NB>(sA, nkb, ks_s, nkey, S, nph, lane); }
                     else { k_commit<NB>(sB, lane, my); if (more) k_fetch<NB>(sB, nkb, ks_s, nkey, S, nph, lane); }
                     __builtin_amdgcn_sched_barrier(0);
-#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_NOMFMA)         // ... or issue no MFMA (and read no LDS)
-                    if (!(FK_DBG_WHO))
-#endif
-#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_VALUCVT)        // ... or convert K on the vector ALU: fp32 MFMAs only, none of the fp16 ones
-                    if (FK_DBG_WHO) mfma_phase<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, sh);
-                    else
-#endif
-#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_CUT)            // ... or one of the cuts of mfma_phase_mx (mfma_tile.h)
-                    if (FK_DBG_WHO) mfma_phase_mx<NB, FK_DBG_MATE_CUT>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
-                    else
-#endif
-#if defined(FK_DBG_DELAY) && defined(FK_DBG_MATE_REGMFMA)        // ... or the same MFMAs on register operands: no LDS read in the matrix phase
-                    if (FK_DBG_WHO) {
-                        f32x16 z9;
-                        for (int i9 = 0; i9 < 16; ++i9) z9[i9] = 0.0f;
-                        for (int r9 = 0; r9 < 4; ++r9) {
-                            z9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pm0, pm1, z9, 0, 0, 0);
-                            z9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pm1, pm0, z9, 0, 0, 0);
-                        }
-                        for (int r9 = 0; r9 < 32; ++r9) {
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(z9[r9 & 15], 1.0f, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, z9[r9 & 15], acc1, 0, 0, 0);
-                        }
-                    } else
-#endif
+                    FKH_MATE_PHASE
                     if (F16) mfma_phase_f16<NB>(acc0, acc1, my, reinterpret_cast<const f16x8 *>(As + s * AS_FLOATS) + ph * 4 * 64 + lane, n31, hi);
                     else
                     mfma_phase_mx<NB>(acc0, acc1, my, As + s * AS_FLOATS + ph * (DH / 2) * 64 + lane, n31, hi, pm0, pm1);
@@ -400,23 +358,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 FKF_STAMP(17 + 2 * (t % 2));
-#if defined(FK_DBG_DELAY) && FK_DBG_DELAY < 8
-                if (FK_DBG_WHO) {                                // debug: some workgroups are slow in phase A (no NaN involved)
-                    const uint64_t t_end = wall_clock64() + g_dbg_delay_ticks;     // 100 MHz ticks: 15 us per tile unless set otherwise
-#if FK_DBG_DELAY == 6
-                    // every workgroup, but only SOME of its waves (a hash of workgroup, wave and tile picks them): the waves of a workgroup
-                    // reach the end of phase A far apart -- does the kernel depend on its waves running in step?
-                    if ((((blockIdx.y * gridDim.x + blockIdx.x) * 2654435761u + w * 40503u + t * 977u) >> 7 & 3u) == 0u)
-                        while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
-#elif FK_DBG_DELAY == 4
-                    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
-#else
-                    float zz = acc0[0];
-                    while (wall_clock64() < t_end) { for (int q9 = 0; q9 < 64; ++q9) zz = __builtin_fmaf(zz, 1.0000001f, 1e-30f); }
-                    if (zz == 123.456f) acc0[0] = zz;
-#endif
-                }
-#endif
+                FKH_DELAY_AFTER_TILE();
                 if (F16) {
                     // the instruction follows IEEE on Inf / NaN operands, element by element, and so does the oracle's restatement of
                     // it: nothing to redo -- only remember that the tile holds a NaN (general softmax path later on)
@@ -502,12 +444,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // (returns false when the launch is abandoned: every thread of the workgroup leaves)
     auto read_max = [&](auto sc) -> bool {
         constexpr int s = decltype(sc)::value;
-#if defined(FK_DBG_DELAY) && defined(FK_DBG_VICTIM_WAIT)          // hunt: everybody ELSE sits out 150 us between phase A and the first hand-off
-        if (!(FK_DBG_WHO)) { const uint64_t t_end = wall_clock64() + 15000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }
-#endif
-#if defined(FK_DBG_DELAY) && FK_DBG_DELAY == 9
-        if (FK_DBG_WHO) { const uint64_t t_end = wall_clock64() + g_dbg_delay_ticks; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8); }   // (fastkv_debug_set_delay; default 15 us)
-#endif
+        FKH_BEFORE_FIRST_HANDOFF();
         const uint64_t *pm = pmax + (size_t)bgv_s[s] * nblk * 32;     // [nblk][32] granules: row maxima
         if (w == 0 && !wait_first_granules(pm, 32, nblk, token, lane, sp)) s_abort = 1;
         __syncthreads();
@@ -531,15 +468,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                 }
             }
             s_rf[part][row] = v;
-#ifdef FK_DBG_SYNCAND
-            if (tix == 0) s_dbg_flag = 0;
-            __syncthreads();
-            if (!ok) s_dbg_flag = 1;
-            __syncthreads();
-            if (!s_dbg_flag) break;
-#else
-            if (__syncthreads_and(ok)) break;
-#endif
+            if (FKH_SYNC_AND(ok)) break;
             if (tix == 0 && spin_failed(sp)) s_abort = 1;      // a record behind a current granule 0 is still old: rare
             __syncthreads();
             if (s_abort) return false;
@@ -679,15 +608,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
             }
             s_ru[part][row] = s2;
             s_rb[part][row] = bad;
-#ifdef FK_DBG_SYNCAND
-            if (tix == 0) s_dbg_flag = 0;
-            __syncthreads();
-            if (!ok) s_dbg_flag = 1;
-            __syncthreads();
-            if (!s_dbg_flag) break;
-#else
-            if (__syncthreads_and(ok)) break;
-#endif
+            if (FKH_SYNC_AND(ok)) break;
             if (tix == 0 && spin_failed(sp)) s_abort = 1;
             __syncthreads();
             if (s_abort) return false;
@@ -855,9 +776,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     if (all_keys) all_keys[(size_t)bg * all_key_stride + j] = (uint16_t)mono16(c16);
                 }
             }
-#ifndef FK_DBG_NO_HIST
-            if (want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
-#endif
+            if (FKH_HIST && want_hist && last_vh) hist12_add(s_hist, mono16(c16) >> 4, is_out, lane);
         }
         FKF_STAMP(31);
         if (all_keys && last_vh && blk == 0 && (int)tix < (int)(all_key_stride - n)) all_keys[(size_t)bg * all_key_stride + n + tix] = 0;
@@ -1187,9 +1106,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [unit span][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
     uint64_t *cu_slots = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8));
-#ifdef FK_OLD_NUMBERING
-    cu_slots = nullptr;                                          // (measurement builds: other units share compute units by design, every workgroup would report)
-#endif
+    if (FKH_OLD_NUMBERING) cu_slots = nullptr;                   // (hunt builds: other units share compute units by design, every workgroup would report)
     uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
     // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
     // for each other until the spin limit and be reported as FASTKV_EABORTED).  Within this process the library sees to it:
@@ -1339,7 +1256,7 @@ extern "C" int fastkv_debug_fused_placement(int enable, unsigned int *host, size
     if (n_words > 1024 * 4) return FASTKV_EINVAL;
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::g_placement), n_words * sizeof(unsigned int)) == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
-#ifdef FK_DBG_DELAY
+#if defined(FK_HUNT) && defined(FK_DBG_DELAY)
 extern "C" int fastkv_debug_set_delay(int ticks)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_delay_ticks), &ticks, sizeof(int)) == hipSuccess ? 0 : -3;

@@ -1,4 +1,4 @@
-"""Experiment (measurement build: FASTKV_BUILD_DIR=build_x_stag FASTKV_CXXFLAGS="-DFK_OLD_NUMBERING -DFK_DBG_DELAY=8 -DFK_DBG_WHO=(yb==1)"):
+"""Experiment (measurement build: FASTKV_BUILD_DIR=build_x_stag FASTKV_CXXFLAGS="-DFK_HUNT -DFK_OLD_NUMBERING -DFK_DBG_DELAY=8 -DFK_DBG_WHO=(yb==1)"):
 the pair launch of score_fused with the two layers' workgroups sharing compute units (old numbering: workgroup (x, layer 0) beside
 (x, layer 1)) and layer 1 started DELAY_TICKS late -- does one layer's memory-bound phase A overlap the other's vector phases?
 Inputs rotate over six K sets (0.8 GB) so that nothing is served by the 256 MB Infinity Cache."""

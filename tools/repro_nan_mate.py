@@ -22,7 +22,7 @@ if kind == "KALL": k[0, 0, :, 17] = float("nan")
 want = O.update_kv(q, k, v, W, ks, "avgpool", cap, tsp_len, "index", return_scores=True)
 qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
 wsc = want[4].view(torch.int16)
-if os.environ.get("DELAY_TICKS"):                        # measurement builds with -DFK_DBG_DELAY: the length of a delay in 100 MHz ticks
+if os.environ.get("DELAY_TICKS"):                        # measurement builds with -DFK_HUNT -DFK_DBG_DELAY (csrc/fk_hunt.h): the length of a delay in 100 MHz ticks
     from fastkv_amd._lib import load
     assert load().fastkv_debug_set_delay(int(os.environ["DELAY_TICKS"])) == 0
 nbad = 0
