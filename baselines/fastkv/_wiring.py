@@ -314,6 +314,20 @@ def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, positi
     return hidden_states
 
 
+def defer_hold_for(config, batch: int, seq_len: int, itemsize: int = 2) -> int:
+    """Layers per group of the deferred compression: FASTKV_DEFER_HOLD (default 8), capped by what the waiting layers hold alive
+    (ADVICE r04): a waiting layer keeps its q / k / v -- batch x seq_len x (H + 2 Hkv) x D elements, 0.4 GB per batch row at 32k, 1.6 GB
+    at 128k -- and hold - 1 layers wait at a time; FASTKV_DEFER_HOLD_GIB (default 4) bounds that sum.  32k, batch 1: 8 (2.8 GB held);
+    128k or 32k x batch 4: 3 (3.2 GB); a prompt whose single layer exceeds the bound: 1 = layer by layer."""
+    hold = int(os.environ.get("FASTKV_DEFER_HOLD", "8"))
+    budget = float(os.environ.get("FASTKV_DEFER_HOLD_GIB", "4")) * 2 ** 30
+    heads = getattr(config, "num_attention_heads", 32)
+    kvh = getattr(config, "num_key_value_heads", None) or heads
+    hd = getattr(config, "head_dim", None) or config.hidden_size // heads
+    per_layer = batch * seq_len * (heads + 2 * kvh) * hd * itemsize
+    return max(1, min(hold, int(budget // max(1, per_layer)) + 1))
+
+
 def make_model_forward(modeling, mask_fn_for):
     def model_forward_fastkv(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                              inputs_embeds=None, use_cache=None, **kwargs):
@@ -359,7 +373,8 @@ def make_model_forward(modeling, mask_fn_for):
                 and os.environ.get("FASTKV_DEFER", "1") != "0":
             from fastkv_amd.cluster import DeferredCompression
             defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")),
-                                        hold_long=int(os.environ.get("FASTKV_DEFER_HOLD", "8")))
+                                        hold_long=defer_hold_for(self.config, inputs_embeds.shape[0], inputs_embeds.shape[1],
+                                                                 inputs_embeds.element_size()))
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:
             hidden_states = decoder_layer(hidden_states, attention_mask=causal_mask, position_embeddings=position_embeddings,
                                           position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,

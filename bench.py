@@ -62,15 +62,23 @@ def make_layer_inputs(S, gen, dev):
     return q, k, v
 
 
+# The reference's PUBLISHED recipe (/root/reference/scripts/eval_prefill.sh:4-12: --tsp_idx 15 --tsp_rate 0.2 --retain_rate 0.1 --eviction_mode
+# proportional; pooling / window / kernel at the harness defaults): at 32k every layer up to the TSP layer keeps int(32768 * 0.1) = 3276 rows,
+# the TSP layer hands int(32768 * 0.2) = 6553 tokens on, the 16 layers behind it keep int(6553 * 0.5) = 3276 of 6553 (utils.py:41-46, :86-87, :123-124)
+RECIPE = dict(eviction_mode="proportional", retain_rate=0.1, tsp_rate=0.2)
+
+
 class HotPathPrefill:
-    def __init__(self, dev, seed):
+    def __init__(self, dev, seed, recipe=False):
         from fastkv_amd import FastKVCluster, compress_fastkv
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         L, S = CFG["layers"], CFG["S"]
+        self.recipe = recipe
+        self.tsp_len = int(S * RECIPE["tsp_rate"]) if recipe else CFG["tsp_len"]       # tokens behind the TSP layer
         self.layers_in = []
         for i in range(L):
-            s_i = S if i <= CFG["tsp_idx"] else CFG["tsp_len"]
+            s_i = S if i <= CFG["tsp_idx"] else self.tsp_len
             self.layers_in.append(make_layer_inputs(s_i, gen, dev))
         self.hidden = torch.randn(1, S, CFG["hidden"], generator=gen, device=dev, dtype=torch.float16)
         self.position_ids = torch.arange(S, device=dev)[None]
@@ -80,6 +88,9 @@ class HotPathPrefill:
         args = types.SimpleNamespace(window_size=[CFG["window"]] * L, kernel_size=[CFG["kernel"]] * L, pooling=CFG["pooling"],
                                      max_capacity_prompts=CFG["budget"], tsp_len=CFG["tsp_len"], tsp_rate=0.2,
                                      eviction_mode="constant", tsp_idx=CFG["tsp_idx"], retain_rate=0.1)
+        if recipe:
+            args.max_capacity_prompts, args.eviction_mode = 512, RECIPE["eviction_mode"]     # (the budget flag is at its default and unused)
+            args.retain_rate, args.tsp_rate = RECIPE["retain_rate"], RECIPE["tsp_rate"]
         compress_fastkv(self.model, args)
         self.clusters = [l.self_attn.kv_cluster for l in layers]
         self.defer = os.environ.get("FASTKV_DEFER", "1") != "0"
@@ -184,62 +195,151 @@ def compact_roofline_shape(lib, dev, steps):
     return res
 
 
-def cpu_baseline(work: HotPathPrefill):
-    """CPU oracle (port of utils.py:80-134) on host cores: 2 pre-TSP layers + 2 post-TSP layers + the hidden gather,
-    scaled to the 16 + 16 layers of one step."""
+def _effective_cpus():
+    """(logical CPUs in this process's affinity mask, CPU quota of its cgroup in cores or None).  A container may see all of the host's
+    CPUs in its mask and still be throttled to a few cores' worth of time by cpu.max: OpenMP threads beyond the quota are descheduled
+    in turns, and every barrier then waits for the slowest."""
+    # (FASTKV_BENCH_NCPU: the mask as the PARENT saw it -- with OMP_PROC_BIND set, libgomp binds a process's initial thread to its
+    # first place when it is loaded, i.e. at `import torch`: the child's own mask then reads 1 CPU)
+    n = int(os.environ.get("FASTKV_BENCH_NCPU", "0")) or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    quota = None
+    try:
+        f = open("/sys/fs/cgroup/cpu.max").read().split()                     # cgroup v2: "<quota> <period>" or "max <period>"
+        if f and f[0] != "max":
+            quota = float(f[0]) / float(f[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())      # cgroup v1
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q_ > 0 and p_ > 0:
+                quota = q_ / p_
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
+def cpu_baseline_child_main() -> int:
+    """`bench.py --cpu-baseline-child`: the CPU leg in its OWN process -- started by rank 0 of the N = 1 run before it creates its
+    workload, with OMP_PROC_BIND=close / OMP_PLACES=cores in the environment and no GPU work anywhere in it.  Nothing else of the bench
+    shares the process: no torch intra-op pool spinning beside the oracle's OpenMP team (torch is pinned to ONE thread here and only
+    makes the input tensors), no allocator state of the GPU run.  Prints one `CPU_JSON {...}` line.
+
+    What is timed: the oracle (oracle/fastkv_oracle.c, a port of utils.py:80-134) on synthetic fp16 inputs of the step's shapes:
+    layers 0, 1 (S = 32768), 15 (S = 32768, TSP), 16, 17 (S = 2048) + the hidden gather; 1 warm-up + 5 timed calls each, the MEDIAN
+    scaled to the step's 15 + 1 + 16 layers (`best` beside it).  Contraction contracts: "fmaf" -- the fp32 fma chain, a CPU's native
+    arithmetic and the closest thing to the reference's own CPU matmul -- is the baseline's `value`; "mfma16" -- the integer
+    restatement of the gfx950 matrix instruction, the contract the GPU headline runs -- is timed beside it on layers 0 and 16."""
+    import statistics
+    torch.set_num_threads(1)
     from oracle import fastkv_oracle as O
     from oracle.fastkv_oracle import OracleFastKVCluster
-    G = CFG["H"] // CFG["Hkv"]
-    # The CPU leg times the fp32-fma-chain contraction (what a CPU computes natively: AVX-512 FMAs), not the oracle's integer
-    # restatement of the gfx950 matrix instruction (the default contract, ~5x slower on a CPU and no CPU's native arithmetic)
+    H, Hkv, D, S, W = CFG["H"], CFG["Hkv"], CFG["D"], CFG["S"], CFG["window"]
+    G = H // Hkv
+    ncpu, quota = _effective_cpus()
+    load0 = os.getloadavg()[0] if hasattr(os, "getloadavg") else None
+    gen = torch.Generator().manual_seed(4321)
+
+    def layer(s_i):
+        q = torch.zeros(1, s_i, H, D, dtype=torch.float16)                   # (only the last W rows of q are ever read: utils.py:93)
+        q[:, s_i - W:] = torch.randn(1, W, H, D, generator=gen).half()
+        k = torch.randn(1, s_i, Hkv, D, generator=gen).half()
+        v = torch.randn(1, s_i, Hkv, D, generator=gen).half()
+        return q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+
+    q0, k0, v0 = layer(S)
     O.set_contraction("fmaf")
-    # pick the OpenMP thread count that is fastest on this host (hyper-threads / all 256 logical CPUs are slower)
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    q0, k0, v0 = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[0])
-    best = (None, 1e9)
-    for nt in sorted({min(ncpu, x) for x in (16, 32, 64, 128)}):
+    limit = ncpu if quota is None else max(1, min(ncpu, int(quota)))
+    cands = sorted({min(limit, x) for x in (16, 32, 64, 128)})
+    picks = {}
+    for nt in cands:
         O.set_threads(nt)
-        O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
-        dt = 1e9
-        for _ in range(2):
+        O.update_kv(q0, k0, v0, W, CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
+        ts = []
+        for _ in range(3):
             t0 = time.perf_counter()
-            O.update_kv(q0, k0, v0, CFG["window"], CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
-            dt = min(dt, time.perf_counter() - t0)
-        if dt < best[1]:
-            best = (nt, dt)
-    cores = best[0]
+            O.update_kv(q0, k0, v0, W, CFG["kernel"], CFG["pooling"], CFG["budget"], 0, "score")
+            ts.append(time.perf_counter() - t0)
+        picks[nt] = round(statistics.median(ts) * 1e3, 2)
+    cores = min(picks, key=picks.get)
     O.set_threads(cores)
 
-    def cpu_layer(i):
-        q, k, v = (t.transpose(1, 2).contiguous().cpu().transpose(1, 2) for t in work.layers_in[i])
-        c = work.clusters[i]
-
-        def fresh():                                                         # update_kv may mutate the cluster (proportional mode)
-            return OracleFastKVCluster(c.window_size, c.max_capacity_prompt, c.kernel_size, c.pooling, c.tsp_layer, c.tsp_length,
-                                       c.tsp_rate, c.retain_rate, c.eviction_mode)
-
-        fresh().update_kv(k, q, v, None, G, i)                               # warm-up (page-in, thread pool)
-        best_t, out = 1e9, None
-        for _ in range(3):                                                   # the host is shared: best of 3
-            oc = fresh()
+    def timed(inp, kw, runs=5):
+        q, k, v = inp
+        OracleFastKVCluster(**kw).update_kv(k, q, v, None, G, 0)             # warm-up (page-in, thread team)
+        ts, out = [], None
+        for _ in range(runs):
+            oc = OracleFastKVCluster(**kw)
             t0 = time.perf_counter()
-            out = oc.update_kv(k, q, v, None, G, i)
-            best_t = min(best_t, time.perf_counter() - t0)
-        return best_t, out
+            out = oc.update_kv(k, q, v, None, G, 0)
+            ts.append(time.perf_counter() - t0)
+        return ts, out
 
-    t_pre = [cpu_layer(i)[0] for i in (0, 1)]
-    t_tsp, out = cpu_layer(CFG["tsp_idx"])
-    t_post = [cpu_layer(i)[0] for i in (16, 17)]
-    hid = work.hidden[0].cpu()
-    t0 = time.perf_counter()
-    O.gather_rows(hid, out[2][0].contiguous())
-    t_g = time.perf_counter() - t0
-    step_s = 15 * (sum(t_pre) / 2) + t_tsp + 16 * (sum(t_post) / 2) + t_g
-    return {"value": round(CFG["S"] / step_s, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "ms_per_step": round(step_s * 1e3, 1),
-            "contraction": "fmaf (fp32 fma chain, the CPU's native arithmetic)",
-            "sample": "oracle update_kv: layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, 1 warm-up + best of 3 timed "
-                      f"each, scaled to 15+1+16 layers; OpenMP threads auto-picked from 16/32/64/128 on {ncpu} logical CPUs"}
+    base = dict(window_size=W, max_capacity_prompt=CFG["budget"], kernel_size=CFG["kernel"], pooling=CFG["pooling"], tsp_length=CFG["tsp_len"])
+    inputs = {0: (q0, k0, v0), 1: layer(S), CFG["tsp_idx"]: layer(S), 16: layer(CFG["tsp_len"]), 17: layer(CFG["tsp_len"])}
+    per_layer, tsp_out = {}, None
+    for i, inp in inputs.items():
+        ts, out = timed(inp, dict(base, tsp_layer=(i == CFG["tsp_idx"])))
+        per_layer[i] = ts
+        if i == CFG["tsp_idx"]:
+            tsp_out = out[2]
+    hid = torch.randn(S, CFG["hidden"], generator=gen).half()
+    tg = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.gather_rows(hid, tsp_out[0].contiguous())
+        tg.append(time.perf_counter() - t0)
+
+    def step_of(f):
+        return 15 * (f(per_layer[0]) + f(per_layer[1])) / 2 + f(per_layer[CFG["tsp_idx"]]) + 16 * (f(per_layer[16]) + f(per_layer[17])) / 2 + f(tg)
+
+    step_med, step_best = step_of(statistics.median), step_of(min)
+    # the contract the GPU headline runs, on two of the sampled layers
+    O.set_contraction("mfma16")
+    m_pre, _ = timed(inputs[0], dict(base, tsp_layer=False), runs=3)
+    m_post, _ = timed(inputs[16], dict(base, tsp_layer=False), runs=3)
+    O.set_contraction("fmaf")
+    m_step = 16 * statistics.median(m_pre) + 16 * statistics.median(m_post) + statistics.median(tg)
+    res = {"value": round(S / step_med, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
+           "ms_per_step": round(step_med * 1e3, 1), "ms_per_step_best": round(step_best * 1e3, 1),
+           "contraction": "fmaf (fp32 fma chain: the CPU's native arithmetic, the closest restatement of the reference's own CPU matmul)",
+           "per_layer_ms": {str(i): {"median": round(statistics.median(t) * 1e3, 2), "best": round(min(t) * 1e3, 2), "runs": len(t)}
+                            for i, t in per_layer.items()},
+           "hidden_gather_ms": round(statistics.median(tg) * 1e3, 2),
+           "thread_candidates_ms_layer0": {str(k_): v_ for k_, v_ in picks.items()},
+           "same_contract_as_headline": {"contraction": "mfma16 (integer restatement of v_mfma_f32_32x32x16_f16)", "ms_per_step": round(m_step * 1e3, 1),
+                                         "tokens_per_s": round(S / m_step, 1), "layer0_ms": round(statistics.median(m_pre) * 1e3, 2),
+                                         "layer16_ms": round(statistics.median(m_post) * 1e3, 2),
+                                         "sample": "layers 0 (S=32768) and 16 (S=2048), 1 warm-up + 3 timed, median, scaled to 16 + 16 layers + the gather"},
+           "host": {"logical_cpus_in_mask": ncpu, "cgroup_cpu_quota_cores": quota, "loadavg_1m_before": load0,
+                    "loadavg_1m_after": os.getloadavg()[0] if hasattr(os, "getloadavg") else None,
+                    "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+           "sample": "own process, before the GPU run starts; oracle update_kv on layers 0,1 (S=32768), 15 (TSP), 16,17 (S=2048) + hidden gather, "
+                     "1 warm-up + 5 timed each, MEDIAN scaled to 15+1+16 layers; OpenMP threads picked from "
+                     f"{cands} (median of 3 on layer 0) on {ncpu} logical CPUs" + (f", cgroup quota {quota:.1f} cores" if quota else "")}
+    print("CPU_JSON " + json.dumps(res), flush=True)
+    return 0
+
+
+def cpu_baseline(timeout_s=240):
+    """Runs the CPU leg (cpu_baseline_child_main) in a child process and returns its object.  Called by rank 0 of the N = 1 run before
+    it has created its workload or touched the GPU with anything heavy: the host cores are idle, no thread pool of this process
+    exists in the child."""
+    import subprocess
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") and
+           not k_.startswith("TORCHELASTIC_")}
+    env["FASTKV_BENCH_NCPU"] = str(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    env.setdefault("OMP_PROC_BIND", "close")
+    env.setdefault("OMP_PLACES", "cores")
+    env.pop("OMP_NUM_THREADS", None)                                          # (the launcher pins it to 8 for the ranks; the oracle sets its own)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], env=env, capture_output=True, text=True,
+                           timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the CPU leg did not finish within {timeout_s} s", "kind": "port"}
+    for line in r.stdout.splitlines():
+        if line.startswith("CPU_JSON "):
+            return json.loads(line[len("CPU_JSON "):])
+    return {"error": f"the CPU leg exited with code {r.returncode}", "stderr_tail": r.stderr[-400:], "kind": "port"}
 
 
 def whole_model_ttft(work):
@@ -484,13 +584,12 @@ def self_launch(a) -> int:
     line = None
     for ln in proc.stdout:                                        # ranks print nothing but rank 0's ONE JSON line on stdout
         ln = ln.rstrip("\n")
-        if ln.startswith("{") and '"metric"' in ln:
+        if ln.startswith("{") and '"metric"' in ln and line is None:
             line = ln
+            print(line, flush=True)                              # at once: the long legs behind it report on stderr
         elif ln:
             print(ln, file=sys.stderr)
     rc = proc.wait()
-    if line is not None:
-        print(line, flush=True)
     if rc == 0 and line is None:
         print("bench.py: the ranks exited cleanly but printed no contract line", file=sys.stderr)
         rc = 1
@@ -517,7 +616,35 @@ def rehearse(a, rank, world) -> int:
     return 0
 
 
+def contract_line(world, steps, warmup, ms_per_step, contraction, ranks_seen, backend, violations, defer, defer_hold):
+    """The keys the bench contract names (and the few this path adds), the same for every N -- tests/test_bench_contract.py holds an
+    N = 1 and an N = 8 line to it.  `value` = prompt tokens of ALL ranks / the slowest rank's time for `steps` steps."""
+    value = world * CFG["S"] / (ms_per_step * 1e-3)
+    out = {"metric": "prefill_hotpath_tokens_per_s", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "FastKV hot path (score+select+compact, 32 layers + TSP gather) of one Llama-3-8B prefill, "
+                                  "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
+                      "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
+           "ttft_hotpath_ms": round(ms_per_step, 4),
+           # the arithmetic contract of the contraction (utils.py:94) both sides run by default: "mfma16" = the gfx950 fp16 matrix
+           # instruction on the fp16 operands, restated bit for bit by the oracle; "fmaf" = the fp32 fma chain (FASTKV_CONTRACTION)
+           "contraction": contraction, "ranks_seen": ranks_seen, "backend": backend,
+           # the fused launches' own check of where their workgroups ran (include/fastkv_hip.h: fastkv_placement_violations): 0 = every
+           # pair of workgroups that shared a compute unit in the warm-up and timed steps belonged to one head, as the kernel assumes
+           "placement_violations": violations}
+    if os.environ.get("FASTKV_FUSED") == "0":
+        out["no_wait_kernels"] = "FASTKV_FUSED=0: staged scoring + wait-free selection (what ranks that share one GPU must run)"
+    out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
+                                 f"sequence after the last layer, the layers in front of it in groups of {defer_hold} (FASTKV_DEFER_HOLD: a layer waits "
+                                 "for its peers, q / k / v held meanwhile: 400 MiB per waiting layer); the library scores a group of three or more "
+                                 "32k layers with ONE rolling launch (the entries follow each other over the chip two at a time and out of step; "
+                                 "csrc/fused.hip launch_score_fused) and selects / copies it with one launch each; same rows, same order") if defer else "layer by layer (FASTKV_DEFER=0)"
+    return out
+
+
 def main():
+    t_proc0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -525,11 +652,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="N>1: skip the sequence-sharded / tensor-parallel legs")
     ap.add_argument("--leg", choices=LEGS, default=None, help="internal: run ONE multi-GPU leg in this (child) process")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help="internal: the CPU leg in its own process (cpu_baseline_child_main)")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented replay / roofline-shape / CPU legs")
     ap.add_argument("--no-ttft", action="store_true", help="skip the whole-model TTFT leg (random-init Llama-3-8B, fastkv vs fullkv)")
     ap.add_argument("--rehearse", action="store_true", help="launcher rehearsal (tests): the ranks rendezvous, exchange one all-reduce and "
                     "rank 0 prints a line with value null -- no GPU work, nothing measured")
     a = ap.parse_args()
+    if a.cpu_baseline_child:
+        return cpu_baseline_child_main()
 
     one_rank_rccl = a.gpus == 1 and os.environ.get("BENCH_BACKEND") == "nccl"     # RCCL with the one rank a one-GPU box allows
     if (a.gpus > 1 or one_rank_rccl) and "RANK" not in os.environ and not a.leg:
@@ -541,7 +671,18 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if a.rehearse:
         return rehearse(a, rank, world)
+    # The CPU leg first (N = 1 only), in its own process, while this one has neither touched the GPU nor started a thread pool: the host
+    # cores are as idle as they get (the same code measured 84-816 ms per step from box to box when it ran last,
+    # inside the bench process; what the child records about its host -- quota, load, candidates -- is in the line)
+    cpu = None
+    if world == 1 and rank == 0 and not a.leg and not a.no_extras and not a.no_cpu_baseline and torch.cuda.device_count() > 0:
+        cpu = cpu_baseline()
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback for the product path)"
+    if world > max(1, torch.cuda.device_count()):
+        # more ranks than GPUs (a rehearsal of the N-rank run on a one-GPU box, BENCH_BACKEND=gloo): the ranks' launches share compute
+        # units, which the kernels with in-launch waits do not support (include/fastkv_hip.h "Residency") -- every rank runs the
+        # no-wait kernels, as the header prescribes for processes that share a GPU
+        os.environ.setdefault("FASTKV_FUSED", "0")
     if a.leg:
         return leg_child_main(a)
     local = local % max(1, torch.cuda.device_count())
@@ -583,27 +724,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
-    value = world * CFG["S"] / (ms_per_step * 1e-3)
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted("bench")                                    # (behind the synchronisation: an abandoned launch is an error of the run)
 
-    out = {"metric": "prefill_hotpath_tokens_per_s", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
-           "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-           "config": {"workload": "FastKV hot path (score+select+compact, 32 layers + TSP gather) of one Llama-3-8B prefill, "
-                                  "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
-                      "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
-           "ttft_hotpath_ms": round(ms_per_step, 4),
-           # the arithmetic contract of the contraction (utils.py:94) both sides run by default: "mfma16" = the gfx950 fp16 matrix
-           # instruction on the fp16 operands, restated bit for bit by the oracle; "fmaf" = the fp32 fma chain (FASTKV_CONTRACTION)
-           "contraction": "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16",
-           "ranks_seen": dist.get_world_size() if dist is not None else 1,
-           "backend": (dist.get_backend() if dist is not None else "none"),
-           # the fused launches' own check of where their workgroups ran (include/fastkv_hip.h: fastkv_placement_violations): 0 = every
-           # pair of workgroups that shared a compute unit in the warm-up and timed steps belonged to one head, as the kernel assumes
-           "placement_violations": int(lib.fastkv_placement_violations(0))}
-    out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
-                                 f"sequence after the last layer, the layers in front of it in groups of {work.defer_hold} (FASTKV_DEFER_HOLD: a layer waits "
-                                 "for its peers, q / k / v held meanwhile: 400 MiB per waiting layer; the library scores a group two layers per "
-                                 "fused launch and selects / copies it with one launch each); same rows, same order") if work.defer else "layer by layer (FASTKV_DEFER=0)"
+    out = contract_line(world, a.steps, a.warmup, ms_per_step,
+                        "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16",
+                        dist.get_world_size() if dist is not None else 1, dist.get_backend() if dist is not None else "none",
+                        int(lib.fastkv_placement_violations(0)), work.defer, work.defer_hold)
+
+    if world > 1:
+        return finish_multi_rank(a, out, work, rank, world, dev, dist, t_proc0)
 
     if not a.no_extras:
         # instrumented replay of the same steps: per-kernel HIP-event durations on the launch stream
@@ -681,6 +811,8 @@ def main():
                                             "achieved": round(2 * alg / (us2 * 1e-6) / 1e9, 1),
                                             "frac": round(2 * alg / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                             "traffic": tj.get("score_fused_pair_hbm_bytes_per_launch") if os.path.exists(tpath) else None,
+                                            "traffic_note": "null unless profiles/traffic.json holds a pair-launch row: the PMC passes run the default "
+                                                            "schedule (bench.py --no-extras), which scores groups with the rolling launch and has no pair launch",
                                             "algorithmic_bytes_per_launch": 2 * alg,
                                             "avg_launch_us": round(us2, 2)})
                     out["roofline_one_layer_launch"] = single
@@ -813,8 +945,17 @@ def main():
             out["kv_compact_frac"] = rs["frac_of_8TBps"]
             out["kv_compact_note"] = ("KV gather/compact kernel at the 541 MB roofline shape, rows in the reference's score order (the product "
                                       "default; median over calls, HIP events); index order: compact.roofline_shape.index")
-            if world == 1 and not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(work)
+            # both arithmetic contracts of the step side by side at the top level (VERDICT r04 next #2c): the headline's and the other
+            # one, GPU and CPU (the CPU leg's `value` is the fma chain, its `same_contract_as_headline` the restated matrix instruction)
+            out["step_ms_by_contract"] = {out["contraction"]: out["ms_per_step"], out["other_contract"]["contraction"]: out["other_contract"]["ms_per_step"]}
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+                if "same_contract_as_headline" in cpu:
+                    out["cpu_ms_by_contract"] = {"fmaf": cpu["ms_per_step"], "mfma16": cpu["same_contract_as_headline"]["ms_per_step"]}
+            try:
+                out["published_recipe"] = published_recipe_leg(lib, dev, a.steps)
+            except Exception as e:   # noqa: BLE001 -- an extra; the contract line does not depend on it
+                out["published_recipe"] = {"error": repr(e)[:300]}
             if world == 1 and not a.no_ttft:
                 out["ttft"] = whole_model_ttft(work)
                 out["ttft_ms"] = out["ttft"].get("fastkv", {}).get("ttft_ms")
@@ -837,30 +978,130 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if (world > 1 or one_rank_rccl) and not a.no_legs:
-        # The paths with a real exchange step, each in a freshly spawned child process per rank: a rank that
-        # dies or hangs inside a collective costs that leg, never the contract line.  This process has released its process
-        # group and its tensors; it only waits.
+    if one_rank_rccl and not a.no_legs:
+        # `BENCH_BACKEND=nccl python bench.py --gpus 1`: every leg with the ONE RCCL rank this box allows, in the line
         del work
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        # The legs share one wall-clock budget (FASTKV_BENCH_LEG_BUDGET_S, default 420 s): the contract line is printed after them,
-        # so a fabric that stalls every collective must not hold it back for long.  All ranks apply the same rule to the same
-        # clock reading taken at the same barrier, give or take: a leg some ranks skip simply times out on the others.
-        budget = float(os.environ.get("FASTKV_BENCH_LEG_BUDGET_S", "420"))
+        budget = float(os.environ.get("FASTKV_BENCH_LEG_BUDGET_S", "240"))
         t_legs = time.perf_counter()
         for i, name in enumerate(LEGS):
             left = budget - (time.perf_counter() - t_legs)
-            want = 300 if name.startswith("sp_ttft") else 150
-            if left < 30:
-                res = {"skipped": "leg budget spent"}
-            else:
-                res = spawn_leg(name, i, max(3, a.steps // 4), rank, timeout_s=min(want, left))
-            if rank == 0:
-                out[name] = res
+            out[name] = {"skipped": "leg budget spent"} if left < 30 else spawn_leg(name, i, max(3, a.steps // 4), rank, timeout_s=min(150, left))
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+
+def finish_multi_rank(a, out, work, rank, world, dev, dist, t_proc0) -> int:
+    """N > 1 ranks behind their timed run.  The contract line leaves EARLY: within FASTKV_BENCH_LINE_DEADLINE_S (default 75 s) of this
+    rank's start, whatever the legs do (it used to wait for up to 420 s of legs; a driver whose limit is shorter
+    would have got no line at all from the first multi-GPU run this code ever sees).  Order:
+      1. rank 0 looks at its clock and decides how many of the two short legs (`seq_sharded_weak`, `tp`: the sequence-sharded and the
+         head-sharded operator, 30 s each at most) still fit in front of the deadline; the decision is BROADCAST, so every rank spawns
+         the same children;
+      2. the process group is released, the short legs run in child processes (own rendezvous ports: a rank that dies in a collective
+         costs that leg only) and land in the line;
+      3. rank 0 prints the ONE line, flushed;
+      4. the long legs (`seq_sharded_128k`, `sp_ttft_128k`) run afterwards within FASTKV_BENCH_LEG_BUDGET_S (default 120 s) and are
+         reported on STDERR (`LEGS_JSON {...}`) and, where the directory exists, in gpurun_out/bench_legs_N<world>.json -- stdout
+         carries the one line and nothing else."""
+    deadline = float(os.environ.get("FASTKV_BENCH_LINE_DEADLINE_S", "75"))
+    inline = [("seq_sharded_weak", 30.0), ("tp", 30.0)]
+    n_inline = 0
+    if not a.no_legs:
+        left = deadline - (time.perf_counter() - t_proc0)
+        for _, need in inline:
+            if left >= need + 5.0:
+                n_inline += 1
+                left -= need
+    t = torch.tensor([n_inline], device=dev, dtype=torch.int64)
+    dist.broadcast(t, src=0)                                     # rank 0's clock decides for everybody
+    n_inline = int(t.item())
+    dist.barrier()
+    dist.destroy_process_group()
+    del work
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    steps = max(3, a.steps // 4)
+    for i, (name, need) in enumerate(inline[:n_inline]):
+        res = spawn_leg(name, i, steps, rank, timeout_s=need)
+        if rank == 0:
+            out[name] = res
+    if rank == 0:
+        out["legs_after_the_line"] = [] if a.no_legs else [n for n in LEGS if n not in [x[0] for x in inline[:n_inline]]]
+        out["line_after_s"] = round(time.perf_counter() - t_proc0, 1)
+        print(json.dumps(out), flush=True)
+    if a.no_legs:
+        return 0
+    budget = float(os.environ.get("FASTKV_BENCH_LEG_BUDGET_S", "120"))
+    t_legs = time.perf_counter()
+    late = {}
+    for i, name in enumerate(LEGS):
+        if name in [x[0] for x in inline[:n_inline]]:
+            continue
+        left = budget - (time.perf_counter() - t_legs)
+        # (every rank applies the same rule to its own clock, started at the same barrier give or take: a leg some ranks skip simply
+        # times out on the others -- after the line, that costs nothing but the leg)
+        res = {"skipped": "leg budget spent"} if left < 30 else spawn_leg(name, 10 + i, steps, rank, timeout_s=min(90.0, left))
+        if rank == 0:
+            late[name] = res
+    if rank == 0:
+        print("LEGS_JSON " + json.dumps(late), file=sys.stderr, flush=True)
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(d):
+                with open(os.path.join(d, f"bench_legs_N{world}.json"), "w") as f:
+                    json.dump(late, f)
+        except OSError:
+            pass
+    return 0
+
+
+def published_recipe_leg(lib, dev, steps):
+    """The hot path of one Llama-3-8B 32k prefill under the reference's PUBLISHED recipe (RECIPE above; the only setting its scripts ship)
+    instead of the constant budget of BASELINE.json configs[1]: 16 layers of 32,768 tokens compressed to 3276 rows, the TSP gather of
+    6553 hidden rows, 16 layers of 6553 tokens compressed to 3276 -- those are LONG layers for the default schedule (groups of eight,
+    like the ones in front of the TSP layer), which the constant budget never produces."""
+    import gc
+    work = HotPathPrefill(dev, seed=7000, recipe=True)
+    res = {"recipe": "--tsp_idx 15 --tsp_rate 0.2 --retain_rate 0.1 --eviction_mode proportional (scripts/eval_prefill.sh:4-12); maxpool, window 8, kernel 7",
+           "shapes": f"layers 0-15: S = {CFG['S']} -> {int(CFG['S'] * RECIPE['retain_rate'])} rows; TSP length {work.tsp_len}; layers 16-31: "
+                     f"S = {work.tsp_len} -> {int(work.tsp_len * (RECIPE['retain_rate'] / RECIPE['tsp_rate']))} rows"}
+
+    def timed():
+        for _ in range(2):
+            work.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            work.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    ms = timed()
+    res.update({"ms_per_step": round(ms, 4), "tokens_per_s": round(CFG["S"] / (ms * 1e-3), 1)})
+    profile_read(lib)
+    lib.fastkv_profile_enable(1)
+    for _ in range(steps):
+        work.step()
+    torch.cuda.synchronize()
+    lib.fastkv_profile_enable(0)
+    res["kernels"] = {n: {"launches_per_step": c / steps, "avg_us": round(t / c * 1e3, 2), "us_per_step": round(t / steps * 1e3, 1)}
+                      for n, (c, t) in profile_read(lib).items() if c}
+    work.defer = False
+    ms_seq = timed()
+    work.defer = True
+    res["layer_by_layer"] = {"ms_per_step": round(ms_seq, 4), "tokens_per_s": round(CFG["S"] / (ms_seq * 1e-3), 1)}
+    caps = sorted({c.max_capacity_prompt for c in work.clusters})
+    res["state_after"] = {"max_capacity_prompt": caps, "tsp_length": work.clusters[CFG["tsp_idx"]].tsp_length}
+    from fastkv_amd._lib import raise_if_aborted
+    raise_if_aborted("bench.published_recipe")
+    del work
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

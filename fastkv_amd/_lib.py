@@ -162,13 +162,19 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     return L
 
 
+_violations_seen = 0
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
+        if rc == FASTKV_EPLACEMENT:
+            # the violations behind this report have now been reported: they stay in the library's running total, but
+            # raise_if_aborted does not warn about them a second time
+            global _violations_seen
+            _violations_seen = load().fastkv_placement_violations(0)
         msg = load().fastkv_strerror(rc).decode()
         raise FastKVNativeError(f"fastkv_amd.{what}: {msg} (code {rc})", code=rc)
 
-
-_violations_seen = 0
 
 
 def raise_if_aborted(what: str = "last_status") -> None:

@@ -66,7 +66,17 @@ static int take_abort_status()
 {
     if (!g_abort_host) return FASTKV_OK;
     // word 0: a launch gave up a bounded in-kernel wait; word 1: a decode step ran into a full cache slab (decode.hip)
-    if (__atomic_load_n(g_abort_host, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EABORTED;
+    // (value 1: a bounded wait was given up -- partners that could not become resident; value 2: a workspace without a live control
+    // block, a caller's error.)  Under the fail-safe policy (2, the default) a given-up wait ALSO switches the process to the no-wait
+    // kernels, like a placement report does: whatever held the compute units beyond the spin limit may still be there when the caller
+    // redoes the call, and a rolling launch (whose grid exceeds the chip by design) would abort again.
+    if (__atomic_load_n(g_abort_host, __ATOMIC_ACQUIRE) != 0u) {
+        const uint32_t why = __atomic_exchange_n(g_abort_host, 0u, __ATOMIC_ACQ_REL);
+        if (why) {
+            if ((why & 1u) && placement_policy().load(std::memory_order_relaxed) == 2) no_wait_flag().store(1, std::memory_order_release);
+            return FASTKV_EABORTED;
+        }
+    }
     if (__atomic_load_n(g_abort_host + 1, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 1, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EOVERFLOW;
     // word 2 (FASTKV_DEBUG_BOUNDS=1 only): a gather was handed an index outside [0, S) (compact.hip)
     if (__atomic_load_n(g_abort_host + 2, __ATOMIC_ACQUIRE) != 0u && __atomic_exchange_n(g_abort_host + 2, 0u, __ATOMIC_ACQ_REL)) return FASTKV_EBOUNDS;
@@ -321,7 +331,6 @@ static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t 
     // list and the keys itself and the selection kernel is skipped
     const bool select_all = (kk == L.n);
     uint32_t *arrive = reinterpret_cast<uint32_t *>(ws + L.off_arrive), *seltab = reinterpret_cast<uint32_t *>(ws + L.off_seltab);
-    const size_t nchunks = ((size_t)L.n + 2047) / 2048;
     if (select_all && !by_score && p->tsp_len == 0 && !scores_out) {
         // capacity == S, ascending order, nothing else asked for: the result does not depend on the scores at all -- K/V are
         // copied (candidates in position order, then the window rows), one launch
@@ -360,7 +369,7 @@ static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t 
     if (p->tsp_len) {
         e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
                           reinterpret_cast<const uint32_t *>(ws + L.off_thist), arrive + (size_t)p->B * p->Hkv,
-                          seltab + (size_t)p->B * p->Hkv * nchunks * 64, st, ctrl);       // 32 granules = 64 words per chunk
+                          seltab + SELTAB_ONE_BYTES / 4, st, ctrl);                        // (the TSP rows' own table: fk_host.h)
         if (e != hipSuccess) return fail();
     }
     // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction
@@ -519,8 +528,8 @@ const char *fastkv_strerror(int code)
     case FASTKV_ELAUNCH: return "HIP kernel launch failed";
     case FASTKV_EABORTED:
         return "an earlier fused launch gave up waiting for its co-resident workgroups (another kernel held compute units longer "
-               "than FASTKV_SPIN_LIMIT_MS, or two such launches overlapped): the outputs of that call are invalid -- repeat it, "
-               "with FASTKV_FUSED=0 if the GPU is shared";
+               "than FASTKV_SPIN_LIMIT_MS, or two such launches overlapped): the outputs of that call are invalid -- repeat it; "
+               "under the default policy the process now runs the no-wait kernels (as FASTKV_FUSED=0), see fastkv_set_placement_policy()";
     case FASTKV_EOVERFLOW:
         return "an earlier static-decode step ran into a full cache slab (more steps than enable_static_decode reserved rows for): "
                "the last cached row was overwritten, the tokens from that step on are invalid";

@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(256) decode_greedy_kernel(const uint16_t *__re
         const uint32_t wds[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint32_t h = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+            uint32_t h = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+            if (h == 0x8000u) h = 0;                                                       // -0.0 == +0.0 for torch.argmax: the first zero wins
             const uint32_t key = (h & 0x7fffu) > 0x7c00u ? 0xffffu : mono16(h);           // NaN: maximal
             const unsigned long long k = ((unsigned long long)key << 32) | (uint32_t)~(uint32_t)(i + e);
             best = k > best ? k : best;

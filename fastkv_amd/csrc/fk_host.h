@@ -16,8 +16,13 @@ constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
 constexpr int FUSED_CU_SLOTS = 2048;  // {XCC_ID, SE, SH, CU} of HW_ID as an index: who ran on a compute unit in this launch (placement check of the fused kernel)
 constexpr int EPOCH_STRIDE = 64;     // the workspace epoch advances by this much per operator call: sub-launch s of a call (< EPOCH_STRIDE) uses epoch + s, so
                                      // no two launches ever share a hand-off token (the xor-mixed sub index could alias another epoch's token)
-constexpr int FUSED_MAX_WGS = 1024;  // (unit, span) pairs of one fused score launch -- 512 workgroups (2 per CU) x up to 2 streams: sizes its hand-off records
-constexpr size_t SELTAB_FIXED_BYTES = (size_t)16 << 20;   // fixed area of the split selection's granule tables (rows x 2048-key chunks x 256 B: 65,536 of them)
+constexpr int FUSED_MAX_WGS = 2048;  // (unit, span) pairs whose hand-off records exist at a time -- a regular launch: 512 workgroups (2 per CU) x up to 2 streams; a rolling launch: the 2 F entries its record areas rotate over (round 5: four entries of 512 workgroups): sizes the record areas
+// The split selection's granule tables (select.hip): a launch takes the table path only with rows x chunks <= SPL_MAX_WGS workgroups,
+// one line of SPL_LINE 8-byte granules per workgroup.  An operator call makes two such launches (the per-head rows, the TSP rows): two
+// tables at FIXED offsets, never anything else in them (a launch beyond SPL_MAX_WGS runs the wait-free selection and has no table).
+constexpr int SPL_LINE = 32, SPL_MAX_WGS = 1024;
+constexpr size_t SELTAB_ONE_BYTES = (size_t)SPL_MAX_WGS * SPL_LINE * 8;
+constexpr size_t SELTAB_FIXED_BYTES = 2 * SELTAB_ONE_BYTES;
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -85,9 +90,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     size_t o = CTRL_BYTES;
     L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + FUSED_CU_SLOTS * 8, 256);   // fused score: row max / row sum / halo granules + one {token, unit} granule per compute unit
     L.off_fchain = o; o += align_up((size_t)512 * 1024 * 8, 256);               // fused score, more than 4 query heads per KV head: [unit span][positions]: 512 Ki head-sum granules at most
-    const size_t seltab_bytes = align_up((size_t)p.B * (p.Hkv + 1) * ((size_t)(L.n + 2047) / 2048) * 256, 256);   // split select: 32 8-byte granules per chunk
-    L.off_seltab = o; o += SELTAB_FIXED_BYTES;
-    const bool seltab_fits = seltab_bytes <= SELTAB_FIXED_BYTES;                 // (a call beyond that: its table lies behind the other areas, as in rounds 1-3)
+    L.off_seltab = o; o += SELTAB_FIXED_BYTES;                                   // [per-head rows' table | TSP rows' table], SELTAB_ONE_BYTES each
     L.off_qf = o;     o += align_up((size_t)p.B * p.Hkv * L.R_alloc * p.D * 4, 256);
     L.off_logits = o; o += align_up((size_t)p.B * p.H * p.window * L.Sp * 2, 256);
     L.off_gmax = o;   o += align_up((size_t)p.B * p.H * p.window * 4, 256);
@@ -98,7 +101,6 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_thist = o;  o += (size_t)p.B * HIST12 * 4;                            // ... and of the TSP rows (adjacent: zeroed together)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
-    if (!seltab_fits) { L.off_seltab = o; o += seltab_bytes; }
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {

@@ -84,7 +84,10 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
 // wave is the other wave of its SIMD using the issue slots (vector-ALU work and fp32 MFMAs of a SIMD add up, in one wave or
 // across two: tools/probes/probe_overlap.hip).  The kernel is issue bound (per SIMD: A 27, B 9, C 5, D 4 us), and two streams
 // pay every hand-off's record sweep twice, with twice the producers per head.
-template <int D, int PER, int NB, int NS, bool F16>
+// WPE = workgroups per compute unit (= waves per SIMD) the instantiation is built for: 2 (256 registers, 80 KiB of LDS per workgroup), or 3
+// (round 5: 168 registers, <= 53 KiB -- the two-tiles-per-wave size under the mfma16 contract, for the rolling launch: three workgroups
+// of a compute unit are then in three different phases)
+template <int D, int PER, int NB, int NS, bool F16, int WPE>
 __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -101,7 +104,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
     static_assert(PER % NS == 0, "tiles split evenly over the streams");
     constexpr int W = 8, G = 4, NPH = D / DH, TK = 32 * NB, NW = 8 * NB, PS = PER / NS;
-    constexpr int SLAB_BYTES = 4 * 64 * ROWB, AS_FLOATS = (D / 2) * 64;
+    // (the query block: fp32 values for the fma-chain contract, the fp16 rows as they are -- half the bytes -- for mfma16)
+    constexpr int SLAB_BYTES = 4 * 64 * ROWB, AS_FLOATS = F16 ? (D / 4) * 64 : (D / 2) * 64;
     // Phase B's exponentials are needed again in phase C.  Up to two tiles per wave keep them in registers (64 of them); with
     // four tiles per wave (two 32k layers per launch) the other two tiles park theirs in LDS -- the K slabs and the query
     // operand are dead by then -- as one float4 per lane and word pair (conflict-free ds_write_b128 / ds_read_b128).  Round 2
@@ -234,7 +238,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         // workspace never initialised (fastkv_workspace_init): no hand-off of this launch could be trusted.  Reported like an
         // abandoned wait -- the process-wide flag in pinned host memory, FASTKV_EABORTED at the next call -- and every workgroup
         // leaves at once (the condition is the same for all of them); nothing traps, the context stays usable.
-        if (tix == 0) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tix == 0) __hip_atomic_store(host_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: not a given-up wait, capi.hip take_abort_status)
         return false;
     }
     // (sub 0: the operator call's token, shared with the selection; the epoch advances by EPOCH_STRIDE per call, sub < EPOCH_STRIDE:
@@ -633,7 +637,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // stream's LDS tile, column pad + local position; candidates past n hold the pooling pad value (utils.py:106,108).
     constexpr int TWG = TWG_, PADMAX = 31, TW = TW_;
     static_assert(E_LDS == 0 || NS == 1, "parked exponentials: one stream only");
-    static_assert(CD_BYTES <= (int)sizeof(smem) && sizeof(smem) + 6656 <= 80 * 1024, "two workgroups per CU share 160 KiB of LDS");
+    static_assert(CD_BYTES <= (int)sizeof(smem) && (sizeof(smem) + 6656) * WPE <= 160 * 1024, "WPE workgroups per CU share 160 KiB of LDS");
     const int pad = ksize / 2, lo = blk * TWG;
     const bool avg = pooling == FASTKV_POOL_AVG;
     const float padv = avg ? 0.0f : -INFINITY;
@@ -944,8 +948,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 // paid once per launch: bit-exact, and no faster than one launch per sub-batch (0.822 vs 0.825 ms per step) once both used the same
 // register allocation; the loop needs the thread index laundered through an opaque move or everything derived from it is hoisted
 // and spilled.  Dropped: separate launches are simpler and cannot reuse a hand-off record too early.)
-template <int D, int PER, int NB, int NS, bool F16>
-__global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
+template <int D, int PER, int NB, int NS, bool F16, int WPE = 2>
+__global__ void __launch_bounds__(256, WPE) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
                                                              uint64_t *__restrict__ edges, uint64_t *__restrict__ pmax,
@@ -957,7 +961,7 @@ __global__ void __launch_bounds__(256, 2) score_fused_kernel(const uint16_t *__r
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
                                                              const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts)
 {
-    (void)score_fused_body<D, PER, NB, NS, F16>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
+    (void)score_fused_body<D, PER, NB, NS, F16, WPE>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
                                            spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts);
 }
@@ -979,7 +983,7 @@ static int device_cus()
     }();
     return cus;
 }
-template <int D, int PER, int NB, int NS, bool F16> static bool fused_resident(int grid_wgs)
+template <int D, int PER, int NB, int NS, bool F16, int WPE> static bool fused_resident(int grid_wgs)
 {
     struct Info { int wgs_per_cu, cus; };
     static const Info info = []() {                            // initialised once, thread-safe (C++11 static)
@@ -987,28 +991,36 @@ template <int D, int PER, int NB, int NS, bool F16> static bool fused_resident(i
         int dev = 0, nb = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB, NS, F16>), 256, 0) ==
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<D, PER, NB, NS, F16, WPE>), 256, 0) ==
                 hipSuccess) {
             r.wgs_per_cu = nb;
             r.cus = prop.multiProcessorCount;
         }
         return r;
     }();
-    return info.wgs_per_cu >= 1 && grid_wgs <= (info.wgs_per_cu < 2 ? info.wgs_per_cu : 2) * info.cus;
+    return info.wgs_per_cu >= 1 && grid_wgs <= (info.wgs_per_cu < WPE ? info.wgs_per_cu : WPE) * info.cus;
 }
 
 // One instantiation: residency check + launch.
-template <int D, int PER, int NB, int NS, bool F16> struct FusedLaunch {
-    static bool resident(int wgs) { return fused_resident<D, PER, NB, NS, F16>(wgs); }
+template <int D, int PER, int NB, int NS, bool F16, int WPE = 2> struct FusedLaunch {
+    static bool resident(int wgs) { return fused_resident<D, PER, NB, NS, F16, WPE>(wgs); }
     template <typename... Args> static void launch(dim3 grid, hipStream_t st, Args... args)
     {
-        hipLaunchKernelGGL((score_fused_kernel<D, PER, NB, NS, F16>), grid, dim3(256), 0, st, args...);
+        hipLaunchKernelGGL((score_fused_kernel<D, PER, NB, NS, F16, WPE>), grid, dim3(256), 0, st, args...);
     }
 };
 
 // Calls f(FusedLaunch<D, PER, NB, NS, F16>{}) for the runtime shape; false if that combination is not instantiated.
-template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, bool f16, F &&f)
+template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, bool f16, F &&f, int wpe = 2)
 {
+    // three workgroups per compute unit: the mfma16 contract's two-tiles-per-wave size only (the rolling launch's entries, round 5)
+    if (wpe == 3) {
+        if (per == 2 && nb == 2 && ns == 1 && f16) {
+            if (D == 64) { f(FusedLaunch<64, 2, 2, 1, true, 3>{}); return true; }
+            if (D == 128) { f(FusedLaunch<128, 2, 2, 1, true, 3>{}); return true; }
+        }
+        return false;
+    }
 #define FK_CASE(DV, PV, NBV, NSV, FV) if (D == DV && per == PV && nb == NBV && ns == NSV && f16 == FV) { f(FusedLaunch<DV, PV, NBV, NSV, FV>{}); return true; }
 #define FK_CASES_D(DV, FV)                                                                                          \
     FK_CASE(DV, 1, 1, 1, FV) FK_CASE(DV, 1, 2, 1, FV) FK_CASE(DV, 2, 2, 1, FV) FK_CASE(DV, 4, 2, 1, FV)      /* (32-key tiles only ever come one per wave) */
@@ -1105,6 +1117,11 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     const uint64_t spin_ticks = spin_limit_ticks();
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [unit span][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
+    // The placement check (fastkv_placement_violations) guards the compute-unit pairing of the fp32-fma-chain contract: the hazard it
+    // fences off needs that contract's matrix phase (K from LDS into fp16 MFMAs, those into fp32 MFMAs) beside packed-fp32 arithmetic
+    // (docs/HISTORY.md).  Launches of the mfma16 contract issue neither, so they do not arm it -- regular launches no more than the
+    // rolling launch: on a shared or partly occupied GPU a harmless displacement would otherwise fail the caller's prefill with
+    // FASTKV_EPLACEMENT and drop the process to the no-wait kernels for good.
     uint64_t *cu_slots = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8));
     if (FKH_OLD_NUMBERING) cu_slots = nullptr;                   // (hunt builds: other units share compute units by design, every workgroup would report)
     uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
@@ -1197,7 +1214,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), cu_slots, 0, 0, 1);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, 0, 0, 1);
         });
         *err = hipGetLastError();
         b0 += take;

@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint16_t
 //            launch are co-resident: the host takes this path only for <= SPL_MAX_WGS workgroups; the wait is bounded,
 //            fk_device.h SpinCtl), sum the tables -> k-th value, quota of ties, and the number of winners before this
 //            chunk; ordered compaction of the chunk straight to the output lists.
-constexpr int SPL_THREADS = 256, SPL_CHUNK = SPL_THREADS * 8, SPL_LINE = 32, SPL_MAX_WGS = 1024;
+constexpr int SPL_THREADS = 256, SPL_CHUNK = SPL_THREADS * 8;     // (SPL_LINE, SPL_MAX_WGS: fk_host.h, they size the workspace's table areas)
+static_assert(SELTAB_ONE_BYTES == (size_t)SPL_MAX_WGS * SPL_LINE * sizeof(uint64_t), "one granule line per workgroup of a table launch");
 
 struct SplShared {
     uint32_t wtot[4];

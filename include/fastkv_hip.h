@@ -97,7 +97,9 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  *     tells the rest of the launch (which exits at its next poll) and raises a flag in pinned host memory; nothing traps,
  *     nothing hangs, the HIP context stays usable, indices are clamped so the following stages cannot fault.  The outputs
  *     of that call are invalid, and the NEXT operator call in the process (or fastkv_last_status()) returns FASTKV_EABORTED
- *     once -- the asynchronous-error convention of the HIP runtime itself;
+ *     once -- the asynchronous-error convention of the HIP runtime itself -- and, under the default ("fail safe") policy of
+ *     fastkv_set_placement_policy, the process switches to the no-wait kernels (what FASTKV_FUSED=0 selects): whatever held the
+ *     compute units may still be there when the caller repeats the call, and the repeat must not run into the same wait;
  *   - calls on different streams of ONE process are chained by the library (an event dependency when the stream changes,
  *     taken under a lock that also covers the enqueue), so two such launches of one process never overlap;
  *   - processes that share a GPU, or graphs replayed concurrently on several streams, should set FASTKV_FUSED=0: the
@@ -115,7 +117,8 @@ int fastkv_last_status(void);
  * The fused scoring kernel gives the two workgroups that share a compute unit adjacent spans of one (batch row, kv head): which two
  * share is the GPU's dispatch order on an idle device, an observation and not a promise (DESIGN.md section 8 on why the kernel
  * cares: a workgroup that ran a phase ahead of a DIFFERENT unit's workgroup on its compute unit was measured to produce wrong sums
- * now and then).  Every launch checks it: a workgroup that finds another unit's workgroup of the same launch on its compute unit
+ * now and then -- under the fp32-fma-chain contract (FASTKV_CONTRACTION=fmaf), whose matrix phase is one half of that hazard; launches of
+ * the default "mfma16" contract issue neither half and do not arm the check).  Every launch of the fma-chain contract checks it: a workgroup that finds another unit's workgroup of the same launch on its compute unit
  * is counted in pinned host memory.  Returns the count since the last reset (host only, no synchronisation; complete once the
  * stream has been synchronised).  0 on an idle GPU (the tests assert it); > 0 beside foreign kernels, or when a launch could not
  * become resident all at once -- results were bit-exact in every such test, but the guarantee of the pairing is gone: a shared GPU
@@ -123,7 +126,8 @@ int fastkv_last_status(void);
  */
 int fastkv_placement_violations(int reset);
 /*
- * What a counted violation leads to (process-wide; initial value from FASTKV_STRICT_PLACEMENT: unset -> 2, "1" -> 1, "0" -> 0):
+ * What a counted violation -- and, under policy 2, a given-up wait (FASTKV_EABORTED) -- leads to (process-wide; initial value from
+ * FASTKV_STRICT_PLACEMENT: unset -> 2, "1" -> 1, "0" -> 0):
  *   2  fail safe (default): the next operator call / fastkv_last_status() returns FASTKV_EPLACEMENT once -- the outputs of the calls
  *      since the last report are not vouched for, redo them -- AND the process switches to the no-wait kernels (staged scoring,
  *      wait-free selection: what FASTKV_FUSED=0 selects), so that the redo, and everything after it, has no exposure left;

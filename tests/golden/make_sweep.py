@@ -2,7 +2,10 @@
 
 Run in the build container only (needs /root/reference; never on the GPU box):
 
-    python tests/golden/make_sweep.py
+    python tests/golden/make_sweep.py            # the 24 cases of rounds 3-4 -> sweep32k.npz, sweep_meta.json
+    python tests/golden/make_sweep.py wide       # round 5: 120 cases (24 seeds x {constant, recipe} x {maxpool, avgpool} + 24 peaked)
+                                                 # -> sweep_wide.npz (row digests; full rows only where a row flips), sweep_wide_meta.json
+                                                 # (per-contraction rates with 95 % Wilson intervals, overall and per family)
 
 For every case of tests/golden_cases.py:SWEEP_CASES (Llama-3-8B geometry, S = 32768; both poolings; the constant budget of
 BASELINE.json configs[1] and the published proportional recipe) the REFERENCE (baselines/fastkv/utils.py:80-134, imported,
@@ -33,7 +36,7 @@ import numpy as np
 import torch
 
 from gen_inputs import make_qkv
-from golden_cases import SWEEP_CASES
+from golden_cases import SWEEP_CASES, SWEEP_WIDE_CASES
 from baselines.fastkv.utils import FastKVCluster      # the reference
 
 sys.path.append(ROOT)                                 # after the reference: only `oracle` is taken from the repository
@@ -70,16 +73,37 @@ def bits(t):
     return t.contiguous().view(torch.int16).to(torch.int32)
 
 
-def sweep_one(contraction, refs, arrays):
+def row_digest(idx) -> int:
+    """64-bit digest of an ascending index row (the wide fixture stores these instead of the rows)."""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(np.ascontiguousarray(np.asarray(idx, dtype=np.int32)).tobytes(), digest_size=8).digest(), "little")
+
+
+def wilson(k, n, z=1.96):
+    """95 % Wilson score interval of a proportion k / n."""
+    if n == 0:
+        return [0.0, 0.0]
+    ph = k / n
+    den = 1 + z * z / n
+    mid = (ph + z * z / (2 * n)) / den
+    half = z * ((ph * (1 - ph) / n + z * z / (4 * n * n)) ** 0.5) / den
+    return [max(0.0, mid - half), min(1.0, mid + half)]
+
+
+def sweep_one(contraction, refs, arrays, cases=None, compact=False):
     """The oracle under one contraction contract against the reference runs in `refs`; fills `arrays` (reference-only data: the same
-    for every contraction) and returns {"cases": ..., "summary": ...}."""
+    for every contraction) and returns {"cases": ..., "summary": ...}.  `compact` (the wide sweep): `arrays` gets a digest per row, the
+    tie metadata, and the full canonical row only where the row flips under this contraction."""
+    cases = SWEEP_CASES if cases is None else cases
     O.set_contraction(contraction)
     meta = {"cases": {}}
     tot_rows = tot_straddle = tot_flip_rows = tot_flips = tot_mism = tot_el = tot_invalid = max_ulp = 0
-    for name, case in SWEEP_CASES.items():
-        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
+    fam = {}
+    for name, case in cases.items():
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
         if name not in refs:
-            refs[name] = run_reference(q, k, v, case)
+            c_, t_ = run_reference(q, k, v, case)
+            refs[name] = (c_, t_) if not compact else (c_.clone(), t_.clone())
         c_ref, t_ref = refs[name]
         _, _, idx_or, tsp_or, c_or, t_or = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"],
                                                        "index", return_scores=True)
@@ -115,15 +139,37 @@ def sweep_one(contraction, refs, arrays):
         tflips = sorted(tgot - set(tsel.tolist()))
         trf = t_ref[0].float()
         tvalid = set(torch.nonzero(trf > tvk).flatten().tolist()) <= tgot <= set(torch.nonzero(trf >= tvk).flatten().tolist())
-        arrays[name + ".idx"] = can.numpy().astype(np.uint16)
-        arrays[name + ".tsp"] = tcan.numpy().astype(np.uint16)
-        arrays[name + ".ties"] = ties
-        arrays[name + ".c_sampled"] = c_ref[..., ::64].contiguous().view(torch.int16).numpy()
+        if compact:
+            arrays[name + ".dig"] = np.array([[row_digest(can[b, g].numpy()) for g in range(Hkv)] for b in range(B)], dtype=np.uint64)
+            arrays[name + ".tsp_dig"] = np.array([row_digest(tcan.numpy())], dtype=np.uint64)
+            arrays[name + ".ties"] = ties
+            for r in rows:
+                if r["flips"]:
+                    arrays[name + ".row%d_%d" % tuple(r["row"])] = can[r["row"][0], r["row"][1]].numpy().astype(np.uint16)
+            if tflips:
+                arrays[name + ".tsp"] = tcan.numpy().astype(np.uint16)
+            case = {k_: v_ for k_, v_ in case.items()}
+        else:
+            arrays[name + ".idx"] = can.numpy().astype(np.uint16)
+            arrays[name + ".tsp"] = tcan.numpy().astype(np.uint16)
+            arrays[name + ".ties"] = ties
+            arrays[name + ".c_sampled"] = c_ref[..., ::64].contiguous().view(torch.int16).numpy()
         m = {"case": case, "score_elements": int(d.numel()), "mismatching_scores": int((d > 0).sum()), "max_ulp": int(d.max()),
              "rows": rows, "tsp": {"mismatching_scores": int(tmm.sum()), "max_ulp": int(td.max()), "straddling": int(tnear.sum()),
                                    "flips": len(tflips), "flipped_positions": tflips,
                                    "valid_topk_of_reference_scores": bool(tvalid)}}
+        if compact:                                               # (keep the meta small: per row only what is not the default)
+            m["rows"] = [r for r in rows if r["flips"] or r["straddling"] or not r["valid_topk_of_reference_scores"]]
+            m["rows_total"] = len(rows)
         meta["cases"][name] = m
+        f = fam.setdefault(case.get("family", "all"), dict(cases=0, rows=0, flip_rows=0, flips=0, invalid=0, mism=0, el=0))
+        f["cases"] += 1
+        f["rows"] += len(rows) + 1
+        f["flip_rows"] += sum(1 for r in rows if r["flips"]) + (1 if tflips else 0)
+        f["flips"] += sum(r["flips"] for r in rows) + len(tflips)
+        f["invalid"] += sum(1 for r in rows if not r["valid_topk_of_reference_scores"]) + (0 if tvalid else 1)
+        f["mism"] += int((d > 0).sum()) + int(tmm.sum())
+        f["el"] += int(d.numel()) + int(td.numel())
         max_ulp = max(max_ulp, int(d.max()), int(td.max()))
         tot_rows += len(rows) + 1
         tot_straddle += sum(1 for r in rows if r["straddling"]) + (1 if tnear.any() else 0)
@@ -134,15 +180,38 @@ def sweep_one(contraction, refs, arrays):
         tot_el += int(d.numel()) + int(td.numel())
         print(contraction, name, "mismatching", m["mismatching_scores"], "max ulp", m["max_ulp"], "straddling rows",
               sum(1 for r in rows if r["straddling"]), "flipping rows", sum(1 for r in rows if r["flips"]), "tsp flips", len(tflips), flush=True)
-    meta["summary"] = {"cases": len(SWEEP_CASES), "rows": tot_rows, "score_elements": tot_el, "mismatching_scores": tot_mism,
+    meta["summary"] = {"cases": len(cases), "rows": tot_rows, "score_elements": tot_el, "mismatching_scores": tot_mism,
                        "mismatch_rate": tot_mism / tot_el, "max_ulp": max_ulp, "rows_with_a_straddling_mismatch": tot_straddle,
                        "rows_that_flip": tot_flip_rows, "indices_flipped": tot_flips,
                        "row_flip_rate": tot_flip_rows / tot_rows,
-                       "rows_whose_set_is_not_a_valid_topk_of_the_reference_scores": tot_invalid}
+                       "rows_whose_set_is_not_a_valid_topk_of_the_reference_scores": tot_invalid,
+                       "row_flip_rate_ci95": wilson(tot_flip_rows, tot_rows), "invalid_row_rate": tot_invalid / tot_rows,
+                       "invalid_row_rate_ci95": wilson(tot_invalid, tot_rows)}
+    meta["families"] = {k_: dict(v_, mismatch_rate=v_["mism"] / v_["el"], row_flip_rate=v_["flip_rows"] / v_["rows"],
+                                 row_flip_rate_ci95=wilson(v_["flip_rows"], v_["rows"]), invalid_row_rate=v_["invalid"] / v_["rows"],
+                                 invalid_row_rate_ci95=wilson(v_["invalid"], v_["rows"])) for k_, v_ in fam.items()}
     return meta
 
 
+def main_wide():
+    arrays, refs = {}, {}
+    meta = {"note": "the WIDE sweep (round 5): 24 seeds x {constant budget 2048 / 2048, published recipe 3276 / 6553} x {maxpool, avgpool} of randn "
+                    "inputs + 24 peaked cases (3000 planted heavy hitters per KV head), S = 32768, Llama-3-8B geometry; per contraction "
+                    "contract of the oracle: how far its scores / index sets are from the REFERENCE's (baselines/fastkv/utils.py:80-134, "
+                    "imported), overall and per family, with 95 % Wilson intervals on the per-row rates.  Rows = 8 KV heads + the TSP row per case.",
+            "contractions": {}}
+    for contraction in ("fmaf", "mfma16"):
+        meta["contractions"][contraction] = sweep_one(contraction, refs, arrays, SWEEP_WIDE_CASES, compact=True)
+        print(contraction, json.dumps(meta["contractions"][contraction]["summary"], indent=1))
+        print(contraction, json.dumps(meta["contractions"][contraction]["families"], indent=1))
+    np.savez_compressed(os.path.join(HERE, "sweep_wide.npz"), **arrays)
+    with open(os.path.join(HERE, "sweep_wide_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        return main_wide()
     arrays, refs = {}, {}
     meta = {"note": "flips = indices of canonical_topk(oracle scores) that are not in canonical_topk(reference scores); one entry per "
                     "contraction contract of the oracle (oracle/fastkv_oracle.c: the fp32 fma chain / the gfx950 fp16 matrix instruction)",

@@ -56,6 +56,20 @@ for _s in range(12):
     SWEEP_CASES[f"sweep_recipe_{_s:02d}"] = dict(seed=200 + _s, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, pooling="avgpool",
                                                  cap=3276, tsp_len=6553)
 
+# The WIDE sweep (round 5, VERDICT r04 next #2a; tests/golden/make_sweep.py wide -> sweep_wide.npz / sweep_wide_meta.json): 24 seeds x
+# {constant budget, published recipe} x {maxpool, avgpool} = 96 randn cases + 24 "peaked" cases (3000 planted heavy-hitter keys per KV
+# head, gen_inputs.make_qkv(peaked=...): attention with margins randn does not have), the four configurations taking turns
+_WIDE_CFG = {"cmax": dict(pooling="maxpool", cap=2048, tsp_len=2048), "cavg": dict(pooling="avgpool", cap=2048, tsp_len=2048),
+             "rmax": dict(pooling="maxpool", cap=3276, tsp_len=6553), "ravg": dict(pooling="avgpool", cap=3276, tsp_len=6553)}
+SWEEP_WIDE_CASES = {}
+for _f, (_fam, _cfg) in enumerate(_WIDE_CFG.items()):
+    for _s in range(24):
+        SWEEP_WIDE_CASES[f"wide_{_fam}_{_s:02d}"] = dict(seed=300 + 100 * _f + _s, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, family=_fam, **_cfg)
+for _s in range(24):
+    _fam = list(_WIDE_CFG)[_s % 4]
+    SWEEP_WIDE_CASES[f"wide_peak_{_s:02d}"] = dict(seed=700 + _s, B=1, H=32, Hkv=8, S=32768, D=128, W=8, ks=7, family="peak", peaked=3000,
+                                                  **_WIDE_CFG[_fam])
+
 # Per-query-head selection (the SnapKV baseline's rule, tests/golden/make_snapkv.py)
 SNAPKV_CASES = {
     "snap_avg": dict(seed=31, B=1, H=8, Hkv=2, S=700, D=128, W=8, ks=5, pooling="avgpool", cap=96),

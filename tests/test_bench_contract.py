@@ -75,3 +75,44 @@ def test_a_failing_rank_fails_the_launcher():
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"])
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_contract_keys_are_the_same_for_every_n_and_match_the_driver_record():
+    """The N = 1 and the N = 8 line are built by ONE function (bench.contract_line): same keys, same config keys, value = all ranks'
+    tokens over the slowest rank's time; and the driver's latest record of an N = 1 run (BENCH_rNN.json, when the round has one)
+    carries every one of them (VERDICT r04 next #6)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    one = bench.contract_line(1, 20, 3, 0.6, "mfma16", 1, "none", 0, True, 8)
+    eight = bench.contract_line(8, 20, 3, 0.7, "mfma16", 8, "nccl", 0, True, 8)
+    assert set(one) == set(eight) and set(one["config"]) == set(eight["config"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config"):
+        assert key in one, key
+    assert one["scaling"] == "weak" and eight["n_gpus"] == 8 and "workload" in one["config"] and "model" not in one["config"]
+    assert abs(one["value"] - 32768 / 0.6e-3) < 1 and abs(eight["value"] - 8 * 32768 / 0.7e-3) < 1
+    assert "rolling launch" in one["config"]["schedule"]
+    recs = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")))
+    if recs:
+        rec = json.load(open(recs[-1]))
+        parsed = rec.get("parsed") or {}
+        if parsed:
+            extra = parsed.get("extra_keys") or []                            # (the driver lists the non-contract keys by name only)
+            extra = list(extra) if isinstance(extra, (list, tuple, dict)) else []
+            missing = [k for k in one if k not in parsed and k not in extra]
+            assert not missing, (recs[-1], missing)
+            assert parsed["metric"] == one["metric"] and parsed["unit"] == one["unit"]
+            w = parsed["config"]["workload"]                                  # (the driver keeps the first ~120 characters of a string)
+            assert one["config"]["workload"].startswith(w[:100]) and len(w) >= 100
+
+
+def test_cpu_leg_reads_the_cgroup_quota(monkeypatch, tmp_path):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("FASTKV_BENCH_NCPU", "256")
+    n, quota = bench._effective_cpus()
+    assert n == 256 and (quota is None or quota > 0)

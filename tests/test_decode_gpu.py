@@ -281,6 +281,11 @@ def test_greedy_step_tail_matches_torch_argmax(B, V):
             logits[-1, -1, V // 2 + 5] = float("nan")
         if step == 4:
             logits[0, -1, V - 1] = 100.0                                      # the last element
+        if step == 5 and V > 16:
+            # a row whose maximum is zero, a -0.0 in front of a +0.0: equal for torch.argmax, the first one wins
+            logits[-1, -1, :] = -logits[-1, -1, :].abs() - 1.0
+            logits[-1, -1, 11] = -0.0
+            logits[-1, -1, 14] = 0.0
         ref = logits[:, -1, :].argmax(dim=-1, keepdim=True)
         ops.decode_greedy(logits, scratch, tok, pos, log, log_index)
         torch.cuda.synchronize()

@@ -148,3 +148,58 @@ def test_an_aborted_launch_is_raised_not_absorbed(rec, monkeypatch):
     with pytest.raises(FastKVNativeError) as ei:
         d.add_tsp_layer(8, _cluster(tsp_layer=True), k, q, v)
     assert ei.value.code == -3
+
+
+@pytest.mark.parametrize("layers,tsp_idx,want", [(32, 15, [8, 8, 8, 8]), (36, 17, [8, 8, 2, 8, 8, 2])])
+def test_published_recipe_schedule_and_state(rec, monkeypatch, layers, tsp_idx, want):
+    """The reference's published recipe (/root/reference/scripts/eval_prefill.sh:4-12; scripts2/eval_prefill.sh:37-47 for the 36-layer
+    Ministral-8B with TSP layer 17) at 32,768 tokens, host logic only: `compress_fastkv` pushes the rates (utils.py:25-46), every call
+    rewrites `max_capacity_prompt` (3276 in front of and behind the TSP layer: int(32768 * 0.1) and int(6553 * 0.5)) and the TSP layer
+    its `tsp_length` (6553) (utils.py:86-87, :123-124) -- and the 6553-token layers behind the TSP layer, longer than
+    FASTKV_DEFER_MAX_LEN, run as LONG layers in groups of eight like the ones in front of it (the constant budget never does that)."""
+    import types
+    rec.max_entries = 16
+    S = 32768
+    mods = [types.SimpleNamespace(self_attn=types.SimpleNamespace(kv_cluster=C.FastKVCluster())) for _ in range(layers)]
+    model = types.SimpleNamespace(model=types.SimpleNamespace(layers=mods))
+    args = types.SimpleNamespace(window_size=[8] * layers, kernel_size=[7] * layers, pooling="maxpool", max_capacity_prompts=512, tsp_len=2048,
+                                 tsp_rate=0.2, eviction_mode="proportional", tsp_idx=tsp_idx, retain_rate=0.1)
+    C.compress_fastkv(model, args)
+    d = C.DeferredCompression(max_len=4096, hold_long=8)
+    done, s_now = {}, S
+    for i, m in enumerate(mods):
+        cl = m.self_attn.kv_cluster
+        q, k, v = _layer(i, s_now)
+        if cl.tsp_layer:
+            ko, vo, tsp, ready = d.add_tsp_layer(i, cl, k, q, v)
+            done[i] = ko
+            s_now = tsp.shape[1]
+        else:
+            ready = d.add(i, cl, k, q, v)
+        for j, ko, vo in ready:
+            done[j] = ko
+    for j, ko, vo in d.flush():
+        done[j] = ko
+    assert [c[1] for c in rec.calls] == want and all(c[0] == "entries" for c in rec.calls)
+    assert s_now == 6553 and [c[2] for c in rec.calls if c[2]] == [6553]
+    assert sorted(done) == list(range(layers)) and all(t.shape[2] == 3276 and float(t[0, 0, 0, 0]) == float(j) for j, t in done.items())
+    assert [m.self_attn.kv_cluster.max_capacity_prompt for m in mods] == [3276] * layers
+    assert mods[tsp_idx].self_attn.kv_cluster.tsp_length == 6553
+    assert [m.self_attn.kv_cluster.retain_rate for m in mods] == [0.1] * (tsp_idx + 1) + [0.5] * (layers - tsp_idx - 1)
+
+
+def test_group_size_is_capped_by_the_bytes_the_waiting_layers_hold(monkeypatch):
+    """FASTKV_DEFER_HOLD = 8 no longer scales the held q / k / v with the prompt and the batch without bound."""
+    import types
+    from baselines.fastkv._wiring import defer_hold_for
+    cfg = types.SimpleNamespace(num_attention_heads=32, num_key_value_heads=8, head_dim=128, hidden_size=4096)
+    monkeypatch.delenv("FASTKV_DEFER_HOLD", raising=False)
+    monkeypatch.delenv("FASTKV_DEFER_HOLD_GIB", raising=False)
+    assert defer_hold_for(cfg, 1, 32768) == 8 and defer_hold_for(cfg, 1, 8192) == 8
+    assert defer_hold_for(cfg, 1, 131072) == 3 and defer_hold_for(cfg, 4, 32768) == 3
+    assert defer_hold_for(cfg, 16, 131072) == 1
+    monkeypatch.setenv("FASTKV_DEFER_HOLD", "2")
+    assert defer_hold_for(cfg, 1, 32768) == 2
+    monkeypatch.setenv("FASTKV_DEFER_HOLD", "16")
+    monkeypatch.setenv("FASTKV_DEFER_HOLD_GIB", "64")
+    assert defer_hold_for(cfg, 1, 32768) == 16

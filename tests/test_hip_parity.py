@@ -689,6 +689,8 @@ from gen_inputs import make_qkv
 from fastkv_amd import ops
 from fastkv_amd._lib import load, FastKVNativeError
 from oracle import fastkv_oracle as O
+from helpers import default_contraction
+O.set_contraction(default_contraction())                                    # (children may run under FASTKV_CONTRACTION=fmaf)
 L = load(); dev = torch.device('cuda:0')
 q, k, v = make_qkv(77, 1, 32, 8, 32768, 128, 8)
 qd, kd, vd = (t.transpose(1, 2).contiguous().to(dev).transpose(1, 2) for t in (q, k, v))
@@ -719,16 +721,24 @@ def test_operator_next_to_a_kernel_that_holds_half_the_chip(dev):
     """A long-running kernel on another stream holds half of the compute units while the operator runs (32k shape: the fused
     scoring kernel's 512 workgroups and the split selection wait for partners that cannot become resident until the other
     kernel ends).  The launch is delayed, not broken: same bits as the oracle, no report."""
+    # The placement check belongs to the fp32-fma-chain contract (the hazard it fences off needs that contract's matrix phase:
+    # include/fastkv_hip.h fastkv_placement_violations): those launches count.  Launches of the default mfma16 contract do not arm it
+    # (ADVICE r04): same delay, same bits, nothing counted and nothing reported under the DEFAULT policy.
     r = _child("HOLD_MS = 300\nRESET = 1\n" + _RESIDENCY_CHILD +
                "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nassert viol > 0, viol\nprint('child ok')\n",
-               {"FASTKV_STRICT_PLACEMENT": "0"})
+               {"FASTKV_STRICT_PLACEMENT": "0", "FASTKV_CONTRACTION": "fmaf"})
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    r = _child("HOLD_MS = 300\nRESET = 0\n" + _RESIDENCY_CHILD +
+               "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nassert viol == 0, viol\n"
+               "assert same(run()) and L.fastkv_last_status() == 0 and not ops.no_wait_mode()\nprint('child ok')\n",
+               {"FASTKV_CONTRACTION": "mfma16"})
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     # (viol > 0: squeezed onto half of the chip, workgroups of different heads shared compute units -- the launch's own placement check
     # counts that; the result was right all the same.  FASTKV_STRICT_PLACEMENT=0 above = count only.)
     # The DEFAULT policy fails safe (ADVICE r03): the next call reports FASTKV_EPLACEMENT once -- the caller redoes the affected call --
     # and the process has switched to the no-wait kernels, so the redo cannot be exposed again whatever else runs on the GPU;
     # FASTKV_STRICT_PLACEMENT=1 reports and keeps the fused kernels.
-    for env, want_no_wait in (({}, True), ({"FASTKV_STRICT_PLACEMENT": "1"}, False)):
+    for env, want_no_wait in (({"FASTKV_CONTRACTION": "fmaf"}, True), ({"FASTKV_CONTRACTION": "fmaf", "FASTKV_STRICT_PLACEMENT": "1"}, False)):
         r = _child("HOLD_MS = 300\nRESET = 0\n" + _RESIDENCY_CHILD + f"""
 from fastkv_amd._lib import FASTKV_EPLACEMENT
 assert viol > 0 and not ops.no_wait_mode()
@@ -739,6 +749,11 @@ except FastKVNativeError as e:
     assert e.code == FASTKV_EPLACEMENT, str(e)
 assert ops.no_wait_mode() == {want_no_wait}
 assert L.fastkv_placement_violations(0) == viol                          # (reported violations stay in the running count)
+import warnings
+from fastkv_amd._lib import raise_if_aborted
+with warnings.catch_warnings():
+    warnings.simplefilter('error')                                       # ... and are not warned about a second time (ADVICE r04)
+    raise_if_aborted('after the report')
 torch.cuda.synchronize()
 L.fastkv_profile_enable(1)
 assert same(run()) and L.fastkv_last_status() == 0                       # the redo
@@ -808,6 +823,24 @@ def test_seed_sweep_32k_on_gpu(dev):
                                          return_indices=True)
         check_against_sweep(name, idx.cpu(), tsp.cpu(), z, meta)
         assert torch.equal(ko.cpu(), expected_kv(k, idx.cpu(), case["W"]))
+
+
+def test_wide_sweep_32k_on_gpu(dev):
+    """Every second case of the wide sweep (tests/golden/sweep_wide.npz: 24 seeds x {constant, recipe} x {maxpool, avgpool} + 24 peaked
+    cases, canonical top-k of the REFERENCE's scores as row digests) through the operator under the default contract: every row
+    matches the reference's digest except the rows the fixture lists, which differ by exactly the listed positions."""
+    from fastkv_amd import ops
+    from golden_cases import SWEEP_WIDE_CASES
+    from test_oracle_golden import _sweep_wide, check_against_wide_sweep
+    z, meta = _sweep_wide()
+    for i, (name, case) in enumerate(SWEEP_WIDE_CASES.items()):
+        if i % 2:
+            continue
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
+        qd, kd, vd = (_to_dev(t, dev) for t in (q, k, v))
+        ko, vo, tsp, idx = ops.update_kv(qd, kd, vd, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "index",
+                                         return_indices=True)
+        check_against_wide_sweep(name, idx.cpu(), tsp.cpu(), z, meta)
 
 
 def test_per_query_head_selection_snapkv_rule(dev):

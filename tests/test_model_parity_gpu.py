@@ -28,13 +28,13 @@ def _build(family, monkeypatch, defer, extra=(), S=S, LAYERS=LAYERS, TSP_IDX=TSP
     monkeypatch.setenv("FASTKV_DEFER", defer)
     monkeypatch.setenv("FASTKV_DEFER_HOLD", "8")
     monkeypatch.setenv("FASTKV_SLAB_CACHE", "0")
-    name = {"llama": "llama3-8b", "mistral": "mistral-7b"}[family]
+    name = {"llama": "llama3-8b", "mistral": "mistral-7b", "ministral": "ministral-8b"}[family]
     a = prefill.parse_args(["--model_path", name, "--num_layers", str(LAYERS), "--device", "cuda", "--save_txt", "", "--method", "fastkv",
                             "--max_capacity_prompts", str(BUDGET), "--tsp_len", str(TSP_LEN), "--tsp_idx", str(TSP_IDX),
                             "--pooling", "maxpool", *extra])
     a.save_txt = False
     a.context_lengths = [S]
-    (replace_llama if family == "llama" else replace_mistral)("fastkv")
+    (replace_llama if family == "llama" else replace_mistral)("fastkv")             # (Ministral-8B is a MistralForCausalLM)
     torch.manual_seed(101)
     model = prefill.build_model(a, "cuda")
     set_model(model, a)
@@ -62,6 +62,28 @@ def test_32k_prefill_every_layer_against_the_oracle(family, defer, monkeypatch):
     _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, [8, 8, 1])
 
 
+# The reference's PUBLISHED recipe -- the only setting its scripts ship (/root/reference/scripts/eval_prefill.sh:4-12: Llama-3.1-8B,
+# `--tsp_idx 15 --tsp_rate 0.2 --retain_rate 0.1 --eviction_mode proportional`; /root/reference/scripts2/eval_prefill.sh:37-47:
+# Ministral-8B-Instruct-2410, `--tsp_idx 17`, same rates; pooling / window / kernel at the harness defaults maxpool / 8 / 7).  At 32,768
+# tokens: every layer up to the TSP layer keeps int(32768 * 0.1) = 3276 rows, the TSP layer passes int(32768 * 0.2) = 6553 tokens on,
+# and the layers behind it -- retain_rate 0.1 / 0.2 = 0.5 (utils.py:41-46) -- keep int(6553 * 0.5) = 3276 of 6553.  Unlike the constant
+# budget, the layers behind the TSP layer are LONGER than FASTKV_DEFER_MAX_LEN: the default schedule runs them as "long" layers in
+# groups of eight (cluster.py DeferredCompression.add), so the whole-depth cases below drive [8, 8, 8, 8] (Llama: 16 + 16 layers) and
+# [8, 8, 2, 8] (Ministral geometry, 26 of its 36 layers: 18 in front of / including the TSP layer 17, 8 behind it) entry calls.
+RECIPE = ("--eviction_mode", "proportional", "--retain_rate", "0.1", "--tsp_rate", "0.2")
+
+
+@pytest.mark.parametrize("family,layers,tsp_idx,defer,calls", [
+    ("llama", 32, 15, "1", [8, 8, 8, 8]),
+    ("llama", 18, 15, "0", []),
+    ("ministral", 26, 17, "1", [8, 8, 2, 8]),
+    ("ministral", 20, 17, "0", []),
+])
+def test_published_recipe_32k_every_layer_against_the_oracle(family, layers, tsp_idx, defer, calls, monkeypatch):
+    _prefill_against_the_oracle(family, defer, monkeypatch, S, layers, tsp_idx, calls, extra=RECIPE, tsp_len=int(S * 0.2),
+                                caps=(int(S * 0.1), int(int(S * 0.2) * (0.1 / 0.2))))
+
+
 def test_70k_prefill_every_layer_against_the_oracle(monkeypatch):
     """A prompt beyond what a regular fused scoring launch holds (70,000 tokens): the three layers in front of and including the TSP
     layer are compressed TOGETHER -- one rolling launch whose entries are halves of a layer's KV heads (csrc/fused.hip) -- and every
@@ -69,12 +91,15 @@ def test_70k_prefill_every_layer_against_the_oracle(monkeypatch):
     _prefill_against_the_oracle("llama", "1", monkeypatch, 70000, 4, 2, [3, 1])
 
 
-def _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, deferred_calls):
+def _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, deferred_calls, extra=(), tsp_len=TSP_LEN, caps=None):
+    """`caps` = (capacity of the layers up to and including the TSP layer, capacity of the layers behind it); default: the constant
+    budget everywhere.  `extra`: more harness flags (the published recipe's --eviction_mode proportional ...)."""
+    TSP_LEN_, caps = tsp_len, caps or (BUDGET, BUDGET)
     from fastkv_amd import cluster as C
     from fastkv_amd import ops
     from oracle.fastkv_oracle import OracleFastKVCluster
 
-    model, a = _build(family, monkeypatch, defer, S=S, LAYERS=LAYERS, TSP_IDX=TSP_IDX)
+    model, a = _build(family, monkeypatch, defer, extra=extra, S=S, LAYERS=LAYERS, TSP_IDX=TSP_IDX)
     captured = {}
 
     def grab(layer_idx, cl, k, q, v):
@@ -116,8 +141,8 @@ def _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, 
     # the schedule under test really ran: two groups of eight (the TSP layer closing the second) + the post-TSP layer at the end
     assert entry_calls == (deferred_calls if defer == "1" else []), entry_calls
     assert sorted(captured) == list(range(LAYERS))
-    assert [captured[i][1].shape[2] for i in range(LAYERS)] == [S] * (TSP_IDX + 1) + [TSP_LEN] * (LAYERS - TSP_IDX - 1)
-    assert seen == [S] * TSP_IDX + [TSP_LEN] * (LAYERS - TSP_IDX)            # the TSP layer's OUTPUT is already gathered
+    assert [captured[i][1].shape[2] for i in range(LAYERS)] == [S] * (TSP_IDX + 1) + [TSP_LEN_] * (LAYERS - TSP_IDX - 1)
+    assert seen == [S] * TSP_IDX + [TSP_LEN_] * (LAYERS - TSP_IDX)           # the TSP layer's OUTPUT is already gathered
 
     pkv = out.past_key_values
     tsp_model = model.model.layers[TSP_IDX].self_attn.tsp_idx
@@ -137,9 +162,17 @@ def _prefill_against_the_oracle(family, defer, monkeypatch, S, LAYERS, TSP_IDX, 
                 bad.append("rewired position ids differ")
         elif wt is not None:
             bad.append(f"layer {i}: the oracle produced a TSP index on a non-TSP layer")
+        # the state the call leaves on the cluster object (proportional mode rewrites max_capacity_prompt on every call and tsp_length
+        # on the TSP layer, utils.py:86-87, :123-124; `compress_fastkv` and later prompts read them): product object == oracle object
+        cl = model.model.layers[i].self_attn.kv_cluster
+        if (cl.max_capacity_prompt, cl.tsp_length, cl.tsp_layer) != (oc.max_capacity_prompt, oc.tsp_length, oc.tsp_layer):
+            bad.append(f"layer {i}: cluster state {(cl.max_capacity_prompt, cl.tsp_length)} != the oracle's {(oc.max_capacity_prompt, oc.tsp_length)}")
+        if cl.max_capacity_prompt != caps[0 if i <= TSP_IDX else 1]:
+            bad.append(f"layer {i}: capacity {cl.max_capacity_prompt}")
         captured[i] = None
     assert not bad, bad
-    assert tuple(pkv.layers[0].keys.shape) == (1, 8, BUDGET, 128) and tuple(pkv.layers[LAYERS - 1].keys.shape) == (1, 8, BUDGET, 128)
+    assert model.model.layers[TSP_IDX].self_attn.kv_cluster.tsp_length == TSP_LEN_
+    assert tuple(pkv.layers[0].keys.shape) == (1, 8, caps[0], 128) and tuple(pkv.layers[LAYERS - 1].keys.shape) == (1, 8, caps[1], 128)
     assert out.logits.shape[:2] == (1, 1) and bool(torch.isfinite(out.logits).all())
 
 

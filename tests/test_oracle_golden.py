@@ -1,7 +1,9 @@
 """Pins the CPU oracle (oracle/fastkv_oracle.c) against golden vectors captured from the reference
 (tests/golden/make_golden.py ran /root/reference/baselines/fastkv/utils.py:80-134 in the build container).
 
-Protocol: (1) scores within 1 fp16 ulp on <= 0.1 % of the elements -- the reference's
+Protocol: (1) scores within the contract's gate (tests/helpers.py SCORE_GATES: the fp32 fma chain
+<= 1 fp16 ulp on <= 0.1 % of the elements, as SURVEY wrote it; the fp16 matrix instruction <= 2 ulp on <= 0.2 % on
+these goldens, measured up to 6 ulp on the peaked family of the wide sweep) -- the reference's
 own torch kernels are not reproducible to the last bit across accumulation orders; (2) canonical top-k of
 the REFERENCE's scores == oracle indices, bit-identical; (3) the reference's own (arbitrary-on-ties) pick
 lies between {c > v_k} and {c >= v_k}; (4) K/V rows are exact copies; (5) TSP index = canonical."""
@@ -243,6 +245,79 @@ def test_seed_sweep_32k_flip_statistics(contraction):
         q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"])
         _, _, idx, tsp = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "index")
         check_against_sweep(name, idx, tsp, z, meta)
+
+
+# ------------------------------------------------------------------------------------------------ the WIDE sweep (round 5)
+def row_digest(idx) -> int:
+    """tests/golden/make_sweep.py row_digest: 64-bit digest of an ascending index row."""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(np.ascontiguousarray(np.asarray(idx, dtype=np.int32)).tobytes(), digest_size=8).digest(), "little")
+
+
+def _sweep_wide(contraction=None):
+    import json
+    import os
+    from helpers import GOLDEN, default_contraction
+    z = np.load(os.path.join(GOLDEN, "sweep_wide.npz"))
+    with open(os.path.join(GOLDEN, "sweep_wide_meta.json")) as f:
+        return z, json.load(f)["contractions"][contraction or default_contraction()]
+
+
+def check_against_wide_sweep(name, kv_idx, tsp_idx, z, meta):
+    """As check_against_sweep, on the wide fixture: a row that does not flip under this contraction is held to the DIGEST of
+    canonical_topk(REFERENCE scores); a row that flips has the reference's full row in the fixture and differs from it by exactly
+    the listed positions."""
+    m = meta["cases"][name]
+    listed = {tuple(r["row"]): r for r in m["rows"]}
+    dig = z[name + ".dig"]
+    for b in range(kv_idx.shape[0]):
+        for g in range(kv_idx.shape[1]):
+            r = listed.get((b, g))
+            if r is not None and r["flips"]:
+                want = set(z[name + ".row%d_%d" % (b, g)].astype(np.int64).tolist())
+                got = set(kv_idx[b, g].tolist())
+                assert sorted(got - want) == r["flipped_positions"] and len(want - got) == r["flips"], (name, b, g)
+            else:
+                assert row_digest(kv_idx[b, g].numpy()) == int(dig[b, g]), (name, b, g)
+    if m["tsp"]["flips"]:
+        want, got = set(z[name + ".tsp"].astype(np.int64).tolist()), set(tsp_idx[0].tolist())
+        assert sorted(got - want) == m["tsp"]["flipped_positions"] and len(want - got) == m["tsp"]["flips"], name
+    else:
+        assert row_digest(tsp_idx[0].numpy()) == int(z[name + ".tsp_dig"][0]), name
+
+
+# What the wide sweep measured (tests/golden/sweep_wide_meta.json: 120 cases at S = 32768 = 1080 rows, 35.4 M scores per contract), with
+# headroom: the fraction of fp16 scores that differ from the REFERENCE's, the largest difference in ulps (a 1-ulp logit difference of a
+# heavy hitter moves its probability by several fp16 ulps: the peaked family is where the larger values come from), rows whose index set
+# differs from canonical_topk(reference scores), rows whose set is not even a valid top-k of the reference's scores.
+WIDE_BOUNDS = {"fmaf": dict(rate=5e-4, max_ulp=2, flip_rows=8, invalid=3), "mfma16": dict(rate=1.2e-3, max_ulp=6, flip_rows=26, invalid=13)}
+
+
+@pytest.mark.parametrize("contraction", CONTRACTIONS)
+def test_wide_sweep_statistics_and_replay(contraction):
+    """96 randn cases (24 seeds x {constant budget, published recipe} x {maxpool, avgpool}) + 24 peaked cases per
+    contract.  The committed statistics stay within the bounds above, the 95 % Wilson intervals are consistent with the counts, the
+    fma chain is the contract closer to the reference (fewer differing scores, fewer rows that flip) -- and every fifth case is replayed
+    through the oracle: the listed rows differ by exactly the listed positions, every other row matches the reference's digest."""
+    from golden_cases import SWEEP_WIDE_CASES
+    z, meta = _sweep_wide(contraction)
+    s, bnd = meta["summary"], WIDE_BOUNDS[contraction]
+    assert s["cases"] == len(SWEEP_WIDE_CASES) == 120 and s["rows"] == 1080
+    assert s["mismatch_rate"] < bnd["rate"] and s["max_ulp"] <= bnd["max_ulp"]
+    assert s["rows_that_flip"] <= bnd["flip_rows"] and s["rows_whose_set_is_not_a_valid_topk_of_the_reference_scores"] <= bnd["invalid"]
+    lo, hi = s["row_flip_rate_ci95"]
+    assert lo <= s["row_flip_rate"] <= hi and abs(s["row_flip_rate"] - s["rows_that_flip"] / s["rows"]) < 1e-12
+    assert set(meta["families"]) == {"cmax", "cavg", "rmax", "ravg", "peak"} and all(f["cases"] == 24 for f in meta["families"].values())
+    _, other = _sweep_wide("mfma16" if contraction == "fmaf" else "fmaf")
+    a, b = (s, other["summary"]) if contraction == "fmaf" else (other["summary"], s)
+    assert a["mismatch_rate"] < b["mismatch_rate"] and a["rows_that_flip"] < b["rows_that_flip"]     # fmaf is closer to the reference
+    O.set_contraction(contraction)
+    for i, (name, case) in enumerate(SWEEP_WIDE_CASES.items()):
+        if i % 5:
+            continue
+        q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
+        _, _, idx, tsp = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "index")
+        check_against_wide_sweep(name, idx, tsp, z, meta)
 
 
 @pytest.mark.parametrize("contraction", CONTRACTIONS)

@@ -149,6 +149,62 @@ def test_rolling_launch_on_a_chip_that_is_mostly_taken():
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
+_ABORT_CHILD = _HELD_CHILD.split("side = torch.cuda.Stream()")[0] + """
+from fastkv_amd._lib import FastKVNativeError, FASTKV_EABORTED
+import ctypes
+def fused_launches():
+    n = L.fastkv_profile_kernels()
+    counts, ms = (ctypes.c_int64 * n)(), (ctypes.c_double * n)()
+    assert L.fastkv_profile_read(counts, ms) == 0
+    return {L.fastkv_profile_kernel_name(i).decode(): int(counts[i]) for i in range(n) if counts[i]}
+side = torch.cuda.Stream()
+# another kernel holds 248 of the 256 compute units (31 of the 32 of every XCD: workgroup i of a grid goes to XCD i % 8, an XCD without a
+# free unit would stall the whole dispatch instead) for 900 ms: 16 places are left, no unit of an entry (32 workgroups) finds room, and the wait limit of
+# this process is 40 ms
+assert L.fastkv_debug_occupy(248, 128 * 1024, 900 * 1000, side.cuda_stream) == 0
+time.sleep(0.02)
+t0 = time.perf_counter()
+got = run()
+dt = (time.perf_counter() - t0) * 1e3
+print('held call took %.1f ms' % dt)
+assert dt < 800, dt                                                         # it gave up, it did not wait for the other kernel
+assert not ops.no_wait_mode()
+try:
+    run()                                                                   # the NEXT call reports the abandoned one ...
+    raise SystemExit('no report')
+except FastKVNativeError as e:
+    assert e.code == FASTKV_EABORTED, str(e)
+assert ops.no_wait_mode()                                                   # ... and the process has left the kernels that wait (default policy)
+L.fastkv_profile_enable(1)
+fused_launches()
+redo = run()                                                                # the holder may still be there: the redo does not care
+L.fastkv_profile_enable(0)
+ran = fused_launches()
+print('kernels of the redo:', sorted(ran))
+assert 'score_fused' not in ran, ran
+assert L.fastkv_last_status() == 0
+for a, b in zip(redo, want):
+    assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
+torch.cuda.synchronize()
+print('child ok')
+"""
+
+
+def test_an_abandoned_rolling_launch_switches_the_process_to_the_no_wait_kernels():
+    """a rolling launch's grid exceeds the chip by design; when a foreign kernel holds nearly all compute units for longer
+    than the wait limit, the launch is abandoned and REPORTED (FASTKV_EABORTED at the next call) -- and under the default policy the
+    process then runs the no-wait kernels, so the caller's redo cannot run into the same wait: it succeeds while the foreign kernel
+    may still be there, with the same bits as on the idle chip."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FASTKV_FUSED_ROLLING="1", FASTKV_SPIN_LIMIT_MS="40")
+    env.pop("FASTKV_STRICT_PLACEMENT", None)
+    r = subprocess.run([sys.executable, "-c", _ABORT_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 def test_rolling_launch_replayed_from_a_graph():
     """The operator over four 32k entries captured in a HIP graph and replayed on new data: the rolling launch is ONE kernel whose
     tokens come from the epoch in the workspace (not from launch arguments, which a replay would freeze) -- every replay equals the
