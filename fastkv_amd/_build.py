@@ -20,7 +20,7 @@ HEADERS = ["fk_device.h", "fk_hunt.h", "fk_host.h", "prof.h", "rank.h", "mfma_ti
 # `-target-feature -packed-fp32-ops`: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code (the same IEEE operations per
 # component, issued one by one: +1.4 us on the 77.5 us two-layer scoring launch in the trace, inside the noise of the step).  Why: a workgroup of the fused scoring kernel that
 # ran its packed-fp32 phases beside a partner's matrix phase on one compute unit computed wrong values now and then; without the packed
-# instructions the strongest reproducer of that goes from 40 % wrong launches to 0 of 600.  The host half of the
+# instructions the strongest reproducer of that goes from 40 % wrong launches to 0 of 600 (docs/HISTORY.md).  The host half of the
 # compilation does not know the feature and says so ("not a recognized feature for this target (ignoring feature)"): harmless.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-result",
                "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]

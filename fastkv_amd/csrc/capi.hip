@@ -340,7 +340,11 @@ static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t 
     uint32_t *epoch_bump = nullptr;                          // set when the fused score kernel ran: the compaction advances the epoch
     // (all_idx != nullptr switches the scoring stage to "identity selection": with score order only the keys are needed, so
     // the list goes to a scratch row area that nobody reads)
-    hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
+    // (the TSP row sums ride in the per-head selection launch where there is one on the split path: fk_host.h TspFold)
+    static const bool fold_off = []() { const char *e_ = getenv("FASTKV_TSP_FOLD"); return e_ && e_[0] == '0'; }();
+    const uint32_t *hist_rows = reinterpret_cast<const uint32_t *>(ws + L.off_hist);
+    const bool fold_tsp = !fold_off && t && !select_all && select_takes_split(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, hist_rows);
+    hipError_t e = launch_score(*p, L, q, q_strides, k, k_strides, c, L.n_pad, fold_tsp ? nullptr : t, L.n_pad, ws, st, select_all ? idx_asc : nullptr,
                                 select_all ? keys : nullptr, kal, &epoch_bump, pt);
     if (e == hipErrorNotSupported) return FASTKV_EUNSUPPORTED;   // (nothing has been launched)
     if (e != hipSuccess) return FASTKV_ELAUNCH;
@@ -362,8 +366,9 @@ static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t 
     }
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(ws);
     if (!select_all) {
+        const TspFold fold = {p->B, p->Hkv, t, L.n_pad, reinterpret_cast<uint32_t *>(ws + L.off_thist)};
         e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
-                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, st, ctrl);
+                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, st, ctrl, fold_tsp ? &fold : nullptr);
         if (e != hipSuccess) return fail();
     }
     if (p->tsp_len) {

@@ -129,9 +129,13 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
 // chip's idle vector ALUs and costs less than this extra launch; with MANY heads (>= 64: batched prompts, the bench's roofline
 // shape) it is what bounds the copy (174 us against 104 us in index order) and this kernel (all heads in parallel) takes
 // over.  A row whose keys are all equal degenerates to one bin and k^2 / 1024 comparisons per thread (~10 us at k = 2040).
-constexpr int RG_BINS = 4096;
+// BPT = bins per thread: 4096 bins for the budgets of a few thousand rows, fewer for longer winner lists so that bins + lists still fit the
+// workgroup's LDS (round 5: the published recipe keeps 3276 rows per head at 32k and 13,107 at 128k -- beyond the 2688 winners the 4096-bin
+// layout holds in 64 KiB, such calls used to fall back to the k^2 counting inside the copy kernel: 81 us instead of ~45 per 64-head launch).
+template <int BPT>
 __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__ keys, int kk, int kal)
 {
+    constexpr int RG_BINS = 1024 * BPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];
     uint32_t *s_start = reinterpret_cast<uint32_t *>(rg_smem);             // [RG_BINS] counts, then: winners in higher bins
     uint32_t *s_cnt = s_start + RG_BINS;                                    // [RG_BINS] members of the bin
@@ -159,11 +163,12 @@ __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__
     while (((mx - mn) >> sh) >= (uint32_t)RG_BINS) ++sh;
     for (int i = threadIdx.x; i < kk; i += 1024) atomicAdd(&s_start[(s_key[i] - mn) >> sh], 1u);
     __syncthreads();
-    // suffix sums over the bins: thread t owns bins 4t .. 4t+3
+    // suffix sums over the bins: thread t owns bins BPT t .. BPT t + BPT - 1
     {
-        const int b0 = threadIdx.x * 4;
-        const uint32_t c0 = s_start[b0], c1 = s_start[b0 + 1], c2 = s_start[b0 + 2], c3 = s_start[b0 + 3];
-        const uint32_t own = c0 + c1 + c2 + c3;
+        const int b0 = threadIdx.x * BPT;
+        uint32_t cb[BPT], own = 0;
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { cb[u] = s_start[b0 + u]; own += cb[u]; }
         uint32_t v = own;                                                   // -> sum over this and the higher lanes of the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = (uint32_t)__shfl_down((int)v, o, 64); if (lane + o < 64) v += nb; }
@@ -171,12 +176,9 @@ __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__
         __syncthreads();
         uint32_t higher = 0;
         for (int i = w + 1; i < 16; ++i) higher += s_w[i];
-        const uint32_t above = v - own + higher;                            // winners in the bins of higher threads
-        s_cnt[b0] = c0; s_cnt[b0 + 1] = c1; s_cnt[b0 + 2] = c2; s_cnt[b0 + 3] = c3;
-        s_start[b0 + 3] = above;
-        s_start[b0 + 2] = above + c3;
-        s_start[b0 + 1] = above + c3 + c2;
-        s_start[b0] = above + c3 + c2 + c1;
+        uint32_t above = v - own + higher;                                  // winners in the bins of higher threads
+#pragma unroll
+        for (int u = BPT - 1; u >= 0; --u) { s_cnt[b0 + u] = cb[u]; s_start[b0 + u] = above; above += cb[u]; }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kk; i += 1024) {
@@ -205,11 +207,16 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
     ProfScope ps_(K_COMPACT, st);
     const size_t kal = ((size_t)(p.capacity - p.window) + 7) & ~(size_t)7;
     int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                      // 32 KiB of LDS at most
-    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 2688) {           // (its LDS: 48 KiB of bins + 6 bytes per winner <= 64 KiB)
-        // many heads: every head's key list becomes its slot list (workspace memory of this call)
+    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 8704) {
+        // many heads: every head's key list becomes its slot list (workspace memory of this call).  LDS: 12 bytes per bin + 6 per winner
+        // <= 64 KiB: 4096 bins up to 2688 winners, 2048 up to 6656, 1024 up to 8704; longer lists keep the counting inside the copy
         const int kk_ = p.capacity - p.window;
-        const size_t lds = (size_t)3 * RG_BINS * 4 + kal * 4 + kal * 2;
-        hipLaunchKernelGGL(rank_group_kernel, dim3((unsigned)(p.B * p.Hkv)), dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+        const int bpt = kal <= 2688 ? 4 : kal <= 6656 ? 2 : 1;
+        const size_t lds = (size_t)3 * 1024 * bpt * 4 + kal * 4 + kal * 2;
+        const dim3 rg((unsigned)(p.B * p.Hkv));
+        if (bpt == 4) hipLaunchKernelGGL(rank_group_kernel<4>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+        else if (bpt == 2) hipLaunchKernelGGL(rank_group_kernel<2>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+        else hipLaunchKernelGGL(rank_group_kernel<1>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
         keys_in_lds = 2;
     }
     const size_t kpad = (kal + 32 * (size_t)lpr - 1) / (32 * (size_t)lpr) * (32 * (size_t)lpr);   // (rank_partial_padded reads whole steps)
@@ -272,17 +279,19 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *_
     const int64_t pieces = row_bytes >> 4;
     // four pieces of a thread in flight before the first store (8 KiB hidden-state rows: both of a thread's pieces -- a "load, store,
     // load, store" loop pays a memory round trip per piece)
+    // (non-temporal on both sides, as in compact_kv: every source row is read once, every destination byte written once by this launch)
+    typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
     for (int64_t pc = sub; pc < pieces; pc += 4 * (int64_t)lpr) {
-        uint4 x[4];
+        nt_u32x4 x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t q = pc + u * (int64_t)lpr;
-            x[u] = *reinterpret_cast<const uint4 *>(sp + (q < pieces ? q : pc) * 16);
+            x[u] = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(sp + (q < pieces ? q : pc) * 16));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t q = pc + u * (int64_t)lpr;
-            if (q < pieces) *reinterpret_cast<uint4 *>(dp + q * 16) = x[u];
+            if (q < pieces) __builtin_nontemporal_store(x[u], reinterpret_cast<nt_u32x4 *>(dp + q * 16));
         }
     }
 }
@@ -292,7 +301,9 @@ hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const i
 {
     if (rows_out == 0 || batches == 0) return hipSuccess;
     int lpr_shift = 0;
-    while ((1 << lpr_shift) < 256 && ((int64_t)16 << lpr_shift) < row_bytes) ++lpr_shift;
+    // four 16-B pieces per lane where the row is long enough (all of them requested before the first store; with one piece per lane and
+    // 256 lanes on an 8 KiB row half of a thread's four loads were clamped repeats)
+    while ((1 << lpr_shift) < 256 && ((int64_t)64 << lpr_shift) < row_bytes) ++lpr_shift;
     const int rpb = 256 >> lpr_shift;
     dim3 grid((unsigned)((rows_out + rpb - 1) / rpb), (unsigned)batches);
     ProfScope ps_(K_GATHER, st);

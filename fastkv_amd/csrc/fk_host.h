@@ -138,9 +138,22 @@ hipError_t launch_sp_rowstats(const fastkv_problem &p, uint16_t *logits, const f
 hipError_t launch_sp_scores(const fastkv_problem &p, uint16_t *logits, const fastkv_sp_window &w, const float *gmax,
                             const int64_t *sums, uint16_t *c_out, int64_t c_row_stride, uint16_t *t_out,
                             int64_t t_row_stride, int n_own, hipStream_t st);
+// The TSP row sums t[b, j] = fp16(sum over the KV heads of c[b, g, j]) (utils.py:127) + their 12-bit key histogram, computed by extra
+// workgroups of the per-head selection launch instead of a launch of their own (round 5: 8-10 us for 0.5 MB, all latency, on the step's
+// critical path): the selection's own workgroups come first in the grid, the extra ones behind them read the scores the launch is
+// given and share nothing with the selection.  `B` batch rows of `Hkv` score rows each.
+struct TspFold {
+    int B, Hkv;
+    uint16_t *t_out;
+    int64_t t_row_stride;
+    uint32_t *thist;
+};
+// true when launch_select will take the split selection (table or wait-free): the launches a TspFold can ride in
+bool select_takes_split(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, const uint32_t *hist12);
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
-                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl = nullptr);
+                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl = nullptr,
+                         const TspFold *fold = nullptr);
 hipError_t launch_rank_scatter(const int64_t *idx_asc, int64_t asc_row_stride, const uint16_t *keys, int64_t key_row_stride,
                                int64_t rows, int64_t k, int64_t *out, int64_t out_row_stride, hipStream_t st);
 // idx: ascending-position winners; keys != nullptr => rows are placed in ORDER_SCORE (rank by comparison counting, or -- 64 or

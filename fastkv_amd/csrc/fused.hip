@@ -27,7 +27,7 @@
 // Which workgroup works for which (entry, unit, span): numbered unit by unit, span fastest -- a launch of up to one workgroup per
 // compute unit is dispatched unit after unit and gets through a partly occupied GPU.  With more workgroups than compute units,
 // workgroup p and workgroup p + #CUs sit on ONE compute unit; they are given adjacent spans of one unit, so that the hand-offs keep
-// the two in step (see the kernel body; the measurement behind this is in DESIGN.md section 8).
+// the two in step (see the kernel body; the measurement behind this is in docs/HISTORY.md).
 #include "fk_device.h"
 #include "fk_host.h"
 #include "prof.h"
@@ -98,7 +98,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
@@ -138,7 +138,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // Entries 1 .. F-1 of a rolling launch (launch_score_fused; `rolling` = F, the entries the chip holds at a time) start late ON
     // PURPOSE, one K-streaming time apart: entries that begin together stay in step -- all stream K, then all do arithmetic -- and
     // gain nothing from sharing the chip.
-    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
+    // (WPE == 3: an entry is more workgroups than half of the chip's places; only the part of entry 1 that starts WITH entry 0 is held back,
+    // the rest of it starts when places free up, which is late enough)
+    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling && (WPE == 2 || 2 * blockIdx.x < gridDim.x)) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
@@ -152,7 +154,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // tools/probes/probe_lds_iso.hip): the two are given ADJACENT SPANS OF ONE UNIT (the host makes the span count even), so that the
     // hand-offs keep them in step -- neither can be a phase ahead of the other (maxima, sums and halo all need the partner's record).
     // Why that matters: a workgroup that runs its later phases beside one still in phase A (another entry's, held up by the NaN redo
-    // or anything else) was measured to produce wrong row sums / window-row sums now and then (tools/repro_nan_mate.py).
+    // or anything else) was measured to produce wrong row sums / window-row sums now and then (tools/repro_nan_mate.py; docs/HISTORY.md).
     // (a rolling launch may split a batch row's units over `parts` entries -- prompts so long that the units of one row do not fit
     // half of the chip: an entry is then UP / parts units of a row, the rows' parts follow each other in grid order)
     const int UPE = rolling ? UP / parts : UP;                   // units per entry of this launch
@@ -916,7 +918,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NS - 1>;            // (== S0 when NS == 1: the second calls below are compiled out)
+    if (tune & 1) __builtin_amdgcn_s_setprio(3);
     phaseA(S0{});
+    if (tune & 1) __builtin_amdgcn_s_setprio(0);
     FKF_STAMP(1);
     if (NS == 2) phaseA(S1{});
     FKF_STAMP(2);
@@ -959,11 +963,11 @@ __global__ void __launch_bounds__(256, WPE) score_fused_kernel(const uint16_t *_
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune)
 {
     (void)score_fused_body<D, PER, NB, NS, F16, WPE>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts, tune);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1031,6 +1035,14 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
 #undef FK_CASES_D
 #undef FK_CASE
     return false;
+}
+
+// measurement switch of the rolling launch (FASTKV_FUSED_TUNE, bits): 1 = the waves of an entry run phase A (K streaming) at raised
+// issue priority (s_setprio 3), so that their loads / LDS commits are never queued behind the other entry's vector work
+static int fused_tune()
+{
+    static const int t = []() { const char *e = getenv("FASTKV_FUSED_TUNE"); return e ? atoi(e) : 0; }();
+    return t;
 }
 
 // the rolling launch (launch_score_fused) is on unless FASTKV_FUSED_ROLLING=0 / fastkv_set_fused_rolling(0)
@@ -1184,6 +1196,32 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         // Prompts whose rows do not fit half of the chip even then (beyond 32k tokens at 8 KV heads) are split: an entry is 1 / parts of a
         // row's units (4 heads at 64k, 2 at 128k, 1 at 256k), the parts of a row follow each other like entries do -- the units of a row
         // share nothing but the row's inputs.  (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
+        // ---- Round 5: THREE workgroups per compute unit (FASTKV_FUSED_OCC3, csrc/fused.hip score_fused_kernel<..., WPE = 3>).  The launch
+        // above holds two entries of four tiles per wave: two waves per SIMD, each of which spends half of its life waiting for a hand-off
+        // (profiles/r04d_pmc_mfma_summary.json: SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.49, 26 % vector issue, 34 % of HBM).  With two tiles per wave
+        // an entry is 512 workgroups of 168 registers and 51 KiB of LDS: 768 of them are resident -- one and a half entries, three waves per
+        // SIMD in three different phases -- and the grid order does the staggering: the second half of entry e + 1 starts as the workgroups
+        // of entry e leave.  Hand-offs are per unit (a KV head's 64 workgroups, dispatched together), record areas rotate over four entries
+        // (768 consecutive workgroups touch three entries at most).  16k < rows <= 32k tokens at 8 KV heads for now.
+        {
+            static const int occ3_env = []() { const char *e = getenv("FASTKV_FUSED_OCC3"); return e ? atoi(e) : 0; }();
+            const int nwt64 = (p.S + 63) / 64, nblk3 = (nwt64 + 7) / 8, wgs3 = UH * nblk3;
+            bool res3 = false;
+            if (rolling_on && occ3_env && f16 && VH == 1 && p.B >= 3 && p.B <= EPOCH_STRIDE && wgs3 > 256 && wgs3 <= 512 && 4 * wgs3 <= FUSED_MAX_WGS &&
+                fused_dispatch(p.D, 2, 2, 1, true, [&](auto fl) { res3 = decltype(fl)::resident(3 * device_cus()); }, 3) && res3) {
+                const dim3 grid(wgs3, p.B);
+                ProfScope ps_(K_FUSED, st);
+                fused_dispatch(p.D, 2, 2, 1, true, [&](auto fl) {
+                    decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
+                                         p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
+                                         c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
+                                         pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr, (uint64_t *)nullptr, 2,
+                                         occ3_env >= 2 ? stagger_ticks * (occ3_env - 1) / 4 : 0, 1, fused_tune());
+                }, 3);
+                *err = hipGetLastError();
+                return true;
+            }
+        }
         int F = 0, parts = 1;
         const bool have_plan = rolling_plan_for(p, UH, f16, F, parts, ph);
         const int entries = p.B * parts;
@@ -1195,7 +1233,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts * 2 / F, parts);     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts * 2 / F, parts, fused_tune());     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
             });
             *err = hipGetLastError();
             return true;
@@ -1214,7 +1252,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, 0, 0, 1);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, 0, 0, 1, 0);
         });
         *err = hipGetLastError();
         b0 += take;

@@ -139,7 +139,7 @@ __device__ __forceinline__ void perm_operands(int lane, f16x8 &p0, f16x8 &p1)
         p1[e] = (_Float16)(delta == 16 + 8 * h + e ? 1.0f : 0.0f);
     }
 }
-// (CUT: measurement builds of the hunt in DESIGN.md section 8 -- 0 the kernel's phase; 1 the fp16 MFMAs take their K operand from
+// (CUT: measurement builds of the hunt in docs/HISTORY.md -- 0 the kernel's phase; 1 the fp16 MFMAs take their K operand from
 // registers instead of LDS; 2 the fp32 MFMAs take a constant B operand instead of the fp16 MFMAs' results; 3 the fp32 MFMAs take their A
 // operand from registers instead of LDS; 4 the kernel's phase with the fp16 MFMAs' results copied by v_mov_b32 before the fp32 MFMAs read them.  Results are garbage for CUT != 0: only the delayed workgroups run those.)
 template <int NB = 2, int CUT = 0>

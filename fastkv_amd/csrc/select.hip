@@ -298,14 +298,65 @@ struct SplShared {
 // no token, no wait on a partner: one memory round trip instead of publish + poll + sweep, and nothing that needs the
 // workgroups of the launch to be resident together.
 constexpr int SPL_WF_CHUNKS = 16;
+
+// The extra workgroups of a selection launch that carries the TSP row sums (fk_host.h TspFold): workgroup (chunk, b) sums the Hkv score
+// rows of batch row b over the chunk's 2048 positions -- fp32, head order, one rounding: tsp_rowsum_kernel's arithmetic (score.hip;
+// utils.py:127) -- eight positions per thread, every head's 16-B vector requested before the first is used.
+__device__ __forceinline__ void tsp_fold_role(const uint16_t *__restrict__ c, int64_t c_row_stride, int n, int chunk, int b, const TspFold &f)
+{
+    __shared__ uint32_t s_thist[HIST12];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HIST12; i += SPL_THREADS) s_thist[i] = 0;
+    __syncthreads();
+    const int j0 = chunk * SPL_CHUNK + tid * 8;
+    const int jl = ((n - 1) >> 3) << 3;
+    const uint16_t *base = c + (size_t)b * f.Hkv * c_row_stride + (j0 < n ? j0 : jl);
+    float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int g0 = 0; g0 < f.Hkv; g0 += 8) {
+        uint4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const uint4 *>(base + (size_t)(g0 + u < f.Hkv ? g0 + u : g0) * c_row_stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (g0 + u < f.Hkv) {
+                const uint32_t wds[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = a[e] + h2f((uint16_t)((wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
+            }
+        }
+    }
+    uint16_t t16[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t16[e] = f2h_score(a[e]);
+    if (j0 < n) {
+        uint16_t *tp = f.t_out + (size_t)b * f.t_row_stride + j0;
+        if (j0 + 7 < n && (reinterpret_cast<uintptr_t>(tp) & 15) == 0) {
+            *reinterpret_cast<uint4 *>(tp) = make_uint4((uint32_t)t16[0] | ((uint32_t)t16[1] << 16), (uint32_t)t16[2] | ((uint32_t)t16[3] << 16),
+                                                        (uint32_t)t16[4] | ((uint32_t)t16[5] << 16), (uint32_t)t16[6] | ((uint32_t)t16[7] << 16));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (j0 + e < n) tp[e] = t16[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hist12_add(s_thist, mono16(t16[e]) >> 4, j0 + e < n, tid & 63);
+    __syncthreads();
+    uint32_t *gh = f.thist + (size_t)b * HIST12;
+    for (int i = tid; i < HIST12; i += SPL_THREADS) { const uint32_t v = s_thist[i]; if (v) atomicAdd(&gh[i], v); }
+}
+
 template <bool WAITFREE>
 __global__ void __launch_bounds__(SPL_THREADS) select_split_kernel(const uint16_t *__restrict__ scores, int64_t row_stride, int n, int k,
                                                                    int append, int64_t *__restrict__ idx_out, int64_t idx_row_stride,
                                                                    uint16_t *__restrict__ key_out, int64_t key_row_stride,
                                                                    const uint32_t *__restrict__ hist12,
                                                                    uint64_t *__restrict__ table, uint32_t *__restrict__ ctrl,
-                                                                   uint32_t *__restrict__ host_flag, uint64_t spin_ticks)
+                                                                   uint32_t *__restrict__ host_flag, uint64_t spin_ticks, int rows, TspFold fold)
 {
+    if ((int)blockIdx.y >= rows) {                               // (the workgroups behind the selection's: the TSP row sums, fk_host.h TspFold)
+        tsp_fold_role(scores, row_stride, n, blockIdx.x, (int)blockIdx.y - rows, fold);
+        return;
+    }
     __shared__ SplShared sh;
     __shared__ uint32_t s_abort;
     // bounded wait (fk_device.h SpinCtl): same token as the scoring launch of this operator call (the epoch advances in the
@@ -543,11 +594,23 @@ __global__ void __launch_bounds__(256) rank_scatter_kernel(const int64_t *__rest
     if (p < k && sub == 0) out[(size_t)rowi * out_row_stride + r] = idx_asc[(size_t)rowi * asc_row_stride + p];
 }
 
+bool select_takes_split(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, const uint32_t *hist12)
+{
+    const int64_t nchunks = (n + SPL_CHUNK - 1) / SPL_CHUNK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && (row_stride % 8 == 0) && (row_stride >= ((n + 7) & ~(int64_t)7));
+    if (!(hist12 && k > 0 && nchunks >= 2 && rows >= 1 && rows <= 65000 && vec)) return false;
+    const bool table_ok = abort_flag_device() && rows * nchunks <= SPL_MAX_WGS && !no_wait_mode();
+    return table_ok || nchunks <= SPL_WF_CHUNKS;
+}
+
 hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_stride, int64_t n, int64_t k, int append,
                          int64_t *idx_out, int64_t idx_row_stride, uint16_t *key_out, int64_t key_row_stride,
-                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl)
+                         const uint32_t *hist12, uint32_t *arrive, uint32_t *table, hipStream_t st, uint32_t *ctrl, const TspFold *fold)
 {
     if (rows == 0) return hipSuccess;
+    const TspFold nofold = {0, 0, nullptr, 0, nullptr};
+    const TspFold fd = fold ? *fold : nofold;
+    const unsigned extra = fold ? (unsigned)fold->B : 0u;        // (the caller asked select_takes_split first: a fold never reaches select_topk)
     uint32_t *host_flag = ctrl ? abort_flag_device() : nullptr;
     const int64_t nchunks = (n + SPL_CHUNK - 1) / SPL_CHUNK;
     const bool vec = ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && (row_stride % 8 == 0) && (row_stride >= ((n + 7) & ~(int64_t)7));
@@ -559,18 +622,18 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
     const bool table_ok = hist12 && table && host_flag && k > 0 && nchunks >= 2 && rows * nchunks <= SPL_MAX_WGS && rows <= 65535 && vec;
     if (table_ok && !no_waits) {
         ProfScope ps_(K_SELECT_SPLIT, st);
-        hipLaunchKernelGGL(select_split_kernel<false>, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
+        hipLaunchKernelGGL(select_split_kernel<false>, dim3((unsigned)nchunks, (unsigned)rows + extra), dim3(SPL_THREADS), 0, st, scores, row_stride,
                            (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12,
-                           reinterpret_cast<uint64_t *>(table), ctrl, host_flag, spin_limit_ticks());
+                           reinterpret_cast<uint64_t *>(table), ctrl, host_flag, spin_limit_ticks(), (int)rows, fd);
         return hipGetLastError();
     }
     if (hist12 && k > 0 && nchunks >= 2 && nchunks <= SPL_WF_CHUNKS && rows <= 65535 && vec) {
         // every chunk counts the row for itself: no table, no residency requirement, any number of rows (also what rows x
         // chunks beyond SPL_MAX_WGS get instead of one workgroup per row)
         ProfScope ps_(K_SELECT_SPLIT, st);
-        hipLaunchKernelGGL(select_split_kernel<true>, dim3((unsigned)nchunks, (unsigned)rows), dim3(SPL_THREADS), 0, st, scores, row_stride,
+        hipLaunchKernelGGL(select_split_kernel<true>, dim3((unsigned)nchunks, (unsigned)rows + extra), dim3(SPL_THREADS), 0, st, scores, row_stride,
                            (int)n, (int)k, append, idx_out, idx_row_stride, key_out, key_row_stride, hist12,
-                           reinterpret_cast<uint64_t *>(table), ctrl, host_flag, (uint64_t)0);
+                           reinterpret_cast<uint64_t *>(table), ctrl, host_flag, (uint64_t)0, (int)rows, fd);
         return hipGetLastError();
     }
     const int64_t kal = (k + 7) & ~(int64_t)7;

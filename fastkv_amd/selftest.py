@@ -1,4 +1,4 @@
-"""Load-time self-test of the co-residency fixes (tools/probes/README.md "Erratum note").
+"""Load-time self-test of the co-residency fixes (docs/HISTORY.md, tools/probes/README.md "Erratum note").
 
 Round 3 found a silent wrong answer when a workgroup of the fused scoring kernel ran its vector phases beside ANOTHER head's workgroup
 that was still in the fp32-contract matrix phase on the same compute unit; the trigger in the wild was one entry of a multi-entry

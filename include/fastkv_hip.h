@@ -115,7 +115,7 @@ int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
 int fastkv_last_status(void);
 /*
  * The fused scoring kernel gives the two workgroups that share a compute unit adjacent spans of one (batch row, kv head): which two
- * share is the GPU's dispatch order on an idle device, an observation and not a promise (DESIGN.md section 8 on why the kernel
+ * share is the GPU's dispatch order on an idle device, an observation and not a promise (docs/HISTORY.md on why the kernel
  * cares: a workgroup that ran a phase ahead of a DIFFERENT unit's workgroup on its compute unit was measured to produce wrong sums
  * now and then -- under the fp32-fma-chain contract (FASTKV_CONTRACTION=fmaf), whose matrix phase is one half of that hazard; launches of
  * the default "mfma16" contract issue neither half and do not arm the check).  Every launch of the fma-chain contract checks it: a workgroup that finds another unit's workgroup of the same launch on its compute unit

@@ -932,6 +932,19 @@ def test_score_order_with_many_heads_groups_instead_of_counting(dev):
     want = O.update_kv(q, k2, v2, 8, 7, "avgpool", 1100, 0, "score")               # keep-all layers: every candidate ranked
     got = ops.update_kv(_to_dev(q, dev), _to_dev(k2, dev), _to_dev(v2, dev), 8, 7, "avgpool", 1100, 0, "score", return_indices=True)
     assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[3].cpu(), want[2])
+    # longer winner lists (round 5: the published recipe keeps 3276 rows per head at 32k; the grouping pass used to stop at 2688 winners
+    # and such calls fell back to the counting): 2048 bins (<= 6656 winners), 1024 bins (<= 8704), and the counting fallback beyond
+    B2, S2 = 8, 9800
+    k3 = torch.randn(B2, Hkv, S2, D, generator=g).half()
+    v3 = torch.randn(B2, Hkv, S2, D, generator=g).half()
+    sc3 = (torch.rand(B2 * Hkv, S2 - W, generator=g) * 512).floor().half() / 512      # ties everywhere
+    k3d, v3d, sc3d = _to_dev(k3, dev), _to_dev(v3, dev), sc3.to(dev)
+    for kk in (2689, 3268, 6656, 6657, 8704, 8705, S2 - W):
+        asc = ops.select(sc3d, kk, "index").view(B2, Hkv, kk).contiguous()
+        srt = ops.select(sc3d, kk, "score").view(B2, Hkv, kk).contiguous()
+        ko, vo, got = ops.compact(k3d, v3d, asc, W, scores=sc3d.view(B2, Hkv, S2 - W), return_sorted=True)
+        assert torch.equal(got, srt), kk
+        assert torch.equal(ko.cpu(), expected_kv(k3, srt.cpu(), W)) and torch.equal(vo.cpu(), expected_kv(v3, srt.cpu(), W)), kk
 
 
 def test_every_operator_call_spends_its_handoff_token(dev):
@@ -1021,7 +1034,7 @@ def test_a_slow_entry_does_not_disturb_the_entries_beside_it(dev):
     """Regression (round 3): more workgroups than compute units = two workgroups per unit.  With the launch's linear order the
     partner of a workgroup belonged to ANOTHER entry; when that entry was slow in phase A (a NaN in its query window sends every
     tile through the vector-ALU redo) the partner ran its later phases beside it and produced wrong row sums / window-row sums in
-    10-20 % of the launches (tools/repro_nan_mate.py).  The kernel now pairs adjacent spans of ONE unit, which the
+    10-20 % of the launches (tools/repro_nan_mate.py; docs/HISTORY.md).  The kernel now pairs adjacent spans of ONE unit, which the
     hand-offs keep in step.  16 entries x 2 virtual heads x 15 (-> 16) spans = 512 workgroups; the NaN entry itself is NaN all over
     (as in the oracle), every other entry must be bit-exact, launch after launch."""
     from fastkv_amd import ops

@@ -109,7 +109,7 @@ def test_cpu_tensors_are_rejected_not_emulated():
 
 
 def test_library_is_built_without_packed_fp32_instructions():
-    """Round 3: packed-fp32 vector instructions of one workgroup beside another workgroup's matrix phase on a
+    """Round 3 (docs/HISTORY.md): packed-fp32 vector instructions of one workgroup beside another workgroup's matrix phase on a
     compute unit produced wrong values now and then; the library is therefore compiled with `-target-feature -packed-fp32-ops`.
     The flag must stay in the build, and the objects of the shipped library must have been compiled with it."""
     import os

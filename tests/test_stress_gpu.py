@@ -1,6 +1,6 @@
 """A bounded slice of the randomised parity stress (tests/stress_cases.py, the engine of tools/stress_parity.py) inside the suite
 the driver runs: every real defect of this project -- the NaN sign, the unspent hand-off token, the co-residency damage
- -- was found by that tool and by none of the fixed-shape tests.
+(docs/HISTORY.md) -- was found by that tool and by none of the fixed-shape tests.
 
 Fixed seeds, so the cases are the same on every box; what is asserted for the slice as a whole:
   * 0 mismatches against the CPU oracle (scores, indices, K/V rows, TSP index; bit for bit);
@@ -31,7 +31,7 @@ def test_random_parity_slice(n, seed, entries_p):
 
 def test_known_trigger_of_the_co_residency_damage_replayed():
     """Case 197 of seed 11 (16 separately allocated entries, G = 8, S = 14,695, a NaN in entry 0's query window -- the case that
-    exposed the co-residency damage), 30 times: before the two fixes 10-20 % of such launches had wrong
+    exposed the co-residency damage, docs/HISTORY.md), 30 times: before the two fixes 10-20 % of such launches had wrong
     entries 8 / 9."""
     from stress_cases import run_stress
     lines = []

@@ -1,5 +1,5 @@
 // Probe: packed-fp32 arithmetic on HIGH-numbered registers (v[192:255] of a wave that owns all 256) beside the partner's matrix phase
-// (mfma_tile.h, CUT 4) -- the standalone form of DESIGN.md section 8's pair once more, this time with the register numbers the kernel's
+// (mfma_tile.h, CUT 4) -- the standalone form of docs/HISTORY.md's pair once more, this time with the register numbers the kernel's
 // softmax phases really use.  B computes a chain of v_pk_fma_f32 in inline assembly on v[200:215] and the same chain with v_fma_f32 on low
 // registers; they must agree bit for bit.
 #include "../../fastkv_amd/csrc/mfma_tile.h"

@@ -1,4 +1,4 @@
-// Probe: the pair the hunt of DESIGN.md section 8 ended at, outside the kernel.  Workgroups 0..255 ("A") run the fused kernel's matrix phase
+// Probe: the pair the hunt of docs/HISTORY.md ended at, outside the kernel.  Workgroups 0..255 ("A") run the fused kernel's matrix phase
 // (mfma_tile.h: K from LDS into fp16 MFMAs, their results -- CUT 4: copied by v_mov_b32 -- into fp32 MFMAs) in bursts with sleeps between;
 // workgroups 256..511 ("B", their partners on the compute units; both own 80 KiB of LDS and 256 registers) run chains of PACKED fp32
 // arithmetic (the softmax phases' exponential) on inputs that depend on (lane, iteration) only and keep an XOR checksum per thread.
