@@ -328,6 +328,20 @@ def defer_hold_for(config, batch: int, seq_len: int, itemsize: int = 2) -> int:
     return max(1, min(hold, int(budget // max(1, per_layer)) + 1))
 
 
+def defer_max_len_for(config, batch: int, itemsize: int = 2) -> int:
+    """Layers of at most this many tokens wait for the END of the forward pass and are compressed in one launch sequence
+    (DeferredCompression `max_len`): FASTKV_DEFER_MAX_LEN, default 8192 since round 5 -- the 6553-token layers behind the TSP layer of
+    the published recipe at 32k then run as ONE sequence of 16 instead of two groups of eight (0.776 -> 0.750 ms per step) -- capped so
+    that what all of a model's layers would hold alive at that length stays within FASTKV_DEFER_HOLD_GIB (4): 3.2 GB at batch 1."""
+    want = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "8192"))
+    budget = float(os.environ.get("FASTKV_DEFER_HOLD_GIB", "4")) * 2 ** 30
+    heads = getattr(config, "num_attention_heads", 32)
+    kvh = getattr(config, "num_key_value_heads", None) or heads
+    hd = getattr(config, "head_dim", None) or config.hidden_size // heads
+    per_token = max(1, getattr(config, "num_hidden_layers", 32) * batch * (heads + 2 * kvh) * hd * itemsize)
+    return max(0, min(want, int(budget // per_token)))
+
+
 def make_model_forward(modeling, mask_fn_for):
     def model_forward_fastkv(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                              inputs_embeds=None, use_cache=None, **kwargs):
@@ -372,7 +386,7 @@ def make_model_forward(modeling, mask_fn_for):
                 and inputs_embeds.shape[1] > 1 and inputs_embeds.is_cuda \
                 and os.environ.get("FASTKV_DEFER", "1") != "0":
             from fastkv_amd.cluster import DeferredCompression
-            defer = DeferredCompression(max_len=int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096")),
+            defer = DeferredCompression(max_len=defer_max_len_for(self.config, inputs_embeds.shape[0], inputs_embeds.element_size()),
                                         hold_long=defer_hold_for(self.config, inputs_embeds.shape[0], inputs_embeds.shape[1],
                                                                  inputs_embeds.element_size()))
         for decoder_layer in self.layers[: self.config.num_hidden_layers]:

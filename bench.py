@@ -94,7 +94,7 @@ class HotPathPrefill:
         compress_fastkv(self.model, args)
         self.clusters = [l.self_attn.kv_cluster for l in layers]
         self.defer = os.environ.get("FASTKV_DEFER", "1") != "0"
-        self.defer_max_len = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "4096"))
+        self.defer_max_len = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "8192"))     # (baselines/fastkv/_wiring.py defer_max_len_for)
         self.defer_hold = int(os.environ.get("FASTKV_DEFER_HOLD", "8"))
 
     def step(self):
@@ -894,7 +894,7 @@ def main():
                     work.step()
                 torch.cuda.synchronize()
                 ms_all = (time.perf_counter() - t0) / a.steps * 1e3
-                work.defer_max_len = 4096
+                work.defer_max_len = int(os.environ.get("FASTKV_DEFER_MAX_LEN", "8192"))
                 out["deferred_all_layers"] = {"ms_per_step": round(ms_all, 4), "tokens_per_s": round(CFG["S"] / (ms_all * 1e-3), 1),
                                               "note": "FASTKV_DEFER_MAX_LEN=32768: every layer but the TSP layer waits for the end of the "
                                                       "forward pass (+2 GB of K/V held); not the default"}

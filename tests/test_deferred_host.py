@@ -150,22 +150,24 @@ def test_an_aborted_launch_is_raised_not_absorbed(rec, monkeypatch):
     assert ei.value.code == -3
 
 
-@pytest.mark.parametrize("layers,tsp_idx,want", [(32, 15, [8, 8, 8, 8]), (36, 17, [8, 8, 2, 8, 8, 2])])
-def test_published_recipe_schedule_and_state(rec, monkeypatch, layers, tsp_idx, want):
+@pytest.mark.parametrize("layers,tsp_idx,max_len,want", [(32, 15, 4096, [8, 8, 8, 8]), (36, 17, 4096, [8, 8, 2, 8, 8, 2]),
+                                                          (32, 15, 8192, [8, 8, 16]), (36, 17, 8192, [8, 8, 2, 18])])
+def test_published_recipe_schedule_and_state(rec, monkeypatch, layers, tsp_idx, max_len, want):
     """The reference's published recipe (/root/reference/scripts/eval_prefill.sh:4-12; scripts2/eval_prefill.sh:37-47 for the 36-layer
     Ministral-8B with TSP layer 17) at 32,768 tokens, host logic only: `compress_fastkv` pushes the rates (utils.py:25-46), every call
     rewrites `max_capacity_prompt` (3276 in front of and behind the TSP layer: int(32768 * 0.1) and int(6553 * 0.5)) and the TSP layer
     its `tsp_length` (6553) (utils.py:86-87, :123-124) -- and the 6553-token layers behind the TSP layer, longer than
-    FASTKV_DEFER_MAX_LEN, run as LONG layers in groups of eight like the ones in front of it (the constant budget never does that)."""
+    FASTKV_DEFER_MAX_LEN = 4096 (rounds 2-4), run as LONG layers in groups of eight like the ones in front of it (the constant budget
+    never does that); under the default of round 5 (8192) they wait for the end of the forward pass and run as ONE launch sequence."""
     import types
-    rec.max_entries = 16
+    rec.max_entries = 32
     S = 32768
     mods = [types.SimpleNamespace(self_attn=types.SimpleNamespace(kv_cluster=C.FastKVCluster())) for _ in range(layers)]
     model = types.SimpleNamespace(model=types.SimpleNamespace(layers=mods))
     args = types.SimpleNamespace(window_size=[8] * layers, kernel_size=[7] * layers, pooling="maxpool", max_capacity_prompts=512, tsp_len=2048,
                                  tsp_rate=0.2, eviction_mode="proportional", tsp_idx=tsp_idx, retain_rate=0.1)
     C.compress_fastkv(model, args)
-    d = C.DeferredCompression(max_len=4096, hold_long=8)
+    d = C.DeferredCompression(max_len=max_len, hold_long=8)
     done, s_now = {}, S
     for i, m in enumerate(mods):
         cl = m.self_attn.kv_cluster
@@ -203,3 +205,15 @@ def test_group_size_is_capped_by_the_bytes_the_waiting_layers_hold(monkeypatch):
     monkeypatch.setenv("FASTKV_DEFER_HOLD", "16")
     monkeypatch.setenv("FASTKV_DEFER_HOLD_GIB", "64")
     assert defer_hold_for(cfg, 1, 32768) == 16
+
+
+def test_the_end_of_pass_regime_is_capped_by_bytes_too(monkeypatch):
+    import types
+    from baselines.fastkv._wiring import defer_max_len_for
+    cfg = types.SimpleNamespace(num_attention_heads=32, num_key_value_heads=8, head_dim=128, hidden_size=4096, num_hidden_layers=32)
+    monkeypatch.delenv("FASTKV_DEFER_MAX_LEN", raising=False)
+    monkeypatch.delenv("FASTKV_DEFER_HOLD_GIB", raising=False)
+    assert defer_max_len_for(cfg, 1) == 8192                       # 32 layers x 8192 tokens x 12 KiB = 3.2 GB <= 4 GiB
+    assert defer_max_len_for(cfg, 2) == 5461                       # two batch rows: the regime shrinks instead of holding 6.4 GB
+    monkeypatch.setenv("FASTKV_DEFER_MAX_LEN", "4096")
+    assert defer_max_len_for(cfg, 1) == 4096
