@@ -118,9 +118,10 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     from benchmark import prefill
     from fastkv_amd import ops
 
-    def run(defer, slab="0", tsp_idx="0", S=3000, B=1, hold="8"):
+    def run(defer, slab="0", tsp_idx="0", S=3000, B=1, hold="8", max_len="8192"):
         monkeypatch.setenv("FASTKV_DEFER", defer)
         monkeypatch.setenv("FASTKV_DEFER_HOLD", hold)
+        monkeypatch.setenv("FASTKV_DEFER_MAX_LEN", max_len)
         monkeypatch.setenv("FASTKV_SLAB_CACHE", slab)
         a = prefill.parse_args(["--model_path", "llama3-8b", "--num_layers", "6", "--device", "cuda", "--save_txt", "", "--method",
                                 "fastkv", "--max_capacity_prompts", "512", "--tsp_len", "1024", "--tsp_idx", tsp_idx, "--pooling", "maxpool"])
@@ -149,14 +150,22 @@ def test_deferred_compression_of_the_post_tsp_layers_changes_nothing(monkeypatch
     assert torch.equal(l1, l0) and torch.equal(d1, d0) and len(c1) == len(c0) == 6
     for (k1, v1), (k0, v0) in zip(c1, c0):
         assert torch.equal(k1, k0) and torch.equal(v1, v0)
-    # FASTKV_DEFER_HOLD=2: long layers in front of the TSP layer wait for ONE peer: layers 0 and 1 of a 5000-token prompt run as a pair
-    # when layer 1 arrives, layer 2 waits and is taken along by the TSP layer (3), layers 4 and 5 behind it run together at the end
+    # FASTKV_DEFER_HOLD=2, FASTKV_DEFER_MAX_LEN=4096: long layers in front of the TSP layer wait for ONE peer: layers 0 and 1 of a
+    # 5000-token prompt run as a pair when layer 1 arrives, layer 2 waits and is taken along by the TSP layer (3), layers 4 and 5 behind it
+    # run together at the end
     del calls[:]
-    lp, dp, cp = run("1", tsp_idx="3", S=5000, hold="2")
+    lp, dp, cp = run("1", tsp_idx="3", S=5000, hold="2", max_len="4096")
     assert calls == [2, 2, 2]
     lq, dq, cq = run("0", tsp_idx="3", S=5000)
     assert calls == [2, 2, 2] and torch.equal(lp, lq) and torch.equal(dp, dq)
     for (k1, v1), (k0, v0) in zip(cp, cq):
+        assert torch.equal(k1, k0) and torch.equal(v1, v0)
+    # the default of round 5 (layers of up to 8192 tokens wait for the end of the pass, or for the TSP layer): the three layers in front of
+    # the TSP layer go along with it, the two behind it run at the end -- same caches, same logits
+    del calls[:]
+    lr, dr, cr = run("1", tsp_idx="3", S=5000)
+    assert calls == [4, 2] and torch.equal(lr, lq) and torch.equal(dr, dq)
+    for (k1, v1), (k0, v0) in zip(cr, cq):
         assert torch.equal(k1, k0) and torch.equal(v1, v0)
     del calls[:]
     # the default (groups of up to eight): layers 0-2 wait, the TSP layer (3) takes all three along (one call of four entries: the library
