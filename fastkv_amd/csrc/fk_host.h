@@ -39,7 +39,7 @@ struct Layout {
     int G, R, RB, passes, R_alloc;   // query rows per KV head (G*W), rows per pass, passes, padded rows
     int n, Sp, n_pad;                // candidates S-W, padded logits row stride, padded score row stride
     int ntA;                         // tiles of score_logits
-    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_fpart, off_fchain, off_fspill, off_idx, off_keys, total;
+    size_t off_qf, off_logits, off_gmax, off_rinv, off_c, off_t, off_hist, off_thist, off_arrive, off_seltab, off_fpart, off_fchain, off_idx, off_keys, total;
     int zero_words;                  // u32 words from off_hist that row_stats zeroes: histograms + arrival counters
 };
 
@@ -65,7 +65,6 @@ static inline int resolve_engine(const fastkv_problem &p)
     return e != ENGINE_AUTO ? e : default_contract_f16() ? ENGINE_MFMA16 : (R >= 24 ? ENGINE_MFMA : ENGINE_VALU);
 }
 
-bool conveyor_wanted();           // fused.hip: FASTKV_FUSED_CONVEYOR
 static inline Layout make_layout(const fastkv_problem &p)
 {
     Layout L;
@@ -102,10 +101,6 @@ static inline Layout make_layout(const fastkv_problem &p)
     L.off_thist = o;  o += (size_t)p.B * HIST12 * 4;                            // ... and of the TSP rows (adjacent: zeroed together)
     L.off_arrive = o; o += align_up((size_t)p.B * (p.Hkv + 1) * 4, 256);        // split select: arrival counter per score row (zeroed too)
     L.zero_words = (int)((o - L.off_hist) / 4);
-    // the conveyor of the fused scoring kernel (fused.hip): 512 workgroups x 3 entries x 64 KiB of packed logits between their phases --
-    // private to a workgroup, nothing token-tagged: it may lie behind the shape-dependent areas.  Only calls the conveyor can take.
-    L.off_fspill = 0;
-    if (conveyor_wanted() && p.B >= 3 && p.D == 128 && p.window == 8 && p.S >= 8192) { L.off_fspill = o; o += (size_t)512 * 3 * 65536; }
     L.off_idx = o;    o += align_up((size_t)p.B * p.Hkv * (size_t)(p.capacity > p.window ? p.capacity - p.window : 0) * 8, 256);
     L.off_keys = o;   // winners' 16-bit keys in ascending position, rows padded to a multiple of 8
     {

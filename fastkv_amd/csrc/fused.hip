@@ -87,12 +87,7 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
 // WPE = workgroups per compute unit (= waves per SIMD) the instantiation is built for: 2 (256 registers, 80 KiB of LDS per workgroup), or 3
 // (round 5: 168 registers, <= 53 KiB -- the two-tiles-per-wave size under the mfma16 contract, for the rolling launch: three workgroups
 // of a compute unit are then in three different phases)
-// CONV (round 5, "the conveyor": launch_score_fused): the workgroup is PERSISTENT over the entries of a group -- it owns one span of one
-// unit and, iteration after iteration, runs phase A of entry e, phase B of the entry it took through phase A ONE iteration earlier, phase
-// C of the one before that and phase D of the one before that.  Every hand-off record is then published a whole iteration (20-30 us)
-// before its readers ask for it: nobody waits.  The packed logits of the two entries between their phases A and C are parked in
-// a private area of the workspace (64 KiB per workgroup and entry, L2-resident), the exponentials are recomputed in phase C.
-template <int D, int PER, int NB, int NS, bool F16, int WPE, bool CONV>
+template <int D, int PER, int NB, int NS, bool F16, int WPE>
 __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -103,7 +98,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune, uint4 *__restrict__ spill)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
@@ -115,19 +110,16 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // four tiles per wave (two 32k layers per launch) the other two tiles park theirs in LDS -- the K slabs and the query
     // operand are dead by then -- as one float4 per lane and word pair (conflict-free ds_write_b128 / ds_read_b128).  Round 2
     // recomputed them instead (128 more registers do not fit): 13.2 us of phase C against 3.9 us (per-wave stamps, r03).
-    constexpr int E_REGS = CONV ? 0 : (PER < 4 ? PER : 2), E_LDS = CONV ? 0 : PER - E_REGS;    // (the conveyor recomputes them in phase C)
-    static_assert(!CONV || (NS == 1 && F16), "the conveyor: one stream, mfma16 contract");
+    constexpr int E_REGS = PER < 4 ? PER : 2, E_LDS = PER - E_REGS;
     constexpr int E_BYTES = 4 * E_LDS * 64 * 2 * NW * 4;          // 64 KiB (32 KiB with 32-key tiles) per workgroup when PER == 4
     // the window-row sums of phases C / D are fp16 values: kept as fp16 bits when the parked exponentials need the room
-    using tile_t = std::conditional_t<(E_LDS > 0 || CONV), uint16_t, float>;
+    using tile_t = std::conditional_t<(E_LDS > 0), uint16_t, float>;
     constexpr int TWG_ = 4 * PS * TK, TW_ = TWG_ + 64;            // 31 halo columns on either side; rows stay 8-B / 16-B aligned
     constexpr int HIST_BYTES = HIST12 * 4;
     // phases C / D: [parked exponentials | histogram (inside the exponentials' area once they are consumed, behind them when
     // there are none)] [window-row-sum tiles of the streams]
     constexpr int CD_HEAD = E_BYTES >= HIST_BYTES ? E_BYTES : (E_BYTES + NS * HIST_BYTES);
-    // (the conveyor: the window-row-sum tiles of TWO entries live beside the carved block -- phase D reads the tile phase C wrote one
-    // iteration earlier, across a phase A --, only the histogram shares it)
-    constexpr int CD_BYTES = CONV ? HIST_BYTES : CD_HEAD + NS * G * TW_ * (int)sizeof(tile_t);
+    constexpr int CD_BYTES = CD_HEAD + NS * G * TW_ * (int)sizeof(tile_t);
     constexpr int A_BYTES = SLAB_BYTES + NS * AS_FLOATS * 4;
     // one block of LDS, carved twice: phase A = the waves' K slabs + the fp32 query operand of every stream; phases B-D (all
     // of phase A is over by then, on every stream) = parked exponentials, the window-row-sum tiles, the key histograms
@@ -140,28 +132,15 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     __shared__ uint32_t s_rb[FUSED_PARTS][32];
     __shared__ float s_gm[NS][32], s_ri[NS][32];               // row maxima / reciprocal row sums of the streams' heads
     __shared__ uint32_t s_abort;
-    tile_t *conv_tiles = nullptr;
-    float (*conv_gm)[32] = nullptr;
-    uint32_t (*conv_tnan)[4] = nullptr;
-    if constexpr (CONV) {
-        __shared__ __attribute__((aligned(16))) tile_t s_conv_tiles[2 * G * TW_];   // [iteration parity][head][column]
-        __shared__ float s_conv_gm[4][32];                       // row maxima of the entries between their phases B and C
-        __shared__ uint32_t s_conv_tnan[4][4];                   // [entry slot][wave]: tiles whose contraction held a NaN
-        conv_tiles = s_conv_tiles; conv_gm = s_conv_gm; conv_tnan = s_conv_tnan;
-    }
     FKH_SHARED
-    // (not const: the conveyor's loop re-derives them from an opaque copy of the thread index in every iteration -- otherwise the compiler
-    // hoists every address and index the unrolled phases derive from it out of the loop and parks them in scratch: 836 B per lane)
-    unsigned tix = threadIdx.x;
-    int lane = tix & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tix >> 6);
+    const unsigned tix = threadIdx.x;
+    const int lane = tix & 63, w = __builtin_amdgcn_readfirstlane(tix >> 6);
     // Entries 1 .. F-1 of a rolling launch (launch_score_fused; `rolling` = F, the entries the chip holds at a time) start late ON
     // PURPOSE, one K-streaming time apart: entries that begin together stay in step -- all stream K, then all do arithmetic -- and
     // gain nothing from sharing the chip.
     // (WPE == 3: an entry is more workgroups than half of the chip's places; only the part of entry 1 that starts WITH entry 0 is held back,
     // the rest of it starts when places free up, which is late enough)
-    if (CONV) { if (start_delay > 0 && blockIdx.y > 0) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); } }   // (the second pipeline starts half an iteration late)
-    else if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling && (WPE == 2 || 2 * blockIdx.x < gridDim.x)) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
+    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling && (WPE == 2 || 2 * blockIdx.x < gridDim.x)) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
@@ -178,16 +157,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // or anything else) was measured to produce wrong row sums / window-row sums now and then (tools/repro_nan_mate.py; docs/HISTORY.md).
     // (a rolling launch may split a batch row's units over `parts` entries -- prompts so long that the units of one row do not fit
     // half of the chip: an entry is then UP / parts units of a row, the rows' parts follow each other in grid order)
-    const int UPE = (rolling && !CONV) ? UP / parts : UP;        // units per entry of this launch
+    const int UPE = rolling ? UP / parts : UP;                   // units per entry of this launch
     const int nblk = gridDim.x / UPE;
     int hvp, blk, yb, ent = 0, part_base = 0;
-    if (CONV) {
-        // the conveyor: `rolling` = the entries of the launch, blockIdx.y = the pipeline (0 / 1: the even / the odd entries); the workgroup
-        // owns span `blk` of unit `hvp` for every entry of its pipeline
-        ent = blockIdx.y;
-        yb = ent;
-        hvp = blockIdx.x / nblk; blk = blockIdx.x - hvp * nblk;
-    } else if (NS == 1 && !rolling && !FKH_OLD_NUMBERING) {      // (a rolling launch: entry = blockIdx.y, one workgroup per compute unit and entry)
+    if (NS == 1 && !rolling && !FKH_OLD_NUMBERING) {             // (a rolling launch: entry = blockIdx.y, one workgroup per compute unit and entry)
         const int T = gridDim.x * gridDim.y, p = blockIdx.y * gridDim.x + blockIdx.x, P = T > ncu ? T - ncu : 0;
         const int l = p >= ncu ? 2 * (p - ncu) + 1 : (p < P ? 2 * p : 2 * P + (p - P));     // logical index: unit-major, span fastest
         const int unit = l / nblk;
@@ -205,7 +178,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     } else {
         hvp = blockIdx.x % UP; blk = blockIdx.x / UP; yb = blockIdx.y;
     }
-    int b = yb + b0;
+    const int b = yb + b0;
     if (place && tix == 0) {
         uint32_t *pl = place + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;
         pl[0] = __builtin_amdgcn_s_getreg(63492);                  // HW_ID (all 32 bits)
@@ -224,7 +197,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         bg_s[s] = b * Hkv + g_s[s];
         // hand-off records are per virtual head of THIS launch (a rolling launch: of the 2 F entries that can be on the chip or
         // about to be; the entry's own token tells its records from those of entry - 2 F)
-        bgv_s[s] = CONV ? (ent % 8) * UPE + hv : rolling ? (ent % (2 * rolling)) * UPE + (hv - part_base) : (yb * Hkv + g_s[s]) * VH + vh_s[s];
+        bgv_s[s] = rolling ? (ent % (2 * rolling)) * UPE + (hv - part_base) : (yb * Hkv + g_s[s]) * VH + vh_s[s];
         kb_s[s] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[s] * ks_h;   // (per-entry base: fk_host.h PtrTables)
     }
     const int n = S - W;
@@ -232,7 +205,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     const int wave_id = blk * 4 + w;
     unsigned char *my = smem + w * (64 * ROWB);
     float *As = reinterpret_cast<float *>(smem + SLAB_BYTES);  // [NS][AS_FLOATS]
-    int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
+    const int n31 = lane & 31, hi = lane >> 5, sh = hi * 16;
 
     // tile t of the wave (0 .. PER-1): stream t / PS, tile wt(t) of that stream's row of tiles (contiguous keys per workgroup)
     auto tile_wt = [&](int t) { return wave_id * PS + (t % PS); };
@@ -242,7 +215,6 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // ---------------------------------------------------------------- A operands (see score_logits_mfma_kernel)
     constexpr int QV = 32 * (D / 8) / 256;
     uint4 qv[NS][QV];
-    if constexpr (!CONV)                                         // (the conveyor: per entry, in its loop)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -257,7 +229,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                               : make_uint4(0u, 0u, 0u, 0u);
         }
     KStage sA, sB;
-    if constexpr (!CONV) k_fetch<NB>(sA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
+    k_fetch<NB>(sA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
     // (the control block is read only now: its round trip hides behind the query / first-tile loads issued above instead of
     // standing in front of them)
@@ -273,8 +245,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     }
     // (sub 0: the operator call's token, shared with the selection; the epoch advances by EPOCH_STRIDE per call, sub < EPOCH_STRIDE:
     // the tokens of all launches are distinct values of one bijective mix)
-    uint32_t token = handoff_token(ctrl[2] + sub + (rolling ? (uint32_t)ent : 0u));
-    SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
+    const uint32_t token = handoff_token(ctrl[2] + sub + (rolling ? (uint32_t)ent : 0u));
+    const SpinCtl sp = make_spin(ctrl, host_flag, token, spin_ticks);
     if (tix == 0) s_abort = 0;
     // Placement check.  The pairing above ASSUMES which workgroups share a compute unit; this notices when the assumption did not hold:
     // every workgroup swaps {token, its unit} into the slot of the compute unit it runs on (one returning atomic, asked for now, looked
@@ -294,7 +266,6 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
     // is published, so passing the first hand-off implies the row is clean.  The TSP histograms and the arrival counters of
     // the selection are touched by later kernels only.
-    if constexpr (!CONV)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         if (vh_s[s] == VH - 1) {                               // the group that fills the histogram in phase D
@@ -310,7 +281,6 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         for (int i = lo + (int)tix; i < hi2; i += 256) zero_area[first + i] = 0;
     }
 
-    if constexpr (!CONV)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -331,10 +301,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         }
     __syncthreads();
     FKF_STAMP(16);
-    if constexpr (!CONV) {
-        if (NPH >= 2) k_fetch<NB>(sB, kb_s[0], ks_s, tile_key0(0), S, 1, lane);
-        else if (tile_valid(1)) k_fetch<NB>(sB, kb_s[(1 / PS) % NS], ks_s, tile_key0(1), S, 0, lane);
-    }
+    if (NPH >= 2) k_fetch<NB>(sB, kb_s[0], ks_s, tile_key0(0), S, 1, lane);
+    else if (tile_valid(1)) k_fetch<NB>(sB, kb_s[(1 / PS) % NS], ks_s, tile_key0(1), S, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 
     // lg[t][i]: a packed pair of scaled + masked fp16 logits.  NB == 2: query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns
@@ -343,18 +311,14 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][NW];
-    float ev[E_REGS ? E_REGS : 1][2][NW];
+    float ev[E_REGS][2][NW];
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
     f32x4_ *ebuf = reinterpret_cast<f32x4_ *>(smem) + (size_t)w * E_LDS * (NW / 2) * 64 + lane;   // [tile][word pair][lane] of this wave
     uint32_t tile_nan = 0;                                       // bit t: tile t's contraction held a NaN (wave-uniform)
 
     // ================================================================ phase A of stream s: logits of its tiles, row maxima,
     // publication of the workgroup's 32 partial maxima as {token, value} granules
-    // (the phases take the K stages / the packed logits / the NaN bits they work on as PARAMETERS -- the regular launches pass the variables
-    // above; the conveyor passes objects whose scope is one iteration of its loop: a stage or a logits array that is carried around the
-    // loop through a by-reference capture is not promoted to registers -- every access becomes a scratch access behind s_waitcnt vmcnt(0),
-    // which also drains the K prefetch pipeline: phase A ran 5x slower that way)
-    auto phaseA = [&](auto sc, KStage &sA, KStage &sB, uint32_t (&lg)[PER][NW], uint32_t &tile_nan) {
+    auto phaseA = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         float mx[16];                                            // mx[r] = running maximum of row m(r) over this lane's columns
         uint32_t mx16[NW];                                       // the same for full tiles, as packed fp16 pairs
@@ -528,7 +492,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 
     // ================================================================ phase B of stream s: e = exp(x - max), fixed-point row
     // sums, publication of the workgroup's 32 partial sums (two granules each)
-    auto phaseB = [&](auto sc, uint32_t (&lg)[PER][NW], const uint32_t tile_nan) {
+    auto phaseB = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         float gm[16];
 #pragma unroll
@@ -540,8 +504,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         const bool gm_finite = __all(gm_ok);                         // wave-uniform: +-inf or NaN row maxima send every tile the general way
         f32x2 epair = {0.0f, 0.0f};                                  // the even word's exponentials, until the odd word's join them
         auto keep = [&](int t, int i, f32x2 e) {                     // t, i: compile-time after unrolling
-            if (CONV) { (void)epair; }                               // (the conveyor recomputes the exponentials in phase C)
-            else if (t < E_REGS) { ev[t < E_REGS ? t : 0][0][i] = e.x; ev[t < E_REGS ? t : 0][1][i] = e.y; }
+            if (t < E_REGS) { ev[t < E_REGS ? t : 0][0][i] = e.x; ev[t < E_REGS ? t : 0][1][i] = e.y; }
             else if (i & 1) ebuf[((t - E_REGS) * (NW / 2) + (i >> 1)) * 64] = (f32x4_){epair.x, epair.y, e.x, e.y};
             else epair = e;
         };
@@ -681,33 +644,19 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     const bool avg = pooling == FASTKV_POOL_AVG;
     const float padv = avg ? 0.0f : -INFINITY;
     const bool want_hist = all_idx == nullptr;
-    int conv_par = 0;                                            // (conveyor) which of the two tile buffers the current phase works on
-    auto tile_of = [&](int s) {
-        if constexpr (CONV) return reinterpret_cast<tile_t(*)[TW]>(conv_tiles + (size_t)conv_par * G * TW);
-        else return reinterpret_cast<tile_t(*)[TW]>(smem + CD_HEAD + (size_t)s * G * TW * sizeof(tile_t));
-    };
-    auto hist_of = [&](int s) { return reinterpret_cast<uint32_t *>(smem + ((E_BYTES >= HIST_BYTES || CONV) ? 0 : E_BYTES) + (size_t)s * HIST_BYTES); };
+    auto tile_of = [&](int s) { return reinterpret_cast<tile_t(*)[TW]>(smem + CD_HEAD + (size_t)s * G * TW * sizeof(tile_t)); };
+    auto hist_of = [&](int s) { return reinterpret_cast<uint32_t *>(smem + (E_BYTES >= HIST_BYTES ? 0 : E_BYTES) + (size_t)s * HIST_BYTES); };
     // a tile element: an fp16-valued number (or the pooling pad value: 0 / -inf), stored as float or as its fp16 bits
     auto tl_put = [](tile_t &dst, float v) { if constexpr (std::is_same<tile_t, float>::value) dst = v; else dst = f2h(v); };
     auto tl_get = [](const tile_t &src) -> float { if constexpr (std::is_same<tile_t, float>::value) return src; else return h2f(src); };
 
-    auto phaseC = [&](auto sc, uint32_t (&lg)[PER][NW], const uint32_t tile_nan) {
+    auto phaseC = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         tile_t(*tile)[TW] = tile_of(s);
         uint32_t *s_hist = hist_of(s);
         float ri[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) ri[i] = s_ri[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
-        // (conveyor: the exponentials are recomputed from the packed logits and the head's row maxima -- the same function of the same
-        // operands as in phase B, chosen by the same conditions: the same bits)
-        float gmc[16];
-        bool gmc_finite = true;
-        if constexpr (CONV) {
-            bool ok_ = true;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { gmc[i] = s_gm[s][(i & 3) + 8 * (i >> 2) + 4 * hi]; ok_ = ok_ && __builtin_fabsf(gmc[i]) < INFINITY; }
-            gmc_finite = __all(ok_);
-        }
         FKF_STAMP(29);
 #pragma unroll
         for (int lt = 0; lt < PS; ++lt) {
@@ -720,7 +669,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                 // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
                 f32x2 p[4];
                 f32x4_ parked[2];                                 // this step's four words of a tile whose exponentials wait in LDS
-                if (!CONV && t >= E_REGS) {
+                if (t >= E_REGS) {
                     parked[0] = ebuf[((t - E_REGS) * (NW / 2) + 2 * i4) * 64];
                     parked[1] = ebuf[((t - E_REGS) * (NW / 2) + 2 * i4 + 1) * 64];
                 }
@@ -728,11 +677,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                 for (int u = 0; u < 4; ++u) {
                     const int wd = 4 * i4 + u, rB = NB == 2 ? wd : (wd + 8) & 15;
                     f32x2 ee;
-                    if constexpr (CONV) {
-                        const f32x2 x = {h2f((uint16_t)(lg[t][wd] & 0xffffu)), h2f((uint16_t)(lg[t][wd] >> 16))};
-                        const bool fast = tile_wt(t) * TK + TK <= S && !((tile_nan >> t) & 1u) && gmc_finite;     // (phase B's condition)
-                        ee = fast ? det_expf2_clamped(x - (f32x2){gmc[wd], gmc[rB]}) : det_expf2(x - (f32x2){gmc[wd], gmc[rB]});
-                    } else if (t < E_REGS) ee = (f32x2){ev[t < E_REGS ? t : 0][0][wd], ev[t < E_REGS ? t : 0][1][wd]};
+                    if (t < E_REGS) ee = (f32x2){ev[t < E_REGS ? t : 0][0][wd], ev[t < E_REGS ? t : 0][1][wd]};
                     else ee = (u & 1) ? (f32x2){parked[u >> 1].z, parked[u >> 1].w} : (f32x2){parked[u >> 1].x, parked[u >> 1].y};
                     const f32x2 pr = ee * (f32x2){ri[wd], ri[rB]};
                     const uint32_t ph = f2h2(pr.x, pr.y);                                 // utils.py:103 -> fp16
@@ -759,7 +704,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         __syncthreads();
         // (the histogram may lie where the parked exponentials were: cleared only now that every wave has consumed them; phase D,
         // its first user, starts behind the barrier of read_halo)
-        if (!CONV && want_hist) for (int i = tix; i < HIST12; i += 256) s_hist[i] = 0;     // (conveyor: cleared in front of phase D, see the loop)
+        if (want_hist) for (int i = tix; i < HIST12; i += 256) s_hist[i] = 0;
         // halo: pooling reaches `pad` positions into the neighbouring workgroups of the head.  Every workgroup publishes its
         // first and last pad values per head as 8-byte {token, value} granules (one write-through store each: the data is the flag)
         uint64_t *eg = edges + ((size_t)bgv_s[s] * nblk + blk) * (2 * G * PADMAX);
@@ -973,143 +918,23 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NS - 1>;            // (== S0 when NS == 1: the second calls below are compiled out)
-    if constexpr (CONV) {
-        // ---------------------------------------------------------------- the conveyor: this workgroup's span of its unit, entry after entry
-        const int E = rolling, pl = (int)blockIdx.y;
-        const size_t wgl = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        constexpr int QUADS = PER * NW / 4;                      // 16-B pieces of a thread's packed logits of one entry
-        uint4 *my_spill = spill + wgl * (3 * QUADS * 256) + tix; // [slot][quad][thread] (re-derived per iteration)
-        auto set_entry = [&](int e) {
-            ent = e;
-            b = e + b0;
-            bg_s[0] = b * Hkv + g_s[0];
-            bgv_s[0] = (e % 8) * UPE + hvp;
-            kb_s[0] = (k_tab ? reinterpret_cast<const uint16_t *>(k_tab[b]) : k + b * ks_b) + (int64_t)g_s[0] * ks_h;
-            token = handoff_token(ctrl[2] + sub + (uint32_t)e);
-            sp = make_spin(ctrl, host_flag, token, spin_ticks);
-        };
-        auto park_logits = [&](int slot, const uint32_t (&x)[PER][NW]) {
-            uint4 *dst = my_spill + (size_t)slot * QUADS * 256;
-#pragma unroll
-            for (int qd = 0; qd < QUADS; ++qd) {
-                const int f = 4 * qd;
-                dst[(size_t)qd * 256] = make_uint4(x[f / NW][f % NW], x[(f + 1) / NW][(f + 1) % NW], x[(f + 2) / NW][(f + 2) % NW], x[(f + 3) / NW][(f + 3) % NW]);
-            }
-        };
-        auto fetch_logits = [&](int slot, uint32_t (&x)[PER][NW]) {
-            const uint4 *src = my_spill + (size_t)slot * QUADS * 256;
-            uint4 v4[QUADS];
-#pragma unroll
-            for (int qd = 0; qd < QUADS; ++qd) v4[qd] = src[(size_t)qd * 256];
-#pragma unroll
-            for (int qd = 0; qd < QUADS; ++qd) {
-                const int f = 4 * qd;
-                x[f / NW][f % NW] = v4[qd].x; x[(f + 1) / NW][(f + 1) % NW] = v4[qd].y; x[(f + 2) / NW][(f + 2) % NW] = v4[qd].z; x[(f + 3) / NW][(f + 3) % NW] = v4[qd].w;
-            }
-        };
-        // what the regular launches do once in front of phase A, per entry: the query block into LDS, the first K requests, the entry's
-        // histogram rows cleared (drained before the entry's first record is published: phase A)
-        auto prep_entry = [&](int e, KStage &stA, KStage &stB) {
-            set_entry(e);
-            uint4 qq[QV];
-#pragma unroll
-            for (int u = 0; u < QV; ++u) {
-                const int item = u * 256 + tix, rowl = item / (D / 8), ch = item - rowl * (D / 8);
-                const int i = rowl / W, r = rowl - i * W;
-                const int qh = g_s[0] * (HV < G ? HV : G * VH) + vh_s[0] * G + i;
-                qq[u] = i < HV ? *reinterpret_cast<const uint4 *>((q_tab ? reinterpret_cast<const uint16_t *>(q_tab[b]) : q + b * qs_b) +
-                                                                  (int64_t)qh * qs_h + (int64_t)(n + r) * qs_s + ch * 8)
-                               : make_uint4(0u, 0u, 0u, 0u);
-            }
-            k_fetch<NB>(stA, kb_s[0], ks_s, tile_key0(0), S, 0, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            if (vh_s[0] == VH - 1) {
-                uint32_t *hist_row = zero_area + (size_t)bg_s[0] * HIST12;
-                for (int i = blk * 256 + (int)tix; i < HIST12; i += nblk * 256)
-                    __hip_atomic_store(hist_row + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int u = 0; u < QV; ++u) {
-                const int item = u * 256 + tix, rowl = item / (D / 8), ch = item - rowl * (D / 8);
-                reinterpret_cast<uint4 *>(As)[((ch >> 1) * 64) + (ch & 1) * 32 + rowl] = qq[u];
-            }
-            __syncthreads();
-            if (NPH >= 2) k_fetch<NB>(stB, kb_s[0], ks_s, tile_key0(0), S, 1, lane);
-            else if (tile_valid(1)) k_fetch<NB>(stB, kb_s[0], ks_s, tile_key0(1), S, 0, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        const int n_it = (E - pl + 1) / 2 + 3;
-        // (no unrolling, no unswitching: the body is four phases of ~10k instructions each; the loop counter is made opaque so that the
-        // compiler keeps ONE copy of every phase)
-#pragma clang loop unroll(disable)
-        for (int it_ = 0; it_ < n_it; ++it_) {
-            int it = it_;
-            asm volatile("" : "+s"(it));
-            {
-                unsigned t_ = threadIdx.x;
-                asm volatile("" : "+v"(t_));
-                tix = t_; lane = tix & 63; n31 = lane & 31; hi = lane >> 5; sh = hi * 16;
-                my_spill = spill + wgl * (3 * QUADS * 256) + tix;
-            }
-            const int eA = pl + 2 * it, eB = eA - 2, eC = eA - 4, eD = eA - 6;
-            if (eA < E) {                                        // ---- phase A of entry eA
-                KStage stA, stB;
-                uint32_t lgA[PER][NW];
-                uint32_t nanA = 0;
-                prep_entry(eA, stA, stB);
-                if (tune & 1) __builtin_amdgcn_s_setprio(3);
-                phaseA(S0{}, stA, stB, lgA, nanA);
-                if (tune & 1) __builtin_amdgcn_s_setprio(0);
-                if (!(tune & 2)) park_logits(it % 3, lgA);
-                if (lane == 0) conv_tnan[it & 3][w] = nanA;
-            }
-            if (eB >= 0 && eB < E && !(tune & 32)) {             // ---- phase B of the entry that went through phase A one iteration ago
-                set_entry(eB);
-                if (!(tune & 4)) { if (!read_max(S0{})) return false; }
-                if (tix < 32) conv_gm[(it - 1) & 3][tix] = s_gm[0][tix];
-                uint32_t lgB[PER][NW];
-                if (!(tune & 2)) fetch_logits((it - 1) % 3, lgB); else { for (int t9 = 0; t9 < PER; ++t9) for (int i9 = 0; i9 < NW; ++i9) lgB[t9][i9] = 0x30003000u + tix; }
-                phaseB(S0{}, lgB, conv_tnan[(it - 1) & 3][w]);
-            }
-            if (eC >= 0 && eC < E && !(tune & 8)) {              // ---- phase C of the one before
-                set_entry(eC);
-                if (!(tune & 4)) { if (!read_sum(S0{})) return false; }
-                if (tix < 32) s_gm[0][tix] = conv_gm[(it - 2) & 3][tix];
-                __syncthreads();
-                uint32_t lgC[PER][NW];
-                if (!(tune & 2)) fetch_logits((it - 2) % 3, lgC); else { for (int t9 = 0; t9 < PER; ++t9) for (int i9 = 0; i9 < NW; ++i9) lgC[t9][i9] = 0x30003000u + tix; }
-                conv_par = it & 1;
-                phaseC(S0{}, lgC, conv_tnan[(it - 2) & 3][w]);
-            }
-            if (eD >= 0 && eD < E && !(tune & 16)) {             // ---- phase D of the one before that (its tile was written one iteration ago)
-                set_entry(eD);
-                conv_par = (it - 1) & 1;
-                if (!(tune & 4)) { if (!read_halo(S0{})) return false; }
-                if (want_hist) { uint32_t *s_hist = hist_of(0); for (int i = tix; i < HIST12; i += 256) s_hist[i] = 0; }
-                __syncthreads();
-                phaseD_any(S0{});
-            }
-            __syncthreads();                                     // (the histogram shares LDS with the K slabs of the next phase A)
-        }
-        return true;
-    }
     if (tune & 1) __builtin_amdgcn_s_setprio(3);
-    phaseA(S0{}, sA, sB, lg, tile_nan);
+    phaseA(S0{});
     if (tune & 1) __builtin_amdgcn_s_setprio(0);
     FKF_STAMP(1);
-    if (NS == 2) phaseA(S1{}, sA, sB, lg, tile_nan);
+    if (NS == 2) phaseA(S1{});
     FKF_STAMP(2);
     if (!read_max(S0{})) return false;
     FKF_STAMP(3);
-    phaseB(S0{}, lg, tile_nan);
+    phaseB(S0{});
     FKF_STAMP(4);
-    if (NS == 2) { if (!read_max(S1{})) return false; FKF_STAMP(5); phaseB(S1{}, lg, tile_nan); }
+    if (NS == 2) { if (!read_max(S1{})) return false; FKF_STAMP(5); phaseB(S1{}); }
     FKF_STAMP(6);
     if (!read_sum(S0{})) return false;
     FKF_STAMP(7);
-    phaseC(S0{}, lg, tile_nan);
+    phaseC(S0{});
     FKF_STAMP(8);
-    if (NS == 2) { if (!read_sum(S1{})) return false; FKF_STAMP(9); phaseC(S1{}, lg, tile_nan); }
+    if (NS == 2) { if (!read_sum(S1{})) return false; FKF_STAMP(9); phaseC(S1{}); }
     FKF_STAMP(10);
     if (!read_halo(S0{})) return false;
     FKF_STAMP(11);
@@ -1127,7 +952,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 // paid once per launch: bit-exact, and no faster than one launch per sub-batch (0.822 vs 0.825 ms per step) once both used the same
 // register allocation; the loop needs the thread index laundered through an opaque move or everything derived from it is hoisted
 // and spilled.  Dropped: separate launches are simpler and cannot reuse a hand-off record too early.)
-template <int D, int PER, int NB, int NS, bool F16, int WPE = 2, bool CONV = false>
+template <int D, int PER, int NB, int NS, bool F16, int WPE = 2>
 __global__ void __launch_bounds__(256, WPE) score_fused_kernel(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
                                                              int H, int Hkv, int S, float sqrtD, float rsqrtD,
@@ -1138,11 +963,11 @@ __global__ void __launch_bounds__(256, WPE) score_fused_kernel(const uint16_t *_
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune, uint4 *__restrict__ spill)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune)
 {
-    (void)score_fused_body<D, PER, NB, NS, F16, WPE, CONV>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
+    (void)score_fused_body<D, PER, NB, NS, F16, WPE>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts, tune, spill);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts, tune);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1221,13 +1046,6 @@ static int fused_tune()
 }
 
 // the rolling launch (launch_score_fused) is on unless FASTKV_FUSED_ROLLING=0 / fastkv_set_fused_rolling(0)
-}  // namespace fk
-bool fk::conveyor_wanted()
-{
-    static const bool on = []() { const char *e = getenv("FASTKV_FUSED_CONVEYOR"); return e && atoi(e) > 0; }();
-    return on;
-}
-namespace fk {
 static std::atomic<int> &rolling_flag()
 {
     static std::atomic<int> f{[]() { const char *e = getenv("FASTKV_FUSED_ROLLING"); return (e && e[0] == '0') ? 0 : 1; }()};
@@ -1378,50 +1196,6 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         // Prompts whose rows do not fit half of the chip even then (beyond 32k tokens at 8 KV heads) are split: an entry is 1 / parts of a
         // row's units (4 heads at 64k, 2 at 128k, 1 at 256k), the parts of a row follow each other like entries do -- the units of a row
         // share nothing but the row's inputs.  (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
-        // ---- Round 5: the CONVEYOR (score_fused_body<..., CONV = true>).  The rolling launch below keeps two entries on the chip out of step,
-        // but every workgroup still WAITS twice per entry for its head's other workgroups (row maxima, row sums: 5 us each, a quarter of
-        // an entry's life on the chip).  Here the 512 resident workgroups are persistent: workgroup (span, pipeline) takes the even / the
-        // odd entries of the group through its span one after the other and runs, per iteration, phase A of entry e, phase B of e - 2,
-        // phase C of e - 4, phase D of e - 6 -- every record it asks for was published a whole iteration earlier.  Between their phases
-        // the packed logits of two entries are parked in the workspace (L2), the exponentials are recomputed.  Same arithmetic, same bits.
-        {
-            static const int conv_env = []() { const char *e = getenv("FASTKV_FUSED_CONVEYOR"); return e ? atoi(e) : 0; }();
-            FusedPlan pc;
-            const bool plan_ok = conv_env && rolling_on && f16 && VH == 1 && p.D == 128 && !all_idx && p.B >= 3 && p.B <= EPOCH_STRIDE && L.off_fspill &&
-                                 fused_plan_for(p, UH, 1, 1, pc, f16, 256) && pc.PERT == 4 && pc.NBV == 2 && pc.nblk * UH <= 256 &&
-                                 (size_t)8 * UH * pc.nblk <= FUSED_MAX_WGS;
-            if (plan_ok) {
-                bool res = false;
-                {
-                    struct Info { int wgs_per_cu, cus; };
-                    static const Info info = []() {
-                        Info r = {0, 0};
-                        int dev = 0, nb = 0;
-                        hipDeviceProp_t prop;
-                        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(score_fused_kernel<128, 4, 2, 1, true, 2, true>), 256, 0) == hipSuccess) {
-                            r.wgs_per_cu = nb;
-                            r.cus = prop.multiProcessorCount;
-                        }
-                        return r;
-                    }();
-                    res = info.wgs_per_cu >= 2 && 2 * pc.nblk * UH <= 2 * info.cus;
-                }
-                if (res) {
-                    const dim3 grid(pc.nblk * UH, 2);
-                    ProfScope ps_(K_FUSED, st);
-                    // the second pipeline starts half an iteration behind the first (an iteration ~ the K streaming + the vector work of an entry)
-                    const int delay = conv_env >= 2 ? (conv_env - 1) * 100 : stagger_ticks;
-                    hipLaunchKernelGGL((score_fused_kernel<128, 4, 2, 1, true, 2, true>), grid, dim3(256), 0, st, (const uint16_t *)k, ks[0], ks[1], ks[2],
-                                       (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv, p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero,
-                                       L.zero_words, p.kernel, p.pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                       spin_ticks, pt ? pt->q : nullptr, pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr,
-                                       (uint64_t *)nullptr, p.B, delay, 1, fused_tune(), reinterpret_cast<uint4 *>(ws + L.off_fspill));
-                    *err = hipGetLastError();
-                    return true;
-                }
-            }
-        }
         // ---- Round 5: THREE workgroups per compute unit (FASTKV_FUSED_OCC3, csrc/fused.hip score_fused_kernel<..., WPE = 3>).  The launch
         // above holds two entries of four tiles per wave: two waves per SIMD, each of which spends half of its life waiting for a hand-off
         // (profiles/r04d_pmc_mfma_summary.json: SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.49, 26 % vector issue, 34 % of HBM).  With two tiles per wave
@@ -1442,7 +1216,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                                          p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                          c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
                                          pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr, (uint64_t *)nullptr, 2,
-                                         occ3_env >= 2 ? stagger_ticks * (occ3_env - 1) / 4 : 0, 1, fused_tune(), (uint4 *)nullptr);
+                                         occ3_env >= 2 ? stagger_ticks * (occ3_env - 1) / 4 : 0, 1, fused_tune());
                 }, 3);
                 *err = hipGetLastError();
                 return true;
@@ -1459,7 +1233,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts * 2 / F, parts, fused_tune(), (uint4 *)nullptr);     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts * 2 / F, parts, fused_tune());     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
             });
             *err = hipGetLastError();
             return true;
@@ -1478,7 +1252,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, 0, 0, 1, 0, (uint4 *)nullptr);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, 0, 0, 1, 0);
         });
         *err = hipGetLastError();
         b0 += take;
