@@ -636,6 +636,10 @@ hipError_t launch_select(const uint16_t *scores, int64_t rows, int64_t row_strid
                            reinterpret_cast<uint64_t *>(table), ctrl, host_flag, (uint64_t)0, (int)rows, fd);
         return hipGetLastError();
     }
+    // (a caller that asked for the TSP row sums to ride along checked select_takes_split first; if the library's mode changed in between
+    // -- another thread's fail-safe switch to the no-wait kernels on a row too long for the wait-free selection -- the row sums would
+    // silently not be computed: refuse instead, loudly)
+    if (fold) return hipErrorInvalidValue;
     const int64_t kal = (k + 7) & ~(int64_t)7;
     const int list_in_lds = kal <= 16384 ? 1 : 0;                      // 96 KiB of dynamic LDS at most
     const size_t dyn = list_in_lds ? (size_t)kal * 6 : 0;

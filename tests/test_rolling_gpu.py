@@ -345,3 +345,43 @@ def test_a_slice_of_the_rolling_soak():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_rolling.py"), "20", "5"], cwd=root, env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "0 mismatches / reports" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+_SWITCH_CHILD = """
+import hashlib, sys, torch
+from fastkv_amd import ops
+from fastkv_amd._lib import raise_if_aborted
+dev = torch.device('cuda:0')
+B, H, Hkv, S, D = 5, 32, 8, 32768, 128
+g = torch.Generator(device=dev).manual_seed(4242)
+q = torch.randn(B, S, H, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+k = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+v = torch.randn(B, S, Hkv, D, generator=g, device=dev, dtype=torch.float16).transpose(1, 2)
+k[1, 3, 777] = float('nan'); q[2, 9, S - 2] = float('inf')
+out = ops.update_kv(q, k, v, 8, 7, 'maxpool', 2048, 2048, 'score', return_indices=True, return_scores=True)
+torch.cuda.synchronize()
+raise_if_aborted('switch child')
+h = hashlib.sha256()
+for t in out:
+    h.update(t.cpu().contiguous().view(torch.uint8).numpy().tobytes())
+print('DIGEST', h.hexdigest())
+"""
+
+
+def test_the_measurement_switches_of_round_5_change_nothing():
+    """The opt-in paths round 5 left in the library -- FASTKV_FUSED_OCC3=1 (the rolling launch with three workgroups of two tiles per
+    wave on a compute unit), FASTKV_FUSED_TUNE=1 (raised issue priority while a wave streams K), FASTKV_TSP_FOLD=0 (the TSP row sums
+    as a launch of their own again) -- give the operator's outputs bit for bit (five 32k entries, a NaN key and an Inf query among them:
+    K / V rows, TSP index, per-head indices, scores)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for name, extra in (("default", {}), ("occ3", {"FASTKV_FUSED_OCC3": "1"}), ("occ3_staggered", {"FASTKV_FUSED_OCC3": "3"}),
+                        ("setprio", {"FASTKV_FUSED_TUNE": "1"}), ("no_fold", {"FASTKV_TSP_FOLD": "0"}), ("no_rolling", {"FASTKV_FUSED_ROLLING": "0"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, (name, r.stdout[-800:] + r.stderr[-1500:])
+        digests[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    assert len(set(digests.values())) == 1, digests
