@@ -207,12 +207,19 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
     ProfScope ps_(K_COMPACT, st);
     const size_t kal = ((size_t)(p.capacity - p.window) + 7) & ~(size_t)7;
     int keys_in_lds = (keys && kal <= 16384) ? 1 : 0;                      // 32 KiB of LDS at most
-    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 8704) {
-        // many heads: every head's key list becomes its slot list (workspace memory of this call).  LDS: 12 bytes per bin + 6 per winner
-        // <= 64 KiB: 4096 bins up to 2688 winners, 2048 up to 6656, 1024 up to 8704; longer lists keep the counting inside the copy
+    if (keys && (int64_t)p.B * p.Hkv >= 64 && kal <= 24000) {
+        // many heads: every head's key list becomes its slot list (workspace memory of this call).  LDS: 12 bytes per bin + 6 per winner:
+        // 4096 bins up to 2688 winners, 2048 up to 6656 (both within the default 64 KiB), 1024 bins up to 24,000 winners (156 KiB: the
+        // published recipe keeps 13,107 rows per head at 128k -- counting those inside the copy kernel cost 0.5 ms per eight layers);
+        // longer lists keep the counting inside the copy
         const int kk_ = p.capacity - p.window;
         const int bpt = kal <= 2688 ? 4 : kal <= 6656 ? 2 : 1;
         const size_t lds = (size_t)3 * 1024 * bpt * 4 + kal * 4 + kal * 2;
+        if (lds > 64 * 1024 - 256) {
+            static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_group_kernel<1>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
+            (void)big_lds;
+        }
         const dim3 rg((unsigned)(p.B * p.Hkv));
         if (bpt == 4) hipLaunchKernelGGL(rank_group_kernel<4>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
         else if (bpt == 2) hipLaunchKernelGGL(rank_group_kernel<2>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);

@@ -1037,11 +1037,12 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
     return false;
 }
 
-// measurement switch of the rolling launch (FASTKV_FUSED_TUNE, bits): 1 = the waves of an entry run phase A (K streaming) at raised
-// issue priority (s_setprio 3), so that their loads / LDS commits are never queued behind the other entry's vector work
+// switch of the rolling launch (FASTKV_FUSED_TUNE, bits; default 1): 1 = the waves of an entry run phase A (K streaming) at raised
+// issue priority (s_setprio 3), so that their loads / LDS commits are never queued behind the other entry's vector work -- measured in
+// round 5 at -3 ... -5 us per eight-layer launch (203.7 / 206.0 / 204.5 -> 200.7 / 201.1 / 201.7 us, alternating runs on one box)
 static int fused_tune()
 {
-    static const int t = []() { const char *e = getenv("FASTKV_FUSED_TUNE"); return e ? atoi(e) : 0; }();
+    static const int t = []() { const char *e = getenv("FASTKV_FUSED_TUNE"); return e ? atoi(e) : 1; }();
     return t;
 }
 

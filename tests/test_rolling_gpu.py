@@ -370,7 +370,7 @@ print('DIGEST', h.hexdigest())
 
 def test_the_measurement_switches_of_round_5_change_nothing():
     """The opt-in paths round 5 left in the library -- FASTKV_FUSED_OCC3=1 (the rolling launch with three workgroups of two tiles per
-    wave on a compute unit), FASTKV_FUSED_TUNE=1 (raised issue priority while a wave streams K), FASTKV_TSP_FOLD=0 (the TSP row sums
+    wave on a compute unit), FASTKV_FUSED_TUNE=0 (no raised issue priority while a wave streams K: the default since round 5 is 1), FASTKV_TSP_FOLD=0 (the TSP row sums
     as a launch of their own again) -- give the operator's outputs bit for bit (five 32k entries, a NaN key and an Inf query among them:
     K / V rows, TSP index, per-head indices, scores)."""
     import os
@@ -379,7 +379,7 @@ def test_the_measurement_switches_of_round_5_change_nothing():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for name, extra in (("default", {}), ("occ3", {"FASTKV_FUSED_OCC3": "1"}), ("occ3_staggered", {"FASTKV_FUSED_OCC3": "3"}),
-                        ("setprio", {"FASTKV_FUSED_TUNE": "1"}), ("no_fold", {"FASTKV_TSP_FOLD": "0"}), ("no_rolling", {"FASTKV_FUSED_ROLLING": "0"})):
+                        ("no_setprio", {"FASTKV_FUSED_TUNE": "0"}), ("no_fold", {"FASTKV_TSP_FOLD": "0"}), ("no_rolling", {"FASTKV_FUSED_ROLLING": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", _SWITCH_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "DIGEST" in r.stdout, (name, r.stdout[-800:] + r.stderr[-1500:])
