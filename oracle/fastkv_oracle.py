@@ -25,6 +25,7 @@ _LIB = os.path.join(_HERE, "libfastkv_oracle.so")
 CFLAGS = ["-O3", "-ffp-contract=off", "-mavx2", "-mfma", "-mf16c", "-fopenmp", "-shared", "-fPIC"]
 
 _lib = None
+CONTRACTION_FMAF = 0                                             # (fastkv_oracle.c FK_CONTRACT_FMAF)
 
 
 def build(force: bool = False) -> str:
@@ -74,6 +75,11 @@ def lib() -> ctypes.CDLL:
         L.fastkv_oracle_mfma16_tiles.restype = ci
         L.fastkv_oracle_set_threads.argtypes = [ci]
         L.fastkv_oracle_get_threads.restype = ci
+        # the default contract follows FASTKV_CONTRACTION, like the HIP side's "auto" (capi.hip default_contract_f16): a process started with
+        # FASTKV_CONTRACTION=fmaf -- the contract to run for accuracy / parity work -- compares fma chain with fma chain without every caller
+        # having to say so
+        if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F"):
+            L.fastkv_oracle_set_contraction(CONTRACTION_FMAF)
         _lib = L
     return _lib
 
@@ -93,6 +99,7 @@ def _check(rc: int, what: str):
 
 
 CONTRACTION = {"fmaf": 0, "mfma16": 1}
+assert CONTRACTION["fmaf"] == 0
 
 
 def set_contraction(name: str) -> None:
