@@ -9,7 +9,7 @@ import torch
 from fastkv_amd import ops
 dev = torch.device("cuda:0")
 H, Hkv, D, W, S = 32, 8, 128, 8, int(os.environ.get("EXP_S", "32768"))
-tag = f"OCC3={os.environ.get('FASTKV_FUSED_OCC3', '0')} CONV={os.environ.get('FASTKV_FUSED_CONVEYOR', '0')} TUNE={os.environ.get('FASTKV_FUSED_TUNE', '0')}"
+tag = f"OCC3={os.environ.get('FASTKV_FUSED_OCC3', '0')} CONV={os.environ.get('FASTKV_FUSED_CONVEYOR', '0')} TUNE={os.environ.get('FASTKV_FUSED_TUNE', '1')} SPLIT1={os.environ.get('FASTKV_FUSED_SPLIT1', '0')}"
 for B in ([int(os.environ["EXP_B"])] if os.environ.get("EXP_B") else (3, 4, 5, 8, 16)):
     nset = max(2, 16 // B)
     g = torch.Generator(device=dev).manual_seed(17 + B)
