@@ -1043,7 +1043,7 @@ def finish_multi_rank(a, out, work, rank, world, dev, dist, t_proc0) -> int:
          reported on STDERR (`LEGS_JSON {...}`) and, where the directory exists, in gpurun_out/bench_legs_N<world>.json -- stdout
          carries the one line and nothing else."""
     deadline = float(os.environ.get("FASTKV_BENCH_LINE_DEADLINE_S", "75"))
-    if rank == 0 and not a.no_extras:
+    if rank == 0 and not a.no_extras and os.environ.get("FASTKV_FUSED") != "0":     # (the no-wait kernels have no grouped scoring launch to price)
         try:
             from fastkv_amd._lib import load
             rf = quick_group_roofline(load(), work)
