@@ -1060,14 +1060,20 @@ static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn,
 
 // The rolling launch's geometry (launch_score_fused): F entries on the chip at a time, each 1 / parts of a batch row's units at its
 // smallest size (four tiles per wave).  false: no such plan (short prompts: many entries fit a regular launch anyway).
+static int rolling_pert_min()
+{
+    static const int v = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_PERT"); return e ? atoi(e) : 4; }();     // measurement aid
+    return v;
+}
 static bool rolling_plan_for(const fastkv_problem &p, int UH, bool f16, int &F, int &parts, FusedPlan &ph)
 {
     static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
     F = 0; parts = 1;
+    const int pert_min = rolling_pert_min();
     for (int pp = 1; pp <= 8 && pp <= UH && !F; pp *= 2) {
         if (UH % pp) break;
         for (int f = f_cap; f >= 2 && !F; --f)
-            if (fused_plan_for(p, UH / pp, 1, 1, ph, f16, 512 / f) && ph.PERT == 4 && (size_t)2 * f * (UH / pp) * ph.nblk <= FUSED_MAX_WGS) { F = f; parts = pp; }
+            if (fused_plan_for(p, UH / pp, 1, 1, ph, f16, 512 / f) && ph.PERT >= pert_min && (size_t)2 * f * (UH / pp) * ph.nblk <= FUSED_MAX_WGS) { F = f; parts = pp; }
     }
     return F != 0 && fused_plan_for(p, UH / parts, 1, 1, ph, f16, 512 / F);
 }
@@ -1227,7 +1233,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         const bool have_plan = rolling_plan_for(p, UH, f16, F, parts, ph);
         const int entries = p.B * parts;
         // (VH == 1: the head-sum chain of models with more than four query heads per KV head has room for two entries' spans only)
-        if (rolling_on && f16 && VH == 1 && have_plan && sb * parts <= F && entries > F && entries <= EPOCH_STRIDE) {
+        if (rolling_on && f16 && VH == 1 && have_plan && (sb * parts <= F || rolling_pert_min() < 4) && entries > F && entries <= EPOCH_STRIDE) {
             const dim3 grid(ph.nblk * (UH / parts), entries);
             ProfScope ps_(K_FUSED, st);
             fused_dispatch(p.D, ph.PERT, ph.NBV, 1, f16, [&](auto fl) {
