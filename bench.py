@@ -139,7 +139,6 @@ class HotPathPrefill:
         if defer is not None:
             for i, ko, vo in defer.flush():
                 cache[i] = (ko, vo)
-        ops.finish_join()                # (FASTKV_FINISH_STREAM=1: the step ends when every cache row is complete on this stream; else a no-op)
         return cache, hidden
 
 

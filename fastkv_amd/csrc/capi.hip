@@ -6,7 +6,6 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
-#include <unordered_map>
 
 using namespace fk;
 
@@ -293,42 +292,6 @@ int fastkv_update_kv_f16(const fastkv_problem *p, const void *q, const int64_t q
 
 }  // extern "C"
 
-// ---- the finish stream (FASTKV_FINISH_STREAM=1; fastkv_finish_join) -----------------------------------------------------------
-// The operator is two halves with different bounds: the scoring launch (vector issue + hand-off latency, a third of HBM) and the
-// "finish" -- selection, grouping pass, K/V copy: latency and HBM.  With the switch on the finish of a call goes to a stream of the
-// library's own (behind an event recorded after the scoring launch), so that the NEXT call's scoring launch -- on another workspace --
-// runs beside it.  What the caller may rely on: `tsp_idx_out` is complete in the order of ITS stream (the stream waits for the TSP
-// selection); k_out / v_out / kv_idx_out are complete in stream order only behind fastkv_finish_join(stream); a workspace is not
-// touched by a later call before the finish that used it is over (the call waits for it: alternate between two workspaces to overlap).
-namespace fk {
-struct FinishState { hipEvent_t scored = nullptr, tsp = nullptr, done = nullptr; bool pending = false; };
-static std::mutex g_finish_mtx;
-static std::unordered_map<void *, FinishState> g_finish;         // per workspace
-static hipStream_t g_finish_stream[16];
-static bool finish_stream_on()
-{
-    static const bool on = []() { const char *e = getenv("FASTKV_FINISH_STREAM"); return e && e[0] == '1'; }();
-    return on;
-}
-static hipStream_t finish_stream_of_device()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!g_finish_stream[dev] && hipStreamCreateWithFlags(&g_finish_stream[dev], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return g_finish_stream[dev];
-}
-}  // namespace fk
-extern "C" int fastkv_finish_join(void *stream)
-{
-    std::lock_guard<std::mutex> lk(fk::g_finish_mtx);
-    for (auto &kv : fk::g_finish)
-        if (kv.second.pending) {
-            if (hipStreamWaitEvent((hipStream_t)stream, kv.second.done, 0) != hipSuccess) return FASTKV_ELAUNCH;
-            kv.second.pending = false;
-        }
-    return FASTKV_OK;
-}
-
 // The operator behind fastkv_update_kv_strided_f16 (one base address + batch stride per tensor) and fastkv_update_kv_ptrs_f16
 // (`pt`: one base address per batch entry, in device memory; q / k / v / k_out / v_out are then ignored).
 static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t q_strides[4], const void *k,
@@ -354,25 +317,6 @@ static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t 
     if (workspace_bytes < L.total) return FASTKV_EWORKSPACE;
     char *ws = (char *)workspace;
     hipStream_t st = (hipStream_t)stream;
-    // (the finish stream: see above.  `fs` = the stream of selection / grouping / copy: the caller's, or the library's own)
-    hipStream_t fs = st;
-    FinishState *fin = nullptr;
-    if (finish_stream_on()) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        hipStream_t side = finish_stream_of_device();
-        if (side && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
-            std::lock_guard<std::mutex> lk(g_finish_mtx);
-            FinishState &f = g_finish[workspace];
-            if (!f.scored) {
-                if (hipEventCreateWithFlags(&f.scored, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.tsp, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g_finish.erase(workspace); return FASTKV_ELAUNCH; }
-            }
-            if (f.pending && hipStreamWaitEvent(st, f.done, 0) != hipSuccess) return FASTKV_ELAUNCH;    // this workspace's previous finish
-            f.pending = false;
-            fin = &f;
-            fs = side;
-        }
-    }
     uint16_t *c = reinterpret_cast<uint16_t *>(ws + L.off_c);
     uint16_t *t = p->tsp_len ? reinterpret_cast<uint16_t *>(ws + L.off_t) : nullptr;
     const int kk = p->capacity - p->window;
@@ -412,45 +356,32 @@ static int update_kv_impl(const fastkv_problem *p, const void *q, const int64_t 
     // From here on token-tagged kernels may be in the stream: if a later stage cannot be launched the epoch is advanced by a
     // one-thread kernel before returning, so that the next call never re-uses this call's hand-off token.
     auto fail = [&]() {
-        if (epoch_bump) (void)launch_epoch_bump(epoch_bump, fs);
-        if (fin) { if (hipEventRecord(fin->done, fs) == hipSuccess) fin->pending = true; (void)hipStreamWaitEvent(st, fin->done, 0); }
+        if (epoch_bump) (void)launch_epoch_bump(epoch_bump, st);
         return FASTKV_ELAUNCH;
     };
-    if (fin) {
-        // everything below runs on the finish stream, behind the scoring launch
-        if (hipEventRecord(fin->scored, st) != hipSuccess || hipStreamWaitEvent(fs, fin->scored, 0) != hipSuccess) { fs = st; fin = nullptr; (void)hipGetLastError(); }
-    }
     if (scores_out) {
         e = hipMemcpy2DAsync(scores_out, (size_t)L.n * 2, c, (size_t)L.n_pad * 2, (size_t)L.n * 2, (size_t)p->B * p->Hkv,
-                             hipMemcpyDeviceToDevice, fs);
+                             hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return fail();
     }
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(ws);
     if (!select_all) {
         const TspFold fold = {p->B, p->Hkv, t, L.n_pad, reinterpret_cast<uint32_t *>(ws + L.off_thist)};
         e = launch_select(c, (int64_t)p->B * p->Hkv, L.n_pad, L.n, kk, 0, idx_asc, kk, keys, kal,
-                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, fs, ctrl, fold_tsp ? &fold : nullptr);
+                          reinterpret_cast<const uint32_t *>(ws + L.off_hist), arrive, seltab, st, ctrl, fold_tsp ? &fold : nullptr);
         if (e != hipSuccess) return fail();
     }
     if (p->tsp_len) {
         e = launch_select(t, p->B, L.n_pad, L.n, p->tsp_len - p->window, p->window, tsp_idx_out, p->tsp_len, nullptr, 0,
                           reinterpret_cast<const uint32_t *>(ws + L.off_thist), arrive + (size_t)p->B * p->Hkv,
-                          seltab + SELTAB_ONE_BYTES / 4, fs, ctrl);                        // (the TSP rows' own table: fk_host.h)
+                          seltab + SELTAB_ONE_BYTES / 4, st, ctrl);                        // (the TSP rows' own table: fk_host.h)
         if (e != hipSuccess) return fail();
-        // the TSP index is what the caller's stream needs next (the gather of the hidden states): it waits for it, not for the copy
-        if (fin && (hipEventRecord(fin->tsp, fs) != hipSuccess || hipStreamWaitEvent(st, fin->tsp, 0) != hipSuccess)) return fail();
     }
     // (every candidate kept + score order: the ascending list is the identity and nobody else reads it -- the compaction
     // derives it instead of loading it)
     e = launch_compact(*p, k, k_strides, v, v_strides, (select_all && by_score) ? nullptr : idx_asc, keys,
-                       by_score ? kv_idx_out : nullptr, k_out, v_out, fs, epoch_bump, out_strides, pt);
-    if (e != hipSuccess) return fail();
-    if (fin) {
-        if (hipEventRecord(fin->done, fs) != hipSuccess) return FASTKV_ELAUNCH;
-        std::lock_guard<std::mutex> lk(g_finish_mtx);
-        fin->pending = true;
-    }
-    return FASTKV_OK;
+                       by_score ? kv_idx_out : nullptr, k_out, v_out, st, epoch_bump, out_strides, pt);
+    return e == hipSuccess ? FASTKV_OK : fail();
 }
 
 extern "C" {

@@ -17,8 +17,6 @@ POOLING = {"avgpool": 0, "maxpool": 1}
 ORDER = {"index": 0, "score": 1}
 
 _ws_cache: dict = {}
-_ws_turn: dict = {}
-FINISH_STREAM = os.environ.get("FASTKV_FINISH_STREAM", "0") == "1"       # (read by the library at its first call, too)
 
 
 def _require_cuda(*ts: torch.Tensor) -> None:
@@ -42,11 +40,6 @@ def _workspace(nbytes: int, device: torch.device, kind: str = "op") -> torch.Ten
     fastkv_workspace_init sets up once per allocation and that only those entry points may touch.
     kind "scratch": plain scratch of the stand-alone select and the sequence-sharded stages (written from byte 0)."""
     key = (device.index, _stream(), kind)
-    if kind == "op" and FINISH_STREAM:
-        # two operator workspaces per stream, taken in turns: the finish of a call (on the library's finish stream) runs beside the
-        # NEXT call's scoring launch only if that call works in another workspace (include/fastkv_hip.h fastkv_finish_join)
-        _ws_turn[key] = slot = 1 - _ws_turn.get(key, 1)
-        key = key + (slot,)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -58,16 +51,6 @@ def _workspace(nbytes: int, device: torch.device, kind: str = "op") -> torch.Ten
             from . import selftest                                  # (once per process; runs on this device with its own workspaces)
             selftest.maybe_run_at_load(device)
     return ws
-
-
-def finish_join() -> None:
-    """With FASTKV_FINISH_STREAM=1: the current stream waits for every selection / copy the library has enqueued on its finish
-    stream so far -- behind this call the compressed K/V of all earlier `update_kv*` calls are complete in stream order.  A no-op
-    otherwise."""
-    if FINISH_STREAM:
-        L = load()
-        L.fastkv_finish_join.argtypes = [ctypes.c_void_p]
-        check(L.fastkv_finish_join(ctypes.c_void_p(_stream())), "finish_join")
 
 
 PLACEMENT_POLICY = {"count": 0, "strict": 1, "failsafe": 2}

@@ -146,17 +146,6 @@ int fastkv_set_no_wait_mode(int on);
 int fastkv_set_fused_rolling(int on);
 int fastkv_no_wait_mode(void);
 
-/* The finish stream (FASTKV_FINISH_STREAM=1 in the environment; off by default).  An operator call is two halves with different
- * bounds: the scoring launch (vector issue and hand-off latency) and the "finish" (selection, grouping pass, K/V copy: latency and
- * HBM).  With the switch on, the update_kv entry points enqueue the finish on a stream of the library's own, behind an event
- * recorded after the scoring launch: the NEXT call's scoring launch -- on another workspace -- then runs beside it.  The contract
- * changes in exactly this: `tsp_idx_out` is still complete in the order of the caller's stream (the stream is made to wait for
- * the TSP selection); k_out / v_out / kv_idx_out / scores_out are complete in the order of `stream` only behind
- * fastkv_finish_join(stream), which makes `stream` wait for every finish enqueued so far.  A workspace is not touched by a later
- * call before the finish that used it is over (the later call's stream waits): alternate between two workspaces to get the overlap.
- * Tensors handed to a call must stay allocated until the join.  Inside a stream capture the switch is ignored. */
-int fastkv_finish_join(void *stream);
-
 /*
  * The whole operator: replaces the compress branch of FastKVCluster.update_kv (utils.py:93-132).
  *   q, k, v        fp16, logical [B,H,S,D] / [B,Hkv,S,D] with the given element strides
