@@ -132,9 +132,17 @@ __global__ void __launch_bounds__(256) compact_kv_kernel(const uint16_t *__restr
 // BPT = bins per thread: 4096 bins for the budgets of a few thousand rows, fewer for longer winner lists so that bins + lists still fit the
 // workgroup's LDS (round 5: the published recipe keeps 3276 rows per head at 32k and 13,107 at 128k -- beyond the 2688 winners the 4096-bin
 // layout holds in 64 KiB, such calls used to fall back to the k^2 counting inside the copy kernel: 81 us instead of ~45 per 64-head launch).
+// Measurement build (-DFK_STAMP): wall-clock stamps (100 MHz) of the grouping pass's stages, per wave (tools/stamp_rank_group.py)
+#ifdef FK_STAMP
+__device__ unsigned long long g_rstamps[4096 * 8];
+#define FKR_STAMP(slot) do { if ((threadIdx.x & 63) == 0) g_rstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) % 4096 * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define FKR_STAMP(slot) do { } while (0)
+#endif
 template <int BPT>
 __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__ keys, int kk, int kal)
 {
+    FKR_STAMP(0);
     constexpr int RG_BINS = 1024 * BPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];
     uint32_t *s_start = reinterpret_cast<uint32_t *>(rg_smem);             // [RG_BINS] counts, then: winners in higher bins
@@ -156,13 +164,16 @@ __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
     if (lane == 0) { s_mn[w] = mn; s_mx[w] = mx; }
+    FKR_STAMP(1);
     __syncthreads();
+    FKR_STAMP(2);
 #pragma unroll
     for (int i = 0; i < 16; ++i) { mn = min(mn, s_mn[i]); mx = max(mx, s_mx[i]); }
     int sh = 0;
     while (((mx - mn) >> sh) >= (uint32_t)RG_BINS) ++sh;
     for (int i = threadIdx.x; i < kk; i += 1024) atomicAdd(&s_start[(s_key[i] - mn) >> sh], 1u);
     __syncthreads();
+    FKR_STAMP(3);
     // suffix sums over the bins: thread t owns bins BPT t .. BPT t + BPT - 1
     {
         const int b0 = threadIdx.x * BPT;
@@ -181,11 +192,13 @@ __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__
         for (int u = BPT - 1; u >= 0; --u) { s_cnt[b0 + u] = cb[u]; s_start[b0 + u] = above; above += cb[u]; }
     }
     __syncthreads();
+    FKR_STAMP(4);
     for (int i = threadIdx.x; i < kk; i += 1024) {
         const uint32_t key = s_key[i], bin = (key - mn) >> sh;
         s_grp[s_start[bin] + atomicAdd(&s_cur[bin], 1u)] = (key << 16) | (uint32_t)(65535 - i);
     }
     __syncthreads();
+    FKR_STAMP(5);
     for (int i = threadIdx.x; i < kk; i += 1024) {
         const uint32_t key = s_key[i], bin = (key - mn) >> sh, me = (key << 16) | (uint32_t)(65535 - i);
         const uint32_t lo = s_start[bin], n = s_cnt[bin];
@@ -193,7 +206,16 @@ __global__ void __launch_bounds__(1024) rank_group_kernel(uint16_t *__restrict__
         for (uint32_t u = 0; u < n; ++u) c += s_grp[lo + u] > me ? 1u : 0u;   // larger key, or the same key at an earlier position
         kr[i] = (uint16_t)(lo + c);
     }
+    FKR_STAMP(6);
 }
+#ifdef FK_STAMP
+}  // namespace fk
+extern "C" int fastkv_debug_read_rank_stamps(unsigned long long *host, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::g_rstamps), n * sizeof(unsigned long long));
+}
+namespace fk {
+#endif
 
 hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t *ks, const void *v, const int64_t *vs,
                           const int64_t *idx, const uint16_t *keys, int64_t *idx_sorted_out, void *k_out, void *v_out,
