@@ -185,13 +185,12 @@ __device__ __forceinline__ f32x2 det_expf2_clamped(f32x2 d)
 // exp_to_fix of both components; NaN components must be excluded by the caller (as with exp_to_fix)
 __device__ __forceinline__ void exp_to_fix2(f32x2 e, uint32_t &hi0, uint32_t &lo0, uint32_t &hi1, uint32_t &lo1)
 {
+    // (a >= 0: a - trunc(a) is v_fract_f32, exact, and the conversion to an integer truncates by itself -- two instructions where
+    // trunc, subtract, convert were three; the same bits)
     const f32x2 a = e * splat2(65536.0f);
-    f32x2 hf;
-    hf.x = __builtin_truncf(a.x);
-    hf.y = __builtin_truncf(a.y);
-    const f32x2 rem = a - hf;
+    const f32x2 rem = {__builtin_amdgcn_fractf(a.x), __builtin_amdgcn_fractf(a.y)};
     const f32x2 l = rem * splat2(16777216.0f);
-    hi0 = (uint32_t)hf.x; hi1 = (uint32_t)hf.y;
+    hi0 = (uint32_t)a.x; hi1 = (uint32_t)a.y;
     lo0 = (uint32_t)__builtin_rintf(l.x); lo1 = (uint32_t)__builtin_rintf(l.y);
 }
 

@@ -647,7 +647,13 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     auto tile_of = [&](int s) { return reinterpret_cast<tile_t(*)[TW]>(smem + CD_HEAD + (size_t)s * G * TW * sizeof(tile_t)); };
     auto hist_of = [&](int s) { return reinterpret_cast<uint32_t *>(smem + (E_BYTES >= HIST_BYTES ? 0 : E_BYTES) + (size_t)s * HIST_BYTES); };
     // a tile element: an fp16-valued number (or the pooling pad value: 0 / -inf), stored as float or as its fp16 bits
-    auto tl_put = [](tile_t &dst, float v) { if constexpr (std::is_same<tile_t, float>::value) dst = v; else dst = f2h(v); };
+    // (every NaN enters the tile as THE positive quiet NaN: phase D's max pooling then is an integer maximum over the bit patterns --
+    // the tile holds -inf (the pooling pad), values >= +0 and that one NaN, whose pattern is the largest, as the reference's max
+    // pooling has it: any NaN in the window wins; the final scores store every NaN as 0x7e00 anyway, f2h_score)
+    auto tl_put = [](tile_t &dst, float v) {
+        const float c = (v != v) ? bits_f32(0x7fc00000u) : v;
+        if constexpr (std::is_same<tile_t, float>::value) dst = c; else dst = f2h(c);
+    };
     auto tl_get = [](const tile_t &src) -> float { if constexpr (std::is_same<tile_t, float>::value) return src; else return h2f(src); };
 
     auto phaseC = [&](auto sc) {
@@ -832,42 +838,78 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                         for (int e = 0; e < 4; ++e) pv[i4][e] = 0.0f;
                         continue;
                     }
-                    float wv[12];
                     const tile_t *row = &tile[i4][PADMAX - 3 + lp];
-                    if constexpr (std::is_same<tile_t, float>::value) {
+                    if (avg) {
+                        float wv[12];
+                        if constexpr (std::is_same<tile_t, float>::value) {
 #pragma unroll
-                        for (int v4 = 0; v4 < 3; ++v4) {
-                            const float4 x = *reinterpret_cast<const float4 *>(row + 4 * v4);
-                            wv[4 * v4] = x.x; wv[4 * v4 + 1] = x.y; wv[4 * v4 + 2] = x.z; wv[4 * v4 + 3] = x.w;
+                            for (int v4 = 0; v4 < 3; ++v4) {
+                                const float4 x = *reinterpret_cast<const float4 *>(row + 4 * v4);
+                                wv[4 * v4] = x.x; wv[4 * v4 + 1] = x.y; wv[4 * v4 + 2] = x.z; wv[4 * v4 + 3] = x.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int v4 = 0; v4 < 3; ++v4) {
+                                const uint2 x = *reinterpret_cast<const uint2 *>(row + 4 * v4);
+                                wv[4 * v4] = h2f((uint16_t)(x.x & 0xffffu)); wv[4 * v4 + 1] = h2f((uint16_t)(x.x >> 16));
+                                wv[4 * v4 + 2] = h2f((uint16_t)(x.y & 0xffffu)); wv[4 * v4 + 3] = h2f((uint16_t)(x.y >> 16));
+                            }
                         }
-                    } else {
 #pragma unroll
-                        for (int v4 = 0; v4 < 3; ++v4) {
-                            const uint2 x = *reinterpret_cast<const uint2 *>(row + 4 * v4);
-                            wv[4 * v4] = h2f((uint16_t)(x.x & 0xffffu)); wv[4 * v4 + 1] = h2f((uint16_t)(x.x >> 16));
-                            wv[4 * v4 + 2] = h2f((uint16_t)(x.y & 0xffffu)); wv[4 * v4 + 3] = h2f((uint16_t)(x.y >> 16));
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float p;
-                        if (avg) {
-                            p = 0.0f;
+                        for (int e = 0; e < 4; ++e) {
+                            float p = 0.0f;
 #pragma unroll
                             for (int o = 0; o < KS; ++o) p = p + wv[e + 3 - PAD + o];
-                            p = p / (float)KS;
-                        } else {
-                            p = -INFINITY;
-#pragma unroll
-                            for (int o = 0; o < KS; ++o) { const float xv = wv[e + 3 - PAD + o]; if (xv > p || xv != xv) p = xv; }
+                            pv[i4][e] = h2f(f2h(p / (float)KS));                              // utils.py:106 -> fp16
                         }
-                        pv[i4][e] = p;
+                    } else {
+                        // max pooling as an INTEGER maximum over the elements' bit patterns (see tl_put: -inf < every value >= +0 < the one
+                        // NaN, as signed integers too): v_max3_i32 over shared partial maxima, 10 instructions for the four positions of a
+                        // head where the compare-and-select chain took 84; the result is an element of the tile: an fp16 value already
+                        int32_t wi[12];
+                        if constexpr (std::is_same<tile_t, float>::value) {
+#pragma unroll
+                            for (int v4 = 0; v4 < 3; ++v4) {
+                                const float4 x = *reinterpret_cast<const float4 *>(row + 4 * v4);
+                                wi[4 * v4] = (int32_t)f32_bits(x.x); wi[4 * v4 + 1] = (int32_t)f32_bits(x.y);
+                                wi[4 * v4 + 2] = (int32_t)f32_bits(x.z); wi[4 * v4 + 3] = (int32_t)f32_bits(x.w);
+                            }
+                        } else {
+#pragma unroll
+                            for (int v4 = 0; v4 < 3; ++v4) {
+                                const uint2 x = *reinterpret_cast<const uint2 *>(row + 4 * v4);
+                                wi[4 * v4] = (int32_t)(int16_t)(x.x & 0xffffu); wi[4 * v4 + 1] = (int32_t)x.x >> 16;
+                                wi[4 * v4 + 2] = (int32_t)(int16_t)(x.y & 0xffffu); wi[4 * v4 + 3] = (int32_t)x.y >> 16;
+                            }
+                        }
+                        auto mx3 = [](int32_t a, int32_t b2, int32_t c2) { return max(max(a, b2), c2); };
+                        int32_t r[4];
+                        if constexpr (PAD == 3) {
+                            const int32_t core = max(mx3(wi[3], wi[4], wi[5]), wi[6]);           // elements every position's window holds
+                            r[0] = max(mx3(wi[0], wi[1], wi[2]), core);
+                            r[1] = max(mx3(wi[1], wi[2], wi[7]), core);
+                            r[2] = max(mx3(wi[2], wi[7], wi[8]), core);
+                            r[3] = max(mx3(wi[7], wi[8], wi[9]), core);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                int32_t m = wi[e + 3 - PAD];
+#pragma unroll
+                                for (int o = 1; o < KS; ++o) m = max(m, wi[e + 3 - PAD + o]);
+                                r[e] = m;
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (std::is_same<tile_t, float>::value) pv[i4][e] = bits_f32((uint32_t)r[e]);
+                            else pv[i4][e] = h2f((uint16_t)(r[e] & 0xffff));
+                        }
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                    for (int i4 = 0; i4 < G; ++i4) if (i4 < HV) gs[e] = gs[e] + h2f(f2h(pv[i4][e]));
+                    for (int i4 = 0; i4 < G; ++i4) if (i4 < HV) gs[e] = gs[e] + pv[i4][e];     // (pv: fp16 values, utils.py:106 / :108)
                     if (!last_vh && j + e < n)
                         __hip_atomic_store(chain_out + lp + e, granule(token, f32_bits(gs[e])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
