@@ -119,6 +119,19 @@ __device__ __forceinline__ uint32_t f2h2(float lo, float hi)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fk_h16x2));
 }
 
+// ---- v_fma_mix_f32: an fp32 fma whose operands may be fp16 values read straight from one half of a register -- the conversion
+// v_cvt_f32_f16 in front of an fp32 add / fma is exact, so "convert, then operate" and the mixed instruction give the same bits with
+// one instruction less.  h2 = a packed pair of fp16 values; _h0 / _h1 pick the low / high half.
+//   mix_add(h, c)     = float(h) + c            (fma(float(h), 1.0, c): the product is exact)
+//   mix_mul(h, b)     = float(h) * b            (fma(float(h), b, -0.0): adding -0 changes no product, not even a zero's sign)
+//   mix_fnma(a, b, h) = fma(-a, b, float(h))
+__device__ __forceinline__ float mix_add_h0(uint32_t h2, float c) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c)); return d; }
+__device__ __forceinline__ float mix_add_h1(uint32_t h2, float c) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c)); return d; }
+__device__ __forceinline__ float mix_mul_h0(uint32_t h2, float b) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(-0.0f)); return d; }
+__device__ __forceinline__ float mix_mul_h1(uint32_t h2, float b) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(-0.0f)); return d; }
+__device__ __forceinline__ float mix_fnma_h0(float a, float b, uint32_t h2) { float d; asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(h2)); return d; }
+__device__ __forceinline__ float mix_fnma_h1(float a, float b, uint32_t h2) { float d; asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(h2)); return d; }
+
 // ---- two elements per instruction: v_pk_mul/fma/add_f32 are IEEE per component, so every component below is bit-identical
 // to the scalar function above (same operations, same order); only rint / convert / select / integer steps stay scalar
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -212,6 +225,15 @@ __device__ __forceinline__ f32x2 scale_div2_finite(f32x2 x, float c, float rc)
 {
     const f32x2 q0 = x * splat2(rc);
     const f32x2 r = fma2(-q0, splat2(c), x);
+    return fma2(r, splat2(rc), q0);
+}
+
+// scale_div2_finite of a packed pair of fp16 values, read by the mixed fma (no conversions in front): the same three operations per
+// component
+__device__ __forceinline__ f32x2 scale_div2_finite_h2(uint32_t h2, float c, float rc)
+{
+    const f32x2 q0 = {mix_mul_h0(h2, rc), mix_mul_h1(h2, rc)};
+    const f32x2 r = {mix_fnma_h0(q0.x, c, h2), mix_fnma_h1(q0.y, c, h2)};
     return fma2(r, splat2(rc), q0);
 }
 

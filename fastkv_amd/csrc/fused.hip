@@ -388,7 +388,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #pragma unroll
                     for (int i = 0; i < NW; ++i) {
                         const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[(i + 8) & 15]);             // matmul -> fp16
-                        const f32x2 scv = scale_div2_finite((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);   // utils.py:94
+                        f32x2 scv;                                                                               // utils.py:94
+                        if constexpr (F16) scv = scale_div2_finite_h2(raw, sqrtD, rsqrtD);
+                        else scv = scale_div2_finite((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);
                         const uint32_t wd = f2h2(scv.x, scv.y);
                         mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
                                                                                           __builtin_bit_cast(h16x2, wd)));
@@ -502,6 +504,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #pragma unroll
         for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; gm_ok = gm_ok && __builtin_fabsf(gm[i]) < INFINITY; }
         const bool gm_finite = __all(gm_ok);                         // wave-uniform: +-inf or NaN row maxima send every tile the general way
+        float ngm[16];                                               // (x - max as x + (-max): the mixed fma takes the addend as it is)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ngm[i] = -gm[i];
         f32x2 epair = {0.0f, 0.0f};                                  // the even word's exponentials, until the odd word's join them
         auto keep = [&](int t, int i, f32x2 e) {                     // t, i: compile-time after unrolling
             if (t < E_REGS) { ev[t < E_REGS ? t : 0][0][i] = e.x; ev[t < E_REGS ? t : 0][1][i] = e.y; }
@@ -522,8 +527,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
                     const int rB = NB == 2 ? i : (i + 8) & 15;
-                    const f32x2 x = {h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))};
-                    const f32x2 e = det_expf2_clamped(x - (f32x2){gm[i], gm[rB]});
+                    f32x2 dlt;                                                                   // x - max, per half of the word
+                    if constexpr (F16) dlt = (f32x2){mix_add_h0(lg[t][i], ngm[i]), mix_add_h1(lg[t][i], ngm[rB])};
+                    else dlt = (f32x2){h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))} - (f32x2){gm[i], gm[rB]};
+                    const f32x2 e = det_expf2_clamped(dlt);
                     keep(t, i, e);
                     uint32_t h0, l0, h1, l1;
                     exp_to_fix2(e, h0, l0, h1, l1);
@@ -674,6 +681,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                 // one packed pair per step: every operation below is per component what the scalar chain does.  NB == 2: the two
                 // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
                 f32x2 p[4];
+                uint32_t phw[4];                                  // the step's four packed probability pairs
                 f32x4_ parked[2];                                 // this step's four words of a tile whose exponentials wait in LDS
                 if (t >= E_REGS) {
                     parked[0] = ebuf[((t - E_REGS) * (NW / 2) + 2 * i4) * 64];
@@ -687,12 +695,22 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     else ee = (u & 1) ? (f32x2){parked[u >> 1].z, parked[u >> 1].w} : (f32x2){parked[u >> 1].x, parked[u >> 1].y};
                     const f32x2 pr = ee * (f32x2){ri[wd], ri[rB]};
                     const uint32_t ph = f2h2(pr.x, pr.y);                                 // utils.py:103 -> fp16
-                    p[u] = (f32x2){h2f((uint16_t)(ph & 0xffffu)), h2f((uint16_t)(ph >> 16))};
+                    phw[u] = ph;
+                    if constexpr (!F16) p[u] = (f32x2){h2f((uint16_t)(ph & 0xffffu)), h2f((uint16_t)(ph >> 16))};
                 }
-                f32x2 a = splat2(0.0f);
-                a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
-                f32x2 c = {__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
-                c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
+                f32x2 a = splat2(0.0f), c;
+                if constexpr (F16) {
+                    // (the fp16 probabilities are added as they are: mixed fma, the same fp32 additions in the same order)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a = (f32x2){mix_add_h0(phw[u], a.x), mix_add_h1(phw[u], a.y)};
+                    c = (f32x2){__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c = (f32x2){mix_add_h0(phw[u], c.x), mix_add_h1(phw[u], c.y)};
+                } else {
+                    a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
+                    c = (f32x2){__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
+                    c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
+                }
                 if (hi) {
                     if (NB == 2) {
                         if (i4 < HV) {
