@@ -31,6 +31,13 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
         break;
     }
     case 12: { const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i]; const uint32_t w = (i & 1) ? f2h2(x2, x) : f2h2(x, x2); r = h2f((uint16_t)((i & 1) ? w >> 16 : w & 0xffffu)); break; }
+    case 13: {                                                   // the two-operation quotient of the fused kernel's epilogue (x: an fp16 value)
+        const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i];
+        const uint32_t w = (i & 1) ? f2h2(x2, x) : f2h2(x, x2);
+        const f32x2 q = scale_div2_finite_h2(w, 1.0f / y, recip_lo(y, 1.0f / y));
+        r = (i & 1) ? q.y : q.x;
+        break;
+    }
     case 11: { const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i]; const f32x2 e = scale_div2((i & 1) ? (f32x2){x2, x} : (f32x2){x, x2}, y, 1.0f / y); r = (i & 1) ? e.y : e.x; break; }
     }
     out[i] = r;
@@ -92,7 +99,7 @@ extern "C" int fastkv_debug_mfma16(const void *a, const void *bt, const float *c
 
 extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream)
 {
-    if (!a || !out || n < 0 || op < 0 || op > 12) return FASTKV_EINVAL;
+    if (!a || !out || n < 0 || op < 0 || op > 13) return FASTKV_EINVAL;
     hipLaunchKernelGGL(fk::debug_contract_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, out64, n);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }

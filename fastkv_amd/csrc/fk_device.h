@@ -124,11 +124,14 @@ __device__ __forceinline__ uint32_t f2h2(float lo, float hi)
 // one instruction less.  h2 = a packed pair of fp16 values; _h0 / _h1 pick the low / high half.
 //   mix_add(h, c)     = float(h) + c            (fma(float(h), 1.0, c): the product is exact)
 //   mix_mul(h, b)     = float(h) * b            (fma(float(h), b, -0.0): adding -0 changes no product, not even a zero's sign)
+//   mix_fma(h, b, c)  = fma(float(h), b, c)
 //   mix_fnma(a, b, h) = fma(-a, b, float(h))
 __device__ __forceinline__ float mix_add_h0(uint32_t h2, float c) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c)); return d; }
 __device__ __forceinline__ float mix_add_h1(uint32_t h2, float c) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c)); return d; }
 __device__ __forceinline__ float mix_mul_h0(uint32_t h2, float b) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(-0.0f)); return d; }
 __device__ __forceinline__ float mix_mul_h1(uint32_t h2, float b) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(-0.0f)); return d; }
+__device__ __forceinline__ float mix_fma_h0(uint32_t h2, float b, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float mix_fma_h1(uint32_t h2, float b, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ float mix_fnma_h0(float a, float b, uint32_t h2) { float d; asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(h2)); return d; }
 __device__ __forceinline__ float mix_fnma_h1(float a, float b, uint32_t h2) { float d; asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(h2)); return d; }
 
@@ -228,13 +231,18 @@ __device__ __forceinline__ f32x2 scale_div2_finite(f32x2 x, float c, float rc)
     return fma2(r, splat2(rc), q0);
 }
 
-// scale_div2_finite of a packed pair of fp16 values, read by the mixed fma (no conversions in front): the same three operations per
-// component
-__device__ __forceinline__ f32x2 scale_div2_finite_h2(uint32_t h2, float c, float rc)
+// x / c for a packed pair of FINITE fp16 values in TWO operations per component, read by the mixed fma (no conversions in front):
+//   q = fma(x, rc, x * rc_lo),   rc = fp32(1 / c),   rc_lo = fma(-rc, c, 1) * rc   (what rc leaves of 1 / c)
+// -- the product x * rc is exact inside the fma (11 x 24 bits), the correction is good to 2^-49 of q, and an fp16 numerator over one of
+// the three divisors sqrt(64), sqrt(128), sqrt(256) never brings the quotient that close to an fp32 rounding boundary: bit-identical to
+// the IEEE fp32 division for EVERY finite fp16 x, zeros with their signs (exhaustive on the GPU: tests/test_hip_parity.py
+// test_arithmetic_contract_on_gpu, op 13).  Other divisors (one wrong zero sign each among 40 tried) and +-inf (NaN) stay with
+// scale_div2.
+__device__ __forceinline__ float recip_lo(float c, float rc) { return __builtin_fmaf(-rc, c, 1.0f) * rc; }
+__device__ __forceinline__ f32x2 scale_div2_finite_h2(uint32_t h2, float rc, float rc_lo)
 {
-    const f32x2 q0 = {mix_mul_h0(h2, rc), mix_mul_h1(h2, rc)};
-    const f32x2 r = {mix_fnma_h0(q0.x, c, h2), mix_fnma_h1(q0.y, c, h2)};
-    return fma2(r, splat2(rc), q0);
+    const float t0 = mix_mul_h0(h2, rc_lo), t1 = mix_mul_h1(h2, rc_lo);
+    return (f32x2){mix_fma_h0(h2, rc, t0), mix_fma_h1(h2, rc, t1)};
 }
 
 // Reduction of 16 per-lane values over the 32 lanes of a half wave in 16 exchanges instead of 80: every step halves the

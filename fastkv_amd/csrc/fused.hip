@@ -308,6 +308,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // lg[t][i]: a packed pair of scaled + masked fp16 logits.  NB == 2: query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns
     // key0 + n31 (low half) and key0 + 32 + n31 (high half).  NB == 1: rows m(i) (low) and m(i + 8) (high) at column
     // key0 + n31.
+    static_assert(!F16 || D == 64 || D == 128 || D == 256, "scale_div2_finite_h2 is exact for these divisors");
+    const float rsqrtD_lo = recip_lo(sqrtD, rsqrtD);             // (what rsqrtD leaves of 1 / sqrtD: fk_device.h scale_div2_finite_h2)
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
     uint32_t lg[PER][NW];
@@ -389,7 +391,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     for (int i = 0; i < NW; ++i) {
                         const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[(i + 8) & 15]);             // matmul -> fp16
                         f32x2 scv;                                                                               // utils.py:94
-                        if constexpr (F16) scv = scale_div2_finite_h2(raw, sqrtD, rsqrtD);
+                        if constexpr (F16) scv = scale_div2_finite_h2(raw, rsqrtD, rsqrtD_lo);
                         else scv = scale_div2_finite((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);
                         const uint32_t wd = f2h2(scv.x, scv.y);
                         mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),

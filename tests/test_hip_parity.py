@@ -323,6 +323,10 @@ def test_arithmetic_contract_on_gpu(dev):
         assert torch.equal(bits(g), bits(allh / c)), D
         g, _ = run(11, allh, c)
         assert torch.equal(bits(g), bits(allh / c)), D
+        # the two-operation quotient of the fused kernel's epilogue (q = fma(x, rc, x * rc_lo)): every FINITE fp16 value, zeros with their signs
+        fin = allh[torch.isfinite(allh)]
+        g, _ = run(13, fin, c[:fin.numel()])
+        assert torch.equal(bits(g), bits(fin / c[:fin.numel()])), D
     # IEEE division / reciprocal as used for 1/sum and /kernel_size
     y = torch.rand(200000, generator=gen) * 4000 + 1e-3
     assert torch.equal(bits(run(1, torch.ones_like(y), y)[0]), bits(1.0 / y))
