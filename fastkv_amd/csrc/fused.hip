@@ -1132,7 +1132,8 @@ static bool rolling_plan_for(const fastkv_problem &p, int UH, bool f16, int &F, 
     static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
     F = 0; parts = 1;
     const int pert_min = rolling_pert_min();
-    for (int pp = 1; pp <= 8 && pp <= UH && !F; pp *= 2) {
+    static const int parts_min = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();   // measurement aid
+    for (int pp = parts_min; pp <= 8 && pp <= UH && !F; pp *= 2) {
         if (UH % pp) break;
         for (int f = f_cap; f >= 2 && !F; --f)
             if (fused_plan_for(p, UH / pp, 1, 1, ph, f16, 512 / f) && ph.PERT >= pert_min && (size_t)2 * f * (UH / pp) * ph.nblk <= FUSED_MAX_WGS) { F = f; parts = pp; }

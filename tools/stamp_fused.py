@@ -33,6 +33,19 @@ for S, B in zip(args[0::2], args[1::2]):
     t0 = st[:, 0].min()
     rel = (st - t0) * 10 / 1000.0
     print(f"S={S} B={B}: waves seen={len(st)} (of min(4096, launched)); {e0.elapsed_time(e1) * 50:.1f} us per call (events, incl. the stamps' stores)")
+    if os.environ.get("STAMP_BY_ENTRY") and B >= 3:
+        # a rolling launch: the buffer holds the last 4096 waves = the last 4096 / (waves per entry) entries; one block per entry, times
+        # relative to the launch's first stamp in the buffer
+        raw = buf.reshape(4096, NSLOT).astype(np.int64)
+        wpe = 4 * ((S + 1023) // 1024) * Hkv                      # waves per entry (four tiles of 64 keys per wave)
+        for e0_ in range(0, 4096, wpe):
+            blk = raw[e0_:e0_ + wpe]
+            blk = blk[blk[:, 14] > 0]
+            if not len(blk):
+                continue
+            r = (blk - t0) * 10 / 1000.0
+            print(f"  entry block at wave {e0_}: " + "  ".join(f"{names[i].split(',')[0][:14]} {np.median(r[:, i]):6.1f}" for i in (0, 22, 3, 4, 7, 8, 11, 14)))
+        continue
     for i in order:
         col = rel[:, i]
         if (st[:, i] == 0).all():
