@@ -227,8 +227,9 @@ def cpu_baseline_child_main() -> int:
     What is timed: the oracle (oracle/fastkv_oracle.c, a port of utils.py:80-134) on synthetic fp16 inputs of the step's shapes:
     layers 0, 1 (S = 32768), 15 (S = 32768, TSP), 16, 17 (S = 2048) + the hidden gather; 1 warm-up + 5 timed calls each, the MEDIAN
     scaled to the step's 15 + 1 + 16 layers (`best` beside it).  Contraction contracts: "fmaf" -- the fp32 fma chain, a CPU's native
-    arithmetic and the closest thing to the reference's own CPU matmul -- is the baseline's `value`; "mfma16" -- the integer
-    restatement of the gfx950 matrix instruction, the contract the GPU headline runs -- is timed beside it on layers 0 and 16."""
+    arithmetic, bit for bit the reference's own CPU matmul and the contract the GPU headline runs since round 6 -- is the baseline's
+    `value`; "mfma16" -- the integer restatement of the gfx950 matrix instruction, the GPU's opt-in fast mode -- is timed beside it on
+    layers 0 and 16."""
     import statistics
     torch.set_num_threads(1)
     from oracle import fastkv_oracle as O
@@ -293,7 +294,7 @@ def cpu_baseline_child_main() -> int:
         return 15 * (f(per_layer[0]) + f(per_layer[1])) / 2 + f(per_layer[CFG["tsp_idx"]]) + 16 * (f(per_layer[16]) + f(per_layer[17])) / 2 + f(tg)
 
     step_med, step_best = step_of(statistics.median), step_of(min)
-    # the contract the GPU headline runs, on two of the sampled layers
+    # the GPU's opt-in fast contract (restated in integer arithmetic: 22x slower on a CPU), on two of the sampled layers
     O.set_contraction("mfma16")
     m_pre, _ = timed(inputs[0], dict(base, tsp_layer=False), runs=3)
     m_post, _ = timed(inputs[16], dict(base, tsp_layer=False), runs=3)
@@ -301,12 +302,12 @@ def cpu_baseline_child_main() -> int:
     m_step = 16 * statistics.median(m_pre) + 16 * statistics.median(m_post) + statistics.median(tg)
     res = {"value": round(S / step_med, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
            "ms_per_step": round(step_med * 1e3, 1), "ms_per_step_best": round(step_best * 1e3, 1),
-           "contraction": "fmaf (fp32 fma chain: the CPU's native arithmetic, the closest restatement of the reference's own CPU matmul)",
+           "contraction": "fmaf (fp32 fma chain: the CPU's native arithmetic, bit for bit the reference's own CPU matmul, the GPU headline's contract)",
            "per_layer_ms": {str(i): {"median": round(statistics.median(t) * 1e3, 2), "best": round(min(t) * 1e3, 2), "runs": len(t)}
                             for i, t in per_layer.items()},
            "hidden_gather_ms": round(statistics.median(tg) * 1e3, 2),
            "thread_candidates_ms_layer0": {str(k_): v_ for k_, v_ in picks.items()},
-           "same_contract_as_headline": {"contraction": "mfma16 (integer restatement of v_mfma_f32_32x32x16_f16)", "ms_per_step": round(m_step * 1e3, 1),
+           "mfma16_contract": {"contraction": "mfma16 (integer restatement of v_mfma_f32_32x32x16_f16)", "ms_per_step": round(m_step * 1e3, 1),
                                          "tokens_per_s": round(S / m_step, 1), "layer0_ms": round(statistics.median(m_pre) * 1e3, 2),
                                          "layer16_ms": round(statistics.median(m_post) * 1e3, 2),
                                          "sample": "layers 0 (S=32768) and 16 (S=2048), 1 warm-up + 3 timed, median, scaled to 16 + 16 layers + the gather"},
@@ -616,6 +617,33 @@ def rehearse(a, rank, world) -> int:
     return 0
 
 
+def default_contraction() -> str:
+    """The arithmetic contract the library runs when nothing is forced (csrc/capi.hip default_contract_f16): the fp32 fma chain -- the
+    contraction that reproduces the reference's logits bit for bit -- unless FASTKV_CONTRACTION=mfma16 opts into the fast mode."""
+    return "mfma16" if os.environ.get("FASTKV_CONTRACTION", "fmaf")[:1] in ("m", "M") else "fmaf"
+
+
+def roofline_of_the_contract(rf, contraction, flop_per_launch):
+    """`rf` = the HBM view of the dominant launch (algorithmic K bytes / HIP-event duration against 8 TB/s).  Under the mfma16 contract
+    that IS the bound (the contraction is ~2 % of the fp16 matrix peak).  Under the fp32-fma-chain contract (the default since round
+    6) the launch is bound by the FP32 lanes the matrix and the vector pipe share: 32 flop per K byte on v_mfma_f32_32x32x2_f32 at a
+    dense peak of 157.3 TFLOP/s (guides/MI355X_MICROARCH.md: = the fp32 vector rate; vector work does not overlap it,
+    tools/probes/probe_overlap.hip) -- `bound` = "mfma", achieved = algorithmic flops of the contraction (2 x H*W query rows x D x S per
+    layer) / the same duration, and the HBM view stays beside it as `hbm_view` (with the PMC traffic)."""
+    if rf is None or contraction != "fmaf":
+        return rf
+    us = rf["avg_launch_us"]
+    tf = flop_per_launch / (us * 1e-6) / 1e12
+    return {"kernel": rf["kernel"], "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": rf.get("traffic"), "traffic_static": rf.get("traffic_static"),
+            "traffic_source": rf.get("traffic_source"), "algorithmic_flops_per_launch": flop_per_launch, "avg_launch_us": us,
+            "entries_per_launch": rf.get("entries_per_launch"),
+            "note": "fp32-fma-chain contract: the contraction runs on v_mfma_f32_32x32x2_f32 (bit-exact fmaf chain, 1/16 of the fp16 matrix rate) and "
+                    "shares the SIMD's FP32 lanes with the softmax's vector work: per 32k layer 14-16 us of matrix issue + ~10 us of vector issue "
+                    "against 8.4 us of K streaming at 8 TB/s",
+            "hbm_view": {k_: rf[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch") if k_ in rf}}
+
+
 def contract_line(world, steps, warmup, ms_per_step, contraction, ranks_seen, backend, violations, defer, defer_hold):
     """The keys the bench contract names (and the few this path adds), the same for every N -- tests/test_bench_contract.py holds an
     N = 1 and an N = 8 line to it.  `value` = prompt tokens of ALL ranks / the slowest rank's time for `steps` steps."""
@@ -627,8 +655,9 @@ def contract_line(world, steps, warmup, ms_per_step, contraction, ranks_seen, ba
                                   "32k context, TSP layer 15, budget 2048, window 8, kernel 7, maxpool",
                       "prompt_tokens_per_rank": CFG["S"], "parallelism": f"dp{world} (independent prompts)" if world > 1 else "single"},
            "ttft_hotpath_ms": round(ms_per_step, 4),
-           # the arithmetic contract of the contraction (utils.py:94) both sides run by default: "mfma16" = the gfx950 fp16 matrix
-           # instruction on the fp16 operands, restated bit for bit by the oracle; "fmaf" = the fp32 fma chain (FASTKV_CONTRACTION)
+           # the arithmetic contract of the contraction (utils.py:94) both sides run: "fmaf" (default since round 6) = the fp32 fma chain,
+           # which IS the reference's fp16 matmul bit for bit; "mfma16" (FASTKV_CONTRACTION=mfma16, the opt-in fast mode) = the gfx950 fp16
+           # matrix instruction on the fp16 operands, restated bit for bit by the oracle
            "contraction": contraction, "ranks_seen": ranks_seen, "backend": backend,
            # the fused launches' own check of where their workgroups ran (include/fastkv_hip.h: fastkv_placement_violations): 0 = every
            # pair of workgroups that shared a compute unit in the warm-up and timed steps belonged to one head, as the kernel assumes
@@ -728,7 +757,7 @@ def main():
     raise_if_aborted("bench")                                    # (behind the synchronisation: an abandoned launch is an error of the run)
 
     out = contract_line(world, a.steps, a.warmup, ms_per_step,
-                        "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16",
+                        default_contraction(),
                         dist.get_world_size() if dist is not None else 1, dist.get_backend() if dist is not None else "none",
                         int(lib.fastkv_placement_violations(0)), work.defer, work.defer_hold)
 
@@ -779,9 +808,10 @@ def main():
                                         ") + softmax (2 in-kernel reductions over the head's workgroups) + window-row "
                                         "sum + pooling + head sum in one launch; logits stay in registers, row sums in LDS") if kname == "score_fused"
                                        else "matrix-pipe contraction; logits written as fp16"}
-            # The contraction must be an fp32 fma chain in ascending head-dim order (bit-exact parity with the CPU oracle), so it
-            # runs on v_mfma_f32_32x32x2_f32 (32 flop per K byte): the FP32 pipe saturates long before HBM does.  Measured
-            # (tools/probes/probe_overlap.hip): vector-ALU work does not overlap the fp32 MFMAs of a SIMD, the two add up.
+            # The matrix-pipe view of the same launch.  Contract "fmaf" (default): the contraction is the fp32 fma chain in ascending
+            # head-dim order on v_mfma_f32_32x32x2_f32 (32 flop per K byte): the FP32 lanes saturate long before HBM does, and vector
+            # work does not overlap the fp32 MFMAs of a SIMD (tools/probes/probe_overlap.hip: the two add up) -- this view becomes the
+            # line's `roofline` below.  Contract "mfma16": the same flops on the fp16 matrix instruction are ~2 % of its peak.
             pipe_peak = FP32_MATRIX_PEAK_TFLOPS if out["contraction"] == "fmaf" else 2500.0    # dense fp16 MFMA peak (MI355X_MICROARCH.md)
             out["fp32_pipe_view"] = {"kernel": kname, "achieved_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2),
                                      "peak_TFLOPs": pipe_peak, "frac": round(flops / (us * 1e-6) / 1e12 / pipe_peak, 4),
@@ -824,7 +854,7 @@ def main():
                     # grid 65536 x defer_hold of score_fused_kernel<128,4,2,1> in the rocprofv3 trace -- is what dominates the default
                     # step, and what the headline prices; the pair launch (the schedule of groups of two) stays beside it.
                     n_grp = int(work.defer_hold)
-                    if n_grp >= 3 and out["contraction"] == "mfma16":
+                    if n_grp >= 3:
                         nl = min(len(work.layers_in), 16)
                         grp = lambda i: [work.layers_in[(i * n_grp + j) % nl] for j in range(n_grp)]   # noqa: E731
                         for i in range(2):
@@ -856,6 +886,7 @@ def main():
                                                           "flop_per_launch": n_grp * flops})
                 except Exception as e:   # noqa: BLE001 -- the one-layer figures stay in place
                     out["roofline"]["pair_launch_error"] = repr(e)[:160]
+            out["roofline"] = roofline_of_the_contract(out["roofline"], out["contraction"], out["fp32_pipe_view"]["flop_per_launch"])
             # the same step with every layer compressed inside its own attention forward, as the reference does it
             if work.defer:
                 work.defer = False
@@ -946,12 +977,12 @@ def main():
             out["kv_compact_note"] = ("KV gather/compact kernel at the 541 MB roofline shape, rows in the reference's score order (the product "
                                       "default; median over calls, HIP events); index order: compact.roofline_shape.index")
             # both arithmetic contracts of the step side by side at the top level (VERDICT r04 next #2c): the headline's and the other
-            # one, GPU and CPU (the CPU leg's `value` is the fma chain, its `same_contract_as_headline` the restated matrix instruction)
+            # one, GPU and CPU (the CPU leg's `value` is the fma chain -- the headline's contract since round 6 --, its `mfma16_contract` the restated matrix instruction)
             out["step_ms_by_contract"] = {out["contraction"]: out["ms_per_step"], out["other_contract"]["contraction"]: out["other_contract"]["ms_per_step"]}
             if cpu is not None:
                 out["cpu_baseline"] = cpu
-                if "same_contract_as_headline" in cpu:
-                    out["cpu_ms_by_contract"] = {"fmaf": cpu["ms_per_step"], "mfma16": cpu["same_contract_as_headline"]["ms_per_step"]}
+                if "mfma16_contract" in cpu:
+                    out["cpu_ms_by_contract"] = {"fmaf": cpu["ms_per_step"], "mfma16": cpu["mfma16_contract"]["ms_per_step"]}
             try:
                 out["published_recipe"] = published_recipe_leg(lib, dev, a.steps)
             except Exception as e:   # noqa: BLE001 -- an extra; the contract line does not depend on it
@@ -1024,9 +1055,10 @@ def quick_group_roofline(lib, work):
     if os.path.exists(tpath) and c3 == 6:
         tj = json.load(open(tpath))
         traffic = tj.get("score_fused_group_hbm_bytes_per_launch") if tj.get("score_fused_group_entries") == n_grp else None
-    return {"kernel": f"score_fused ({n_grp} S=32768 layers per call, {c3 // 6} scoring launch(es) per call; rank 0)", "bound": "hbm",
-            "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-            "traffic": traffic, "traffic_static": True, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2)}
+    rf = {"kernel": f"score_fused ({n_grp} S=32768 layers per call, {c3 // 6} scoring launch(es) per call; rank 0)", "bound": "hbm",
+          "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+          "traffic": traffic, "traffic_static": True, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2)}
+    return roofline_of_the_contract(rf, default_contraction(), 2.0 * H * W * D * S * n_grp * 6 // c3)
 
 
 def finish_multi_rank(a, out, work, rank, world, dev, dist, t_proc0) -> int:

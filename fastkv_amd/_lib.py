@@ -184,7 +184,17 @@ def raise_if_aborted(what: str = "last_status") -> None:
     about everything enqueued before it (benchmark/prefill.py, benchmark/e2e.py); the wiring also calls it un-synchronised at the
     end of every prefill, which reports what has completed by then."""
     L = load()
-    check(L.fastkv_last_status(), what)
+    before = bool(L.fastkv_no_wait_mode())
+    try:
+        check(L.fastkv_last_status(), what)
+    finally:
+        if not before and L.fastkv_no_wait_mode():
+            # the report that was just taken (a given-up wait or, under the fail-safe placement policy, a placement violation) switched
+            # the process to the no-wait kernels for good: say so once -- nothing else tells the caller why every later call is slower
+            import warnings
+            warnings.warn(f"fastkv_amd.{what}: the library has switched this process to the no-wait kernels (staged scoring, wait-free "
+                          "selection; as FASTKV_FUSED=0) after the report above -- ops.set_no_wait_mode(False) switches back",
+                          RuntimeWarning, stacklevel=2)
     global _violations_seen
     total = L.fastkv_placement_violations(0)                # (not reset: bench.py and tests read the running count)
     n, _violations_seen = total - _violations_seen if total >= _violations_seen else total, total

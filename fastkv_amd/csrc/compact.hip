@@ -10,6 +10,7 @@
 #include "fk_device.h"
 #include <cstdlib>
 #include "fk_host.h"
+#include <atomic>
 #include "prof.h"
 #include "rank.h"
 
@@ -237,16 +238,31 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
         const int kk_ = p.capacity - p.window;
         const int bpt = kal <= 2688 ? 4 : kal <= 6656 ? 2 : 1;
         const size_t lds = (size_t)3 * 1024 * bpt * 4 + kal * 4 + kal * 2;
+        // more than the default 64 KiB of dynamic LDS has to be asked for, per device, and may be refused (a part with less LDS per
+        // workgroup): the grouping pass is then skipped and the copy kernel counts by itself, as it does beyond 24,000 winners
+        bool lds_ok = true;
         if (lds > 64 * 1024 - 256) {
-            static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_group_kernel<1>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
-            (void)big_lds;
+            static std::atomic<int> granted[16];                 // per device: 0 unknown, 1 granted, -1 refused
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) lds_ok = false;
+            else {
+                int g = granted[dev].load(std::memory_order_relaxed);
+                if (!g) {
+                    g = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_group_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024 - 512) == hipSuccess ? 1 : -1;
+                    if (g < 0) (void)hipGetLastError();
+                    granted[dev].store(g, std::memory_order_relaxed);
+                }
+                lds_ok = g > 0;
+            }
         }
-        const dim3 rg((unsigned)(p.B * p.Hkv));
-        if (bpt == 4) hipLaunchKernelGGL(rank_group_kernel<4>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
-        else if (bpt == 2) hipLaunchKernelGGL(rank_group_kernel<2>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
-        else hipLaunchKernelGGL(rank_group_kernel<1>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
-        keys_in_lds = 2;
+        if (lds_ok) {
+            const dim3 rg((unsigned)(p.B * p.Hkv));
+            if (bpt == 4) hipLaunchKernelGGL(rank_group_kernel<4>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+            else if (bpt == 2) hipLaunchKernelGGL(rank_group_kernel<2>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+            else hipLaunchKernelGGL(rank_group_kernel<1>, rg, dim3(1024), lds, st, const_cast<uint16_t *>(keys), kk_, (int)kal);
+            keys_in_lds = 2;
+        }
     }
     const size_t kpad = (kal + 32 * (size_t)lpr - 1) / (32 * (size_t)lpr) * (32 * (size_t)lpr);   // (rank_partial_padded reads whole steps)
     const size_t dyn = keys_in_lds == 1 ? kpad * sizeof(uint16_t) : 0;

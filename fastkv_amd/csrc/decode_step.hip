@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(ST_THREADS) decode_step_kernel(const uint16_t 
         }
         FKD_STAMP(10);
         // a record that never came (a producer died): reported like every abandoned wait, FASTKV_EABORTED from the next call
-        if (dead && sa.host_flag) __hip_atomic_store(sa.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (dead && sa.host_flag) __hip_atomic_fetch_or(sa.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
 }

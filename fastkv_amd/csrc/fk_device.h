@@ -362,7 +362,7 @@ __device__ __forceinline__ bool spin_failed(const SpinCtl &sp)
     if (__hip_atomic_load(sp.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sp.token) return true;
     if (__builtin_amdgcn_s_memrealtime() > sp.deadline) {
         __hip_atomic_store(sp.abort_word, sp.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(sp.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_or(sp.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (reasons combine: capi.hip take_abort_status)
         return true;
     }
     return false;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/fastkv_hip.h"
 
 namespace fk {
@@ -16,7 +17,7 @@ constexpr uint64_t CTRL_MAGIC = 0x66617374'6b765f31ull;
 constexpr int FUSED_CU_SLOTS = 2048;  // {XCC_ID, SE, SH, CU} of HW_ID as an index: who ran on a compute unit in this launch (placement check of the fused kernel)
 constexpr int EPOCH_STRIDE = 64;     // the workspace epoch advances by this much per operator call: sub-launch s of a call (< EPOCH_STRIDE) uses epoch + s, so
                                      // no two launches ever share a hand-off token (the xor-mixed sub index could alias another epoch's token)
-constexpr int FUSED_MAX_WGS = 2048;  // (unit, span) pairs whose hand-off records exist at a time -- a regular launch: 512 workgroups (2 per CU) x up to 2 streams; a rolling launch: the 2 F entries its record areas rotate over (round 5: four entries of 512 workgroups): sizes the record areas
+constexpr int FUSED_MAX_WGS = 1024;  // (unit, span) pairs whose hand-off records exist at a time -- a regular launch: 512 workgroups (2 per CU) x up to 2 streams; a rolling launch: the 2 F entries its record areas rotate over (four entries of 256 workgroups at 32k): sizes the record areas
 // The split selection's granule tables (select.hip): a launch takes the table path only with rows x chunks <= SPL_MAX_WGS workgroups,
 // one line of SPL_LINE 8-byte granules per workgroup.  An operator call makes two such launches (the per-head rows, the TSP rows): two
 // tables at FIXED offsets, never anything else in them (a launch beyond SPL_MAX_WGS runs the wait-free selection and has no table).
@@ -26,6 +27,20 @@ constexpr size_t SELTAB_FIXED_BYTES = 2 * SELTAB_ONE_BYTES;
 constexpr int HIST12 = 4096;    // bins of the high-12-bit key histogram that score_finalize / tsp_rowsum build for select
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Measurement switches (FASTKV_FUSED_ROLLING_PERT / _PARTS / _F, FASTKV_FUSED_MAX_WGS, FASTKV_FUSED_STAGGER_US, FASTKV_FUSED_TUNE,
+// FASTKV_FUSED_STREAMS, FASTKV_CHAIN): read from the environment only in builds with -DFK_EXPERIMENTS (FASTKV_CXXFLAGS, into a
+// FASTKV_BUILD_DIR); the product library holds their defaults as constants and dispatches on nothing a test does not cover.
+static inline int exp_env_int(const char *name, int dflt)
+{
+#ifdef FK_EXPERIMENTS
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // fastkv_problem.reserved bits 0-1.  Two arithmetic CONTRACTS for the contraction of utils.py:94 (oracle/fastkv_oracle.c, "the
 // contraction"): the fp32 fma chain -- engines VALU and MFMA (v_mfma_f32_32x32x2_f32), bit-identical to each other -- and "mfma16",
@@ -88,7 +103,7 @@ static inline Layout make_layout(const fastkv_problem &p)
     // tools/soak_rolling.py, one wrong call in 500,000 when the shapes change from call to call and the areas moved with them.
     // Here an area only ever holds granules of earlier launches (older tokens) or the zeros of fastkv_workspace_init.
     size_t o = CTRL_BYTES;
-    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + FUSED_CU_SLOTS * 8, 256);   // fused score: row max / row sum / halo granules + one {token, unit} granule per compute unit
+    L.off_fpart = o;  o += align_up((size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + FUSED_CU_SLOTS * 8 + (size_t)FUSED_MAX_WGS * 8, 256);   // fused score: row max / row sum / halo granules + one {token, unit} granule per compute unit + one "done" granule per (unit, span) of a rolling launch
     L.off_fchain = o; o += align_up((size_t)512 * 1024 * 8, 256);               // fused score, more than 4 query heads per KV head: [unit span][positions]: 512 Ki head-sum granules at most
     L.off_seltab = o; o += SELTAB_FIXED_BYTES;                                   // [per-head rows' table | TSP rows' table], SELTAB_ONE_BYTES each
     L.off_qf = o;     o += align_up((size_t)p.B * p.Hkv * L.R_alloc * p.D * 4, 256);

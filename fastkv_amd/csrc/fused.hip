@@ -84,9 +84,9 @@ __device__ __forceinline__ bool wait_first_granules(const uint64_t *rec, int str
 // wave is the other wave of its SIMD using the issue slots (vector-ALU work and fp32 MFMAs of a SIMD add up, in one wave or
 // across two: tools/probes/probe_overlap.hip).  The kernel is issue bound (per SIMD: A 27, B 9, C 5, D 4 us), and two streams
 // pay every hand-off's record sweep twice, with twice the producers per head.
-// WPE = workgroups per compute unit (= waves per SIMD) the instantiation is built for: 2 (256 registers, 80 KiB of LDS per workgroup), or 3
-// (round 5: 168 registers, <= 53 KiB -- the two-tiles-per-wave size under the mfma16 contract, for the rolling launch: three workgroups
-// of a compute unit are then in three different phases)
+// WPE = workgroups per compute unit (= waves per SIMD) the instantiation is built for: 2 (256 registers, 80 KiB of LDS per workgroup).
+// (Round 5 built WPE = 3 -- 168 registers, <= 53 KiB, three workgroups of a compute unit in three different phases: bit-exact and 15 %
+// slower, docs/HISTORY.md; its instantiations left the library in round 6.)
 template <int D, int PER, int NB, int NS, bool F16, int WPE>
 __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k, int64_t ks_b, int64_t ks_h, int64_t ks_s,
                                                              const uint16_t *__restrict__ q, int64_t qs_b, int64_t qs_h, int64_t qs_s,
@@ -98,7 +98,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, uint64_t *__restrict__ done, int rolling, int start_delay, int parts, int tune)
 {
     // NB = 32-key column blocks per wave tile: 2, or 1 on short prompts (twice the waves; a packed pair is then two query
     // rows of one column instead of two columns of one row).  NW = packed words per tile.  PS = tiles per wave and stream.
@@ -138,9 +138,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // Entries 1 .. F-1 of a rolling launch (launch_score_fused; `rolling` = F, the entries the chip holds at a time) start late ON
     // PURPOSE, one K-streaming time apart: entries that begin together stay in step -- all stream K, then all do arithmetic -- and
     // gain nothing from sharing the chip.
-    // (WPE == 3: an entry is more workgroups than half of the chip's places; only the part of entry 1 that starts WITH entry 0 is held back,
-    // the rest of it starts when places free up, which is late enough)
-    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling && (WPE == 2 || 2 * blockIdx.x < gridDim.x)) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
+    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
@@ -240,7 +238,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         // workspace never initialised (fastkv_workspace_init): no hand-off of this launch could be trusted.  Reported like an
         // abandoned wait -- the process-wide flag in pinned host memory, FASTKV_EABORTED at the next call -- and every workgroup
         // leaves at once (the condition is the same for all of them); nothing traps, the context stays usable.
-        if (tix == 0) __hip_atomic_store(host_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: not a given-up wait, capi.hip take_abort_status)
+        if (tix == 0) __hip_atomic_fetch_or(host_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (bit 1: not a given-up wait; the bits of several reporters combine, capi.hip take_abort_status)
         return false;
     }
     // (sub 0: the operator call's token, shared with the selection; the epoch advances by EPOCH_STRIDE per call, sub < EPOCH_STRIDE:
@@ -253,6 +251,25 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // at when the kernel ends).  Meeting this launch's token with ANOTHER unit in it = a workgroup of another unit ran on this compute
     // unit during the launch (beside this one, or before it where a launch was not resident all at once): counted in pinned word 3,
     // fastkv_placement_violations().  Never on an idle GPU (tests); expected beside a foreign kernel.
+    // ---- Rolling launch: the record areas rotate over 2 F entries, so entry e writes where entry e - 2 F's records lay.  Grid-order
+    // dispatch makes entry e - 2 F OLDER, not FINISHED: a unit of it that is slow -- the fma-chain contract's NaN redo takes a wave
+    // through its tiles at a fraction of the speed; a foreign kernel may hold a compute unit -- can still be waiting for records of its
+    // head when the entries behind it have come and gone (found by the first soak of the rolling launch under the fma chain, round 6: a
+    // group of up to 20 entries with a NaN query row in one of them gave up its waits and was REPORTED, FASTKV_EABORTED).  So the
+    // hand-over of an area is explicit: every workgroup leaves a {token, 1} "done" granule behind its last read of its head's records,
+    // and a workgroup of entry e >= 2 F publishes its first record only when all workgroups of ITS unit in entry e - 2 F have left
+    // theirs.  Those workgroups were dispatched long before this one and need nothing from it: the wait cannot deadlock.  The
+    // granules are looked at once at the start (in the common case they are all there: the predecessor left the chip an entry's
+    // lifetime ago) and polled before the first publish only if they were not.
+    const bool area_handover = rolling && ent >= 2 * rolling;
+    const uint32_t token_prev = area_handover ? handoff_token(ctrl[2] + sub + (uint32_t)(ent - 2 * rolling)) : 0u;
+    uint64_t *done_unit = done + (size_t)bgv_s[0] * nblk;
+    bool prev_done = true;
+    if (area_handover && w == 0) {
+        for (int l = lane; l < nblk; l += 64)
+            prev_done = prev_done && ((uint32_t)(__hip_atomic_load(done_unit + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == token_prev);
+        prev_done = __all(prev_done);
+    }
     uint64_t cu_seen = 0;
     const uint32_t my_unit = (uint32_t)bgv_s[0] + 1u;
     if (cu_slots && tix == 0) {
@@ -308,7 +325,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // lg[t][i]: a packed pair of scaled + masked fp16 logits.  NB == 2: query row m(i) = (i&3) + 8*(i>>2) + 4*hi at columns
     // key0 + n31 (low half) and key0 + 32 + n31 (high half).  NB == 1: rows m(i) (low) and m(i + 8) (high) at column
     // key0 + n31.
-    static_assert(!F16 || D == 64 || D == 128 || D == 256, "scale_div2_finite_h2 is exact for these divisors");
+    static_assert(D == 64 || D == 128 || D == 256, "scale_div2_finite_h2 is exact for these divisors");
     const float rsqrtD_lo = recip_lo(sqrtD, rsqrtD);             // (what rsqrtD leaves of 1 / sqrtD: fk_device.h scale_div2_finite_h2)
     f16x8 pm0, pm1;
     perm_operands(lane, pm0, pm1);
@@ -390,9 +407,8 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #pragma unroll
                     for (int i = 0; i < NW; ++i) {
                         const uint32_t raw = f2h2(acc0[i], NB == 2 ? acc1[i] : acc0[(i + 8) & 15]);             // matmul -> fp16
-                        f32x2 scv;                                                                               // utils.py:94
-                        if constexpr (F16) scv = scale_div2_finite_h2(raw, rsqrtD, rsqrtD_lo);
-                        else scv = scale_div2_finite((f32x2){h2f((uint16_t)(raw & 0xffffu)), h2f((uint16_t)(raw >> 16))}, sqrtD, rsqrtD);
+                        // utils.py:94 (both contracts since round 6: the two-operation quotient on the fp16 pair as it stands)
+                        const f32x2 scv = scale_div2_finite_h2(raw, rsqrtD, rsqrtD_lo);
                         const uint32_t wd = f2h2(scv.x, scv.y);
                         mx16[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, mx16[i]),
                                                                                           __builtin_bit_cast(h16x2, wd)));
@@ -442,7 +458,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         }
         FKF_STAMP(21);
         if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's histogram zeros have reached memory
+        // (rolling launch: the area's previous user must have read its last record -- see `area_handover` above)
+        if (area_handover && w == 0 && !prev_done && !wait_first_granules(done_unit, 1, nblk, token_prev, lane, sp)) s_abort = 1;
         __syncthreads();
+        if (area_handover && s_abort) return;
         if (w == 0 && lane < 32)
             __hip_atomic_store(pmax + ((size_t)bgv_s[s] * nblk + blk) * 32 + lane,
                                granule(token, f32_bits(fmaxf(fmaxf(s_pf[s][0][lane], s_pf[s][1][lane]), fmaxf(s_pf[s][2][lane], s_pf[s][3][lane])))),
@@ -529,9 +548,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
                     const int rB = NB == 2 ? i : (i + 8) & 15;
-                    f32x2 dlt;                                                                   // x - max, per half of the word
-                    if constexpr (F16) dlt = (f32x2){mix_add_h0(lg[t][i], ngm[i]), mix_add_h1(lg[t][i], ngm[rB])};
-                    else dlt = (f32x2){h2f((uint16_t)(lg[t][i] & 0xffffu)), h2f((uint16_t)(lg[t][i] >> 16))} - (f32x2){gm[i], gm[rB]};
+                    const f32x2 dlt = (f32x2){mix_add_h0(lg[t][i], ngm[i]), mix_add_h1(lg[t][i], ngm[rB])};    // x - max, per half of the word
                     const f32x2 e = det_expf2_clamped(dlt);
                     keep(t, i, e);
                     uint32_t h0, l0, h1, l1;
@@ -682,7 +699,6 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
             for (int i4 = 0; i4 < 2 * NB; ++i4) {
                 // one packed pair per step: every operation below is per component what the scalar chain does.  NB == 2: the two
                 // column blocks of head i4; NB == 1: heads i4 and i4 + 2 of the one column
-                f32x2 p[4];
                 uint32_t phw[4];                                  // the step's four packed probability pairs
                 f32x4_ parked[2];                                 // this step's four words of a tile whose exponentials wait in LDS
                 if (t >= E_REGS) {
@@ -698,21 +714,14 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     const f32x2 pr = ee * (f32x2){ri[wd], ri[rB]};
                     const uint32_t ph = f2h2(pr.x, pr.y);                                 // utils.py:103 -> fp16
                     phw[u] = ph;
-                    if constexpr (!F16) p[u] = (f32x2){h2f((uint16_t)(ph & 0xffffu)), h2f((uint16_t)(ph >> 16))};
                 }
                 f32x2 a = splat2(0.0f), c;
-                if constexpr (F16) {
-                    // (the fp16 probabilities are added as they are: mixed fma, the same fp32 additions in the same order)
+                // (the fp16 probabilities are added as they are: mixed fma, the same fp32 additions in the same order)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) a = (f32x2){mix_add_h0(phw[u], a.x), mix_add_h1(phw[u], a.y)};
-                    c = (f32x2){__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
+                for (int u = 0; u < 4; ++u) a = (f32x2){mix_add_h0(phw[u], a.x), mix_add_h1(phw[u], a.y)};
+                c = (f32x2){__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) c = (f32x2){mix_add_h0(phw[u], c.x), mix_add_h1(phw[u], c.y)};
-                } else {
-                    a = a + p[0]; a = a + p[1]; a = a + p[2]; a = a + p[3];
-                    c = (f32x2){__shfl_xor(a.x, 32, 64), __shfl_xor(a.y, 32, 64)};     // upper half: the lower half's sums of rows 0-3
-                    c = c + p[0]; c = c + p[1]; c = c + p[2]; c = c + p[3];
-                }
+                for (int u = 0; u < 4; ++u) c = (f32x2){mix_add_h0(phw[u], c.x), mix_add_h1(phw[u], c.y)};
                 if (hi) {
                     if (NB == 2) {
                         if (i4 < HV) {
@@ -983,6 +992,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     if (tune & 1) __builtin_amdgcn_s_setprio(3);
     phaseA(S0{});
     if (tune & 1) __builtin_amdgcn_s_setprio(0);
+    if (area_handover && s_abort) return false;                  // (uniform: read behind phase A's barrier)
     FKF_STAMP(1);
     if (NS == 2) phaseA(S1{});
     FKF_STAMP(2);
@@ -1004,6 +1014,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     FKF_STAMP(12);
     if (NS == 2) { if (!read_halo(S1{})) return false; FKF_STAMP(13); phaseD_any(S1{}); }
     FKF_STAMP(14);
+    // this workgroup has read its last hand-off record (row maxima, row sums, halo: all behind barriers above): the area may go to
+    // entry e + 2 F once every workgroup of the unit has said so
+    if (rolling && tix == 0) __hip_atomic_store(done_unit + blk, granule(token, 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cu_slots && tix == 0 && (uint32_t)(cu_seen >> 32) == token && (uint32_t)cu_seen != my_unit)
         __hip_atomic_fetch_add(host_flag + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return true;
@@ -1025,11 +1038,11 @@ __global__ void __launch_bounds__(256, WPE) score_fused_kernel(const uint16_t *_
                                                              int64_t *__restrict__ all_idx, uint16_t *__restrict__ all_keys,
                                                              int64_t all_key_stride, int VH, uint64_t *__restrict__ chain,
                                                              uint32_t *__restrict__ host_flag, uint64_t spin_ticks, const uint64_t *__restrict__ q_tab,
-                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, int rolling, int start_delay, int parts, int tune)
+                                                             const uint64_t *__restrict__ k_tab, int HV, int b0, int BG_total, uint32_t sub, int ncu, uint32_t *__restrict__ place, uint64_t *__restrict__ cu_slots, uint64_t *__restrict__ done, int rolling, int start_delay, int parts, int tune)
 {
     (void)score_fused_body<D, PER, NB, NS, F16, WPE>(k, ks_b, ks_h, ks_s, q, qs_b, qs_h, qs_s, H, Hkv, S, sqrtD, rsqrtD, edges, pmax, psum, ctrl, zero_area,
                                            zero_words, ksize, pooling, c_out, c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag,
-                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, rolling, start_delay, parts, tune);
+                                           spin_ticks, q_tab, k_tab, HV, b0, BG_total, sub, ncu, place, cu_slots, done, rolling, start_delay, parts, tune);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1077,23 +1090,17 @@ template <int D, int PER, int NB, int NS, bool F16, int WPE = 2> struct FusedLau
 };
 
 // Calls f(FusedLaunch<D, PER, NB, NS, F16>{}) for the runtime shape; false if that combination is not instantiated.
-template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, bool f16, F &&f, int wpe = 2)
+template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns, bool f16, F &&f)
 {
-    // three workgroups per compute unit: the mfma16 contract's two-tiles-per-wave size only (the rolling launch's entries, round 5)
-    if (wpe == 3) {
-        if (per == 2 && nb == 2 && ns == 1 && f16) {
-            if (D == 64) { f(FusedLaunch<64, 2, 2, 1, true, 3>{}); return true; }
-            if (D == 128) { f(FusedLaunch<128, 2, 2, 1, true, 3>{}); return true; }
-        }
-        return false;
-    }
 #define FK_CASE(DV, PV, NBV, NSV, FV) if (D == DV && per == PV && nb == NBV && ns == NSV && f16 == FV) { f(FusedLaunch<DV, PV, NBV, NSV, FV>{}); return true; }
 #define FK_CASES_D(DV, FV)                                                                                          \
     FK_CASE(DV, 1, 1, 1, FV) FK_CASE(DV, 1, 2, 1, FV) FK_CASE(DV, 2, 2, 1, FV) FK_CASE(DV, 4, 2, 1, FV)      /* (32-key tiles only ever come one per wave) */
     FK_CASES_D(64, false) FK_CASES_D(128, false) FK_CASES_D(256, false)
     FK_CASES_D(64, true) FK_CASES_D(128, true) FK_CASES_D(256, true)
+#ifdef FK_EXPERIMENTS
     // two streams (experiment, fp32 contract only): head dim 128, one tile per stream and wave
     FK_CASE(128, 2, 1, 2, false) FK_CASE(128, 2, 2, 2, false)
+#endif
 #undef FK_CASES_D
 #undef FK_CASE
     return false;
@@ -1104,7 +1111,7 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
 // round 5 at -3 ... -5 us per eight-layer launch (203.7 / 206.0 / 204.5 -> 200.7 / 201.1 / 201.7 us, alternating runs on one box)
 static int fused_tune()
 {
-    static const int t = []() { const char *e = getenv("FASTKV_FUSED_TUNE"); return e ? atoi(e) : 1; }();
+    static const int t = exp_env_int("FASTKV_FUSED_TUNE", 1);
     return t;
 }
 
@@ -1124,15 +1131,21 @@ static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn,
 // smallest size (four tiles per wave).  false: no such plan (short prompts: many entries fit a regular launch anyway).
 static int rolling_pert_min()
 {
-    static const int v = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_PERT"); return e ? atoi(e) : 4; }();     // measurement aid
+    static const int v = exp_env_int("FASTKV_FUSED_ROLLING_PERT", 4);     // measurement aid
     return v;
+}
+// the rolling launch under the fp32-fma-chain contract (round 6): FASTKV_FUSED_ROLLING_FMAF=0 restores round 5's launches of two
+static bool rolling_fmaf()
+{
+    static const bool on = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_FMAF"); return !(e && e[0] == '0'); }();
+    return on;
 }
 static bool rolling_plan_for(const fastkv_problem &p, int UH, bool f16, int &F, int &parts, FusedPlan &ph)
 {
-    static const int f_cap = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_F"); const int v = e ? atoi(e) : 8; return v < 8 ? v : 8; }();
+    static const int f_cap = []() { const int v = exp_env_int("FASTKV_FUSED_ROLLING_F", 8); return v < 8 ? v : 8; }();
     F = 0; parts = 1;
     const int pert_min = rolling_pert_min();
-    static const int parts_min = []() { const char *e = getenv("FASTKV_FUSED_ROLLING_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();   // measurement aid
+    static const int parts_min = []() { const int v = exp_env_int("FASTKV_FUSED_ROLLING_PARTS", 1); return v >= 1 ? v : 1; }();   // measurement aid
     for (int pp = parts_min; pp <= 8 && pp <= UH && !F; pp *= 2) {
         if (UH % pp) break;
         for (int f = f_cap; f >= 2 && !F; --f)
@@ -1146,7 +1159,7 @@ static bool rolling_plan_for(const fastkv_problem &p, int UH, bool f16, int &F, 
 int fused_entries_per_launch(const fastkv_problem &p)
 {
     const bool disabled = no_wait_mode();
-    static const int ns_pref_env = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
+    static const int ns_pref_env = exp_env_int("FASTKV_FUSED_STREAMS", 1) == 2 ? 2 : 1;
     const int G = p.H / p.Hkv, VH = G < 4 ? 1 : G / 4;
     const bool f16 = resolve_engine(p) == ENGINE_MFMA16;
     const int ns_pref = f16 ? 1 : ns_pref_env;      // (two streams under the mfma16 contract: built and measured in round 4, 58 vs 42 us per one-layer launch: not instantiated)
@@ -1156,7 +1169,7 @@ int fused_entries_per_launch(const fastkv_problem &p)
     int best = 0;
     for (int cand = 1; cand <= 64; ++cand)
         if (fused_plan_for(p, p.Hkv * VH, ns_pref, cand, pl, f16)) best = cand;
-    if (!best && f16 && VH == 1 && rolling_flag().load(std::memory_order_relaxed)) {
+    if (!best && (f16 || rolling_fmaf()) && VH == 1 && rolling_flag().load(std::memory_order_relaxed)) {
         // a row too long for a regular launch: the rolling launch takes it in parts, EPOCH_STRIDE entries (= parts) per call at most
         int F = 0, parts = 1;
         if (rolling_plan_for(p, p.Hkv * VH, f16, F, parts, pl) && parts > F) best = EPOCH_STRIDE / parts;
@@ -1170,7 +1183,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 {
     const bool disabled = no_wait_mode();
     // FASTKV_FUSED_STREAMS=2: the two-heads-per-workgroup experiment (measured slower, see the kernel's comment); default 1
-    static const int ns_pref_env = []() { const char *e = getenv("FASTKV_FUSED_STREAMS"); return (e && e[0] == '2') ? 2 : 1; }();
+    static const int ns_pref_env = exp_env_int("FASTKV_FUSED_STREAMS", 1) == 2 ? 2 : 1;
     // virtual heads of 4 query heads per KV head; a group of 1-3 query heads (MHA, G = 2 models, the per-query-head rule's
     // views) is ONE block whose missing heads are zero queries: a quarter to three quarters of the block's matrix work is
     // spent on rows nobody reads, and the launch still beats the three staged kernels with their logits round trip
@@ -1205,6 +1218,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     // rolling launch: on a shared or partly occupied GPU a harmless displacement would otherwise fail the caller's prefill with
     // FASTKV_EPLACEMENT and drop the process to the no-wait kernels for good.
     uint64_t *cu_slots = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8));
+    uint64_t *done = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + (size_t)FUSED_CU_SLOTS * 8);   // rolling launch: one "done" granule per (unit, span) of a record area
     if (FKH_OLD_NUMBERING) cu_slots = nullptr;                   // (hunt builds: other units share compute units by design, every workgroup would report)
     uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
     // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
@@ -1227,7 +1241,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     static hipEvent_t chain_ev[16];
     std::lock_guard<std::mutex> lk(mtx);
     {
-        static const bool chain_off = []() { const char *e = getenv("FASTKV_CHAIN"); return e && e[0] == '0'; }();   // measurement aid
+        static const bool chain_off = exp_env_int("FASTKV_CHAIN", 1) == 0;   // measurement aid
         int dev = 0;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (!chain_off && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && hipStreamIsCapturing(st, &cs) == hipSuccess &&
@@ -1258,7 +1272,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         const bool rolling_on = rolling_flag().load(std::memory_order_relaxed) != 0;
         // how far entry 1 stays behind: ~ the K streaming time of one entry alone (bytes of K at 5 TB/s), in 100 MHz ticks (6 / 12 / 19 /
         // 25 us behind at 32k: 200 / 199 / 203 / 208 us for eight layers)
-        static const int stagger_env = []() { const char *e = getenv("FASTKV_FUSED_STAGGER_US"); return e ? atoi(e) : -1; }();
+        static const int stagger_env = exp_env_int("FASTKV_FUSED_STAGGER_US", -1);
         const int stagger_ticks = stagger_env >= 0 ? stagger_env * 100 : (int)((double)p.Hkv * p.S * p.D * 2.0 / 5.0e12 * 1.0e8);
         FusedPlan ph;
         // F = entries on the chip at a time: as many as fit with four tiles per wave (the smallest entry the kernel is built for).  32k
@@ -1266,44 +1280,18 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
         // Prompts whose rows do not fit half of the chip even then (beyond 32k tokens at 8 KV heads) are split: an entry is 1 / parts of a
         // row's units (4 heads at 64k, 2 at 128k, 1 at 256k), the parts of a row follow each other like entries do -- the units of a row
         // share nothing but the row's inputs.  (FASTKV_FUSED_ROLLING_F caps F: a measurement switch.)
-        // ---- Round 5: THREE workgroups per compute unit (FASTKV_FUSED_OCC3, csrc/fused.hip score_fused_kernel<..., WPE = 3>).  The launch
-        // above holds two entries of four tiles per wave: two waves per SIMD, each of which spends half of its life waiting for a hand-off
-        // (profiles/r04d_pmc_mfma_summary.json: SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.49, 26 % vector issue, 34 % of HBM).  With two tiles per wave
-        // an entry is 512 workgroups of 168 registers and 51 KiB of LDS: 768 of them are resident -- one and a half entries, three waves per
-        // SIMD in three different phases -- and the grid order does the staggering: the second half of entry e + 1 starts as the workgroups
-        // of entry e leave.  Hand-offs are per unit (a KV head's 64 workgroups, dispatched together), record areas rotate over four entries
-        // (768 consecutive workgroups touch three entries at most).  16k < rows <= 32k tokens at 8 KV heads for now.
-        {
-            static const int occ3_env = []() { const char *e = getenv("FASTKV_FUSED_OCC3"); return e ? atoi(e) : 0; }();
-            const int nwt64 = (p.S + 63) / 64, nblk3 = (nwt64 + 7) / 8, wgs3 = UH * nblk3;
-            bool res3 = false;
-            if (rolling_on && occ3_env && f16 && VH == 1 && p.B >= 3 && p.B <= EPOCH_STRIDE && wgs3 > 256 && wgs3 <= 512 && 4 * wgs3 <= FUSED_MAX_WGS &&
-                fused_dispatch(p.D, 2, 2, 1, true, [&](auto fl) { res3 = decltype(fl)::resident(3 * device_cus()); }, 3) && res3) {
-                const dim3 grid(wgs3, p.B);
-                ProfScope ps_(K_FUSED, st);
-                fused_dispatch(p.D, 2, 2, 1, true, [&](auto fl) {
-                    decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
-                                         p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
-                                         c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                         pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr, (uint64_t *)nullptr, 2,
-                                         occ3_env >= 2 ? stagger_ticks * (occ3_env - 1) / 4 : 0, 1, fused_tune());
-                }, 3);
-                *err = hipGetLastError();
-                return true;
-            }
-        }
         int F = 0, parts = 1;
         const bool have_plan = rolling_plan_for(p, UH, f16, F, parts, ph);
         const int entries = p.B * parts;
         // (VH == 1: the head-sum chain of models with more than four query heads per KV head has room for two entries' spans only)
-        if (rolling_on && f16 && VH == 1 && have_plan && (sb * parts <= F || rolling_pert_min() < 4) && entries > F && entries <= EPOCH_STRIDE) {
+        if (rolling_on && (f16 || rolling_fmaf()) && VH == 1 && have_plan && (sb * parts <= F || rolling_pert_min() < 4) && entries > F && entries <= EPOCH_STRIDE) {
             const dim3 grid(ph.nblk * (UH / parts), entries);
             ProfScope ps_(K_FUSED, st);
             fused_dispatch(p.D, ph.PERT, ph.NBV, 1, f16, [&](auto fl) {
                 decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                      p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                      c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, F, stagger_ticks / parts * 2 / F, parts, fused_tune());     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
+                                     pt ? pt->k : nullptr, HV, 0, p.B * p.Hkv, 0u, device_cus(), (uint32_t *)nullptr /* (the placement record holds 1024 workgroups) */, (uint64_t *)nullptr, done, F, stagger_ticks / parts * 2 / F, parts, fused_tune());     // (the F starts spread over two K-streaming times of an entry: 32k 13 us apart, 16k 3.4, 8k 0.8 -- measured flat below that, worse above)
             });
             *err = hipGetLastError();
             return true;
@@ -1322,7 +1310,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, 0, 0, 1, 0);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, done, 0, 0, 1, 0);
         });
         *err = hipGetLastError();
         b0 += take;
@@ -1332,7 +1320,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
 
 static bool fused_plan_for(const fastkv_problem &p, int UH, int ns_pref, int Bn, FusedPlan &pl, bool f16, int max_wgs)
 {
-    static const int cap_env = []() { const char *e = getenv("FASTKV_FUSED_MAX_WGS"); return e ? atoi(e) : 0; }();     // measurement aid
+    static const int cap_env = exp_env_int("FASTKV_FUSED_MAX_WGS", 0);     // measurement aid
     if (cap_env > 0 && cap_env < max_wgs && (int64_t)Bn * UH <= cap_env) max_wgs = cap_env;
     // 64-key wave tiles, or 32-key tiles when those would leave more than half of the chip's 1024 SIMDs without a wave
     pl.NBV = (int64_t)Bn * UH * ((p.S + 63) / 64) <= 512 ? 1 : 2;

@@ -127,6 +127,59 @@ static inline float fix_to_f32(uint64_t s)
 }
 
 
+/* ---------------------------------------------------------------- the softmax, one contract + two REFERENCE-ORDER modes (tests only)
+ *
+ * utils.py:103 is torch's CPU softmax in fp32 (`softmax(x, dim=-1, dtype=torch.float32)`), rounded to fp16.  Its arithmetic on the
+ * AVX-512 build of torch 2.10 (aten/src/ATen/native/cpu/SoftMaxKernel.cpp vec_softmax_lastdim; established in round 6 by running
+ * the installed torch against this restatement: 0 of 11 M fp32 outputs differ, rows of 777 .. 100,003 elements,
+ * tests/golden/make_golden.py `softmax_probe`):
+ *     m = max_j x_j;   e_j = Sleef_expf16_u10(x_j - m)  (at::vec::Vectorized<float>::exp);
+ *     sum = 16 lane-wise SEQUENTIAL fp32 sums (lane l adds elements l, l + 16, l + 32, ...; a ragged tail goes to lanes 0 .. r-1),
+ *           then the horizontal tree  l += l+8,  l += l+4,  l += l+2,  l += l+1;
+ *     p_j = e_j * (1.0f / sum).
+ * The lane count is the vector width of the HOST: the same torch on an AVX2 machine sums 8 lanes (Sleef_expf8_u10 is the same
+ * algorithm) and gives other fp16 probabilities in ~2e-4 of the elements.  A denominator whose value depends on the
+ * summation order cannot be sharded over workgroups or GPUs, so the CONTRACT the HIP kernels share (FK_SOFTMAX_CONTRACT, the
+ * default) sums in 2^-40 fixed point (order-free) and uses det_expf; the two modes below exist so that the tests can show what is
+ * left between the contract and the reference: with the fma-chain contraction AND FK_SOFTMAX_TORCH_AVX512 this file reproduces
+ * the reference's logits, probabilities, scores and index sets BIT FOR BIT on every golden and on all 1080 rows of the wide sweep
+ * (tests/test_oracle_golden.py::test_reference_order_softmax_reproduces_the_reference_bit_for_bit).  The modes are not part of
+ * the product: the HIP library has no twin of them.
+ */
+#define FK_SOFTMAX_CONTRACT 0
+#define FK_SOFTMAX_TORCH_AVX512 1
+#define FK_SOFTMAX_TORCH_AVX2 2
+static int g_softmax = FK_SOFTMAX_CONTRACT;
+void fastkv_oracle_set_softmax(int m) { g_softmax = (m == FK_SOFTMAX_TORCH_AVX512 || m == FK_SOFTMAX_TORCH_AVX2) ? m : FK_SOFTMAX_CONTRACT; }
+int fastkv_oracle_get_softmax(void) { return g_softmax; }
+
+/* SLEEF's single-precision exp with 1.0 ulp bound (`xexpf`, src/libm/sleefsimdsp.c of SLEEF 3.x -- a third-party dependency of
+ * torch, third_party/sleef, absent from /root/reference), restated from its published algorithm with fma where the AVX2 / AVX-512
+ * builds use fma: Cody-Waite reduction by ln2 in two pieces, degree-5 polynomial, 1 + (s*s*u + s), scaling by 2^q in two factors;
+ * below -104 the result is 0.  Pinned against the installed torch: 0 of 131,072 values differ from what torch.softmax computes
+ * (tests/golden/make_golden.py `softmax_probe`; tests/golden/softmax_probe.npz holds the vectors). */
+static inline float sleef_expf_u10(float d)
+{
+    if (!(d >= -104.0f)) return (d != d) ? d : 0.0f;
+    if (d > 100.0f) return INFINITY;
+    const int32_t q = (int32_t)rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    float s = fmaf((float)q, -0.693145751953125f, d);
+    s = fmaf((float)q, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    const int32_t q1 = q >> 1, q2 = q - q1;
+    u = u * bits_f32((uint32_t)((q1 + 0x7f) << 23));
+    u = u * bits_f32((uint32_t)((q2 + 0x7f) << 23));
+    return u;
+}
+/* the exponential of the selected softmax mode */
+static inline float soft_expf(float d) { return g_softmax == FK_SOFTMAX_CONTRACT ? det_expf(d) : sleef_expf_u10(d); }
+
 /* ---------------------------------------------------------------- the contraction, two arithmetic contracts
  *
  * utils.py:94 is an fp16 matmul with fp32 accumulation in an UNSPECIFIED order (0.1 % of the reference's own fp16 logits move by
@@ -152,7 +205,7 @@ static inline float fix_to_f32(uint64_t s)
  */
 #define FK_CONTRACT_FMAF 0
 #define FK_CONTRACT_MFMA16 1
-static int g_contraction = FK_CONTRACT_MFMA16;
+static int g_contraction = FK_CONTRACT_FMAF;         /* the default since round 6: the contraction that IS the reference's, bit for bit */
 void fastkv_oracle_set_contraction(int c) { g_contraction = c == FK_CONTRACT_FMAF ? FK_CONTRACT_FMAF : FK_CONTRACT_MFMA16; }
 int fastkv_oracle_get_contraction(void) { return g_contraction; }
 
@@ -389,15 +442,37 @@ static void row_stats(const uint16_t *row, int S, float *rmax, float *rinv)
 {
     float m = -INFINITY; int has_nan = 0;
     for (int j = 0; j < S; j++) { float x = h2f(row[j]); if (x != x) has_nan = 1; if (x > m) m = x; }
-    uint64_t acc_hi = 0, acc_lo = 0;
-    for (int j = 0; j < S; j++) {
-        uint32_t hi, lo;
-        float e = det_expf(h2f(row[j]) - m);
-        if (e != e) { has_nan = 1; continue; }
-        exp_to_fix(e, &hi, &lo);
-        acc_hi += hi; acc_lo += lo;
+    float sum;
+    if (g_softmax != FK_SOFTMAX_CONTRACT) {
+        /* torch's order (see "the softmax" above): LN lane-wise sequential fp32 sums, the ragged tail into the first lanes, then
+         * the horizontal tree; a row shorter than a vector is summed element by element (vec_reduce_all of a partial vector) */
+        const int LN = g_softmax == FK_SOFTMAX_TORCH_AVX512 ? 16 : 8;
+        float lane[16];
+        if (S < LN) {
+            sum = sleef_expf_u10(h2f(row[0]) - m);
+            for (int j = 1; j < S; j++) sum = sum + sleef_expf_u10(h2f(row[j]) - m);
+        } else {
+            const int full = S - S % LN;
+            for (int l = 0; l < LN; l++) lane[l] = sleef_expf_u10(h2f(row[l]) - m);
+            for (int j = LN; j < full; j += LN)
+                for (int l = 0; l < LN; l++) lane[l] = lane[l] + sleef_expf_u10(h2f(row[j + l]) - m);
+            for (int j = full; j < S; j++) lane[j - full] = lane[j - full] + sleef_expf_u10(h2f(row[j]) - m);
+            for (int w = LN / 2; w >= 1; w /= 2)
+                for (int l = 0; l < w; l++) lane[l] = lane[l] + lane[l + w];
+            sum = lane[0];
+        }
+        if (sum != sum) has_nan = 1;
+    } else {
+        uint64_t acc_hi = 0, acc_lo = 0;
+        for (int j = 0; j < S; j++) {
+            uint32_t hi, lo;
+            float e = det_expf(h2f(row[j]) - m);
+            if (e != e) { has_nan = 1; continue; }
+            exp_to_fix(e, &hi, &lo);
+            acc_hi += hi; acc_lo += lo;
+        }
+        sum = fix_to_f32((acc_hi << 24) + acc_lo);
     }
-    float sum = fix_to_f32((acc_hi << 24) + acc_lo);
     *rmax = m;
     *rinv = has_nan ? NAN : 1.0f / sum;
 }
@@ -408,11 +483,20 @@ static void rowsum_chunk(const uint16_t *L, int S, int W, const float *rmax, con
     for (int j = j_lo; j < j_hi; j++) {
         float a = 0.0f;
         for (int r = 0; r < W; r++) {
-            float e = det_expf(h2f(L[(int64_t)r * S + j]) - rmax[r]);
+            float e = soft_expf(h2f(L[(int64_t)r * S + j]) - rmax[r]);
             a = a + h2f(f2h(e * rinv[r]));
         }
         s_out[j] = f2h(a);
     }
+}
+
+/* The fp16 probabilities themselves (utils.py:103 after `.to(fp16)`), all S columns of the W rows of one (b, h): the stage-level pin
+ * of tests/test_oracle_golden.py (the scores only ever use columns < n). */
+static void probs_chunk(const uint16_t *L, int S, int W, const float *rmax, const float *rinv, int j_lo, int j_hi, uint16_t *P)
+{
+    for (int r = 0; r < W; r++)
+        for (int j = j_lo; j < j_hi; j++)
+            P[(int64_t)r * S + j] = f2h(soft_expf(h2f(L[(int64_t)r * S + j]) - rmax[r]) * rinv[r]);
 }
 
 /* ---------------------------------------------------------------- stage 3: pooling */
@@ -444,9 +528,9 @@ static void pool_chunk(const uint16_t *s, int n, int ksize, int pooling, int j_l
 /* c[b,g,j] (utils.py:93-112) and optionally t[b,j] = fp16(sum_g c[b,g,j]) (utils.py:127).
  * logits_out (optional): [B,H,W,S] fp16 scaled+masked logits, for kernel-level tests.
  * Every stage is parallel over (row, chunk of positions) so that the CPU baseline uses all host cores. */
-int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
-                             int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
-                             uint16_t *c_out, uint16_t *t_out, uint16_t *logits_out)
+static int scores_impl(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
+                       int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
+                       uint16_t *c_out, uint16_t *t_out, uint16_t *logits_out, uint16_t *probs_out)
 {
     if (!q || !k || !c_out || B < 1 || Hkv < 1 || H < Hkv || H % Hkv || D < 1 || W < 1 || S <= W) return FK_EINVAL;
     if (ksize < 1 || !(ksize & 1) || (pooling != 0 && pooling != 1)) return FK_EINVAL;
@@ -491,6 +575,14 @@ int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_
             int lo = c * CH, hi = lo + CH < n ? lo + CH : n;
             rowsum_chunk(L + (size_t)bh * W * S, S, W, rmax + (size_t)bh * W, rinv + (size_t)bh * W, lo, hi, srow + (size_t)bh * n);
         }
+    if (probs_out) {
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+        for (int bh = 0; bh < BH; bh++)
+            for (int c = 0; c < nchS; c++) {
+                int lo = c * CH, hi = lo + CH < S ? lo + CH : S;
+                probs_chunk(L + (size_t)bh * W * S, S, W, rmax + (size_t)bh * W, rinv + (size_t)bh * W, lo, hi, probs_out + (size_t)bh * W * S);
+            }
+    }
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int bh = 0; bh < BH; bh++)
         for (int c = 0; c < nchN; c++) {
@@ -523,6 +615,21 @@ int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_
     if (!logits_out) free(L);
     free(srow); free(pooled); free(qf); free(qh); free(rmax); free(rinv);
     return FK_OK;
+}
+
+int fastkv_oracle_scores_f16(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
+                             int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
+                             uint16_t *c_out, uint16_t *t_out, uint16_t *logits_out)
+{
+    return scores_impl(q, qs, k, ks, B, H, Hkv, S, D, W, ksize, pooling, c_out, t_out, logits_out, NULL);
+}
+/* the same with the two internal stages the reference's goldens pin (tests/golden/make_golden.py spies them): logits_out = the
+ * fp16 tensor that enters the softmax (utils.py:94-101), probs_out = what leaves it (utils.py:103), both [B,H,W,S] */
+int fastkv_oracle_stages_f16(const uint16_t *q, const int64_t *qs, const uint16_t *k, const int64_t *ks,
+                             int B, int H, int Hkv, int S, int D, int W, int ksize, int pooling,
+                             uint16_t *c_out, uint16_t *t_out, uint16_t *logits_out, uint16_t *probs_out)
+{
+    return scores_impl(q, qs, k, ks, B, H, Hkv, S, D, W, ksize, pooling, c_out, t_out, logits_out, probs_out);
 }
 
 /* ---------------------------------------------------------------- canonical top-k */
@@ -832,6 +939,18 @@ int fastkv_oracle_last_query_scores(const uint16_t *q0, const int64_t *qs, const
 }
 
 float fastkv_oracle_det_expf(float d) { return det_expf(d); }
+float fastkv_oracle_sleef_expf(float d) { return sleef_expf_u10(d); }
+/* one softmax row in fp32 under the selected softmax mode (no fp16 rounding of the result): out[j] = soft_exp(x_j - max) * (1 / sum).
+ * The probe of tests/test_oracle_golden.py::test_reference_order_softmax_is_torchs_kernel_bit_for_bit compares it with what the
+ * installed torch produced for the same fp16-valued rows (tests/golden/softmax_probe.npz). */
+int fastkv_oracle_softmax_row_f32(const uint16_t *x16, int S, float *out)
+{
+    if (!x16 || !out || S < 1) return FK_EINVAL;
+    float m, rinv;
+    row_stats(x16, S, &m, &rinv);
+    for (int j = 0; j < S; j++) out[j] = soft_expf(h2f(x16[j]) - m) * rinv;
+    return FK_OK;
+}
 float fastkv_oracle_fix_to_f32(uint64_t s) { return fix_to_f32(s); }
 uint64_t fastkv_oracle_exp_to_fix(float e) { uint32_t hi, lo; exp_to_fix(e, &hi, &lo); return ((uint64_t)hi << 24) + lo; }
 uint16_t fastkv_oracle_f2h(float f) { return f2h(f); }

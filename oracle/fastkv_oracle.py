@@ -25,7 +25,7 @@ _LIB = os.path.join(_HERE, "libfastkv_oracle.so")
 CFLAGS = ["-O3", "-ffp-contract=off", "-mavx2", "-mfma", "-mf16c", "-fopenmp", "-shared", "-fPIC"]
 
 _lib = None
-CONTRACTION_FMAF = 0                                             # (fastkv_oracle.c FK_CONTRACT_FMAF)
+CONTRACTION_FMAF, CONTRACTION_MFMA16 = 0, 1                      # (fastkv_oracle.c FK_CONTRACT_FMAF / FK_CONTRACT_MFMA16)
 
 
 def build(force: bool = False) -> str:
@@ -73,13 +73,18 @@ def lib() -> ctypes.CDLL:
         L.fastkv_oracle_get_contraction.restype = ci
         L.fastkv_oracle_mfma16_tiles.argtypes = [vp, vp, vp, vp, ci, ci]
         L.fastkv_oracle_mfma16_tiles.restype = ci
+        L.fastkv_oracle_stages_f16.argtypes = [vp, i64p, vp, i64p] + [ci] * 8 + [vp, vp, vp, vp]
+        L.fastkv_oracle_stages_f16.restype = ci
+        L.fastkv_oracle_set_softmax.argtypes = [ci]
+        L.fastkv_oracle_get_softmax.restype = ci
+        L.fastkv_oracle_sleef_expf.argtypes = [ctypes.c_float]
+        L.fastkv_oracle_sleef_expf.restype = ctypes.c_float
         L.fastkv_oracle_set_threads.argtypes = [ci]
         L.fastkv_oracle_get_threads.restype = ci
-        # the default contract follows FASTKV_CONTRACTION, like the HIP side's "auto" (capi.hip default_contract_f16): a process started with
-        # FASTKV_CONTRACTION=fmaf -- the contract to run for accuracy / parity work -- compares fma chain with fma chain without every caller
-        # having to say so
-        if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F"):
-            L.fastkv_oracle_set_contraction(CONTRACTION_FMAF)
+        # the default contract follows FASTKV_CONTRACTION, like the HIP side's "auto" (capi.hip default_contract_f16): the fp32 fma chain
+        # unless the process was started with FASTKV_CONTRACTION=mfma16 (the HIP side's opt-in fast mode) -- a suite run under either
+        # compares like with like without every caller having to say so
+        L.fastkv_oracle_set_contraction(CONTRACTION_MFMA16 if os.environ.get("FASTKV_CONTRACTION", "fmaf")[:1] in ("m", "M") else CONTRACTION_FMAF)
         _lib = L
     return _lib
 
@@ -103,14 +108,54 @@ assert CONTRACTION["fmaf"] == 0
 
 
 def set_contraction(name: str) -> None:
-    """The arithmetic contract of the contraction (utils.py:94; fastkv_oracle.c "the contraction"): "mfma16" (default) = what the
-    gfx950 fp16 matrix instruction computes, "fmaf" = the fp32 fma chain.  The HIP side's twins: ops.set_score_engine("mfma16") /
-    ("mfma" | "valu"); "auto" there follows FASTKV_CONTRACTION."""
+    """The arithmetic contract of the contraction (utils.py:94; fastkv_oracle.c "the contraction"): "fmaf" (default) = the fp32 fma
+    chain, "mfma16" = what the gfx950 fp16 matrix instruction computes.  The HIP side's twins: ops.set_score_engine("mfma" | "valu") /
+    ("mfma16"); "auto" there follows FASTKV_CONTRACTION."""
     lib().fastkv_oracle_set_contraction(CONTRACTION[name])
 
 
 def get_contraction() -> str:
     return {v: k for k, v in CONTRACTION.items()}[int(lib().fastkv_oracle_get_contraction())]
+
+
+SOFTMAX = {"contract": 0, "torch_avx512": 1, "torch_avx2": 2}
+
+
+def set_softmax(name: str) -> None:
+    """TESTS ONLY (fastkv_oracle.c "the softmax"): "contract" (default) = the arithmetic the HIP kernels share -- det_expf, 2^-40
+    fixed-point denominator; "torch_avx512" / "torch_avx2" = the reference's own torch CPU kernel restated (SLEEF exp, 16 / 8
+    lane-wise sequential fp32 sums + tree): with the "fmaf" contraction the oracle then reproduces the reference bit for bit.  The
+    HIP library has no twin of these modes."""
+    lib().fastkv_oracle_set_softmax(SOFTMAX[name])
+
+
+def get_softmax() -> str:
+    return {v: k for k, v in SOFTMAX.items()}[int(lib().fastkv_oracle_get_softmax())]
+
+
+def stages(q: torch.Tensor, k: torch.Tensor, window: int = 8, kernel_size: int = 7, pooling: str = "avgpool"):
+    """(c [B,Hkv,n], t [B,n], logits [B,H,W,S], probabilities [B,H,W,S]), fp16: the scores and the two internal stages the
+    stage-level goldens pin -- what enters the reference's softmax (utils.py:94-101) and what leaves it (utils.py:103)."""
+    B, H, S, D = q.shape
+    Hkv = k.shape[1]
+    n = S - window
+    c = torch.empty(B, Hkv, n, dtype=torch.float16)
+    t = torch.empty(B, n, dtype=torch.float16)
+    lg = torch.empty(B, H, window, S, dtype=torch.float16)
+    pr = torch.empty(B, H, window, S, dtype=torch.float16)
+    _check(lib().fastkv_oracle_stages_f16(q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), B, H, Hkv, S, D, window, kernel_size,
+                                          POOLING[pooling], c.data_ptr(), t.data_ptr(), lg.data_ptr(), pr.data_ptr()), "stages")
+    return c, t, lg, pr
+
+
+def softmax_row_f32(x: torch.Tensor) -> torch.Tensor:
+    """One softmax row in fp32 under the selected softmax mode, for a 1-D fp16 row (the probe against torch's kernel)."""
+    assert x.dim() == 1 and x.dtype == torch.float16 and x.is_contiguous()
+    out = torch.empty(x.numel(), dtype=torch.float32)
+    L = lib()
+    L.fastkv_oracle_softmax_row_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    _check(L.fastkv_oracle_softmax_row_f32(x.data_ptr(), x.numel(), out.data_ptr()), "softmax_row")
+    return out
 
 
 def mfma16_tiles(a: torch.Tensor, bt: torch.Tensor, c: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -12,6 +12,12 @@ regenerated from seeds by tests/gen_inputs.py.
 How the internals are captured (the reference never returns them):
   * scores   -- `torch.Tensor.topk` is wrapped by a recording spy for the duration of the call:
                 call #1 sees `attn_cache` [B,Hkv,n] (utils.py:113), call #2 the TSP row (utils.py:127).
+  * logits / probabilities (round 6: the stage-level pin) -- `torch.nn.functional.softmax` is wrapped the same way: its INPUT is the
+                fp16 tensor [B,H,W,S] after matmul, division and window mask (utils.py:94-101), its output rounded to fp16 is what
+                utils.py:103 hands on.  Stored in full for the cases up to 4k tokens, as sha256 + every 64th column for the 32k cases.
+  * `softmax_probe.npz` -- what the installed torch's CPU softmax (fp32) computes for a few fp16-valued rows, and the values of its
+                internal exponential (rows whose sum is exactly 2^14, so that p = exp(x - max) * 2^-14, one exact scaling down to the subnormals): the pin of the oracle's
+                restatement of that kernel (oracle/fastkv_oracle.c "the softmax", FK_SOFTMAX_TORCH_AVX512 / _AVX2).
   * indices  -- V is replaced by a position code (V[...,0]=pos//256, V[...,1]=pos%256, exact in
                 fp16), so `value_states_out[...,0]*256+[...,1]` is the per-head index order.
 """
@@ -46,16 +52,27 @@ def run_reference(q, k, v, case):
                        pooling=case["pooling"], tsp_layer=case["tsp_len"] > 0, tsp_length=case["tsp_len"] or 2048)
     spied = []
     orig = torch.Tensor.topk
+    orig_softmax = torch.nn.functional.softmax
+    stage = {}
 
     def spy(self, *a, **kw):
         spied.append(self.detach().clone())
         return orig(self, *a, **kw)
 
+    def spy_softmax(x, *a, **kw):                               # utils.py:103 (`nn.functional.softmax`, looked up at call time)
+        stage["logits"] = x.detach().clone()                     # fp16 [B,H,W,S]: after utils.py:94-101
+        y = orig_softmax(x, *a, **kw)
+        stage["probs"] = y.detach().to(x.dtype)                  # what `.to(query_states.dtype)` makes of it
+        return y
+
     torch.Tensor.topk = spy
+    torch.nn.functional.softmax = spy_softmax
     try:
         ko, vo, tsp = cl.update_kv(k, q, v, None, q.shape[1] // k.shape[1], 0)
     finally:
         torch.Tensor.topk = orig
+        torch.nn.functional.softmax = orig_softmax
+    run_reference.stage = stage
     return ko, vo, tsp, spied
 
 
@@ -72,6 +89,31 @@ def sha(t: torch.Tensor) -> str:
     return hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
 
 
+def softmax_probe():
+    """What torch's CPU softmax computes (this container: torch 2.10, AVX-512), for the restatement in oracle/fastkv_oracle.c:
+    (1) fp32 outputs for fp16-valued rows of several lengths (ragged tails included); (2) its exponential alone -- rows of 16384
+    zeros followed by values below -10: every lane sum is exactly 1024 and stays there (the tail's exponentials are below half an
+    ulp of it), the sum is 2^14, so p is the exponential the kernel computed times 2^-14 (exact above the subnormals)."""
+    from gen_inputs import normal_f16
+    arrays = {}
+    for i, (S, scale) in enumerate(((777, 3.0), (4096, 2.0), (32768, 3.0), (32768, 1.0), (100003, 3.0), (24, 2.0), (9, 1.0))):
+        x = (torch.from_numpy(normal_f16(900 + i, 1, S).astype(np.float32)) * scale).to(torch.float16)
+        y = torch.nn.functional.softmax(x[None].float(), dim=-1)[0]
+        arrays["row%d_x" % i] = x.view(torch.int16).numpy()
+        arrays["row%d_p" % i] = y.view(torch.int32).numpy()
+    u = torch.from_numpy(normal_f16(950, 1, 16384).astype(np.float32))
+    t = (-(u.abs() * 12.0 + 10.0)).to(torch.float16)             # -10 .. about -60 and beyond
+    t[:8] = torch.tensor([-10.0, -87.0, -88.0, -103.5, -104.0, -104.5, -200.0, -60000.0], dtype=torch.float16)
+    x = torch.cat([torch.zeros(16384, dtype=torch.float16), t])
+    y = torch.nn.functional.softmax(x[None].float(), dim=-1)[0]
+    assert float(y[0]) == 2.0 ** -14
+    arrays["exp_x"] = t.view(torch.int16).numpy()
+    arrays["exp_p"] = y[16384:].contiguous().view(torch.int32).numpy()      # = exp(x) * 2^-14 (one fp32 product; subnormal below x = -77.6)
+    arrays["torch_config"] = np.array([torch.__version__, "AVX512" if "AVX512" in torch.__config__.show() else "other"])
+    np.savez_compressed(os.path.join(HERE, "softmax_probe.npz"), **arrays)
+    print("softmax_probe ok", torch.__version__)
+
+
 def main():
     meta = {}
     for name, case in CASES.items():
@@ -80,6 +122,8 @@ def main():
         ko, vo, tsp, spied = run_reference(q, k, v, case)
         c_ref = spied[0]
         t_ref = spied[1] if len(spied) > 1 else None
+        lg_ref, pr_ref = run_reference.stage["logits"], run_reference.stage["probs"]
+        assert lg_ref.shape == pr_ref.shape == (case["B"], case["H"], case["W"], case["S"]) and lg_ref.dtype == pr_ref.dtype == torch.float16
         # second run with position-coded V to expose the reference's index order
         _, vcode, _, _ = run_reference(q, k, position_code(v), case)
         kk = case["cap"] - case["W"]
@@ -100,6 +144,13 @@ def main():
             arrays["c_ref_sampled"] = c_ref[..., ::st].contiguous().view(torch.int16).numpy()
             if t_ref is not None:
                 arrays["t_ref_sampled"] = t_ref[..., ::st].contiguous().view(torch.int16).numpy()
+        # the two internal stages: full for the small cases, every 64th column (+ sha256 in meta.json) for the 32k cases
+        if case["S"] <= 4096:
+            arrays["logits_ref"] = lg_ref.view(torch.int16).numpy()
+            arrays["probs_ref"] = pr_ref.view(torch.int16).numpy()
+        else:
+            arrays["logits_ref_sampled"] = lg_ref[..., ::64].contiguous().view(torch.int16).numpy()
+            arrays["probs_ref_sampled"] = pr_ref[..., ::64].contiguous().view(torch.int16).numpy()
         # canonical top-k of the reference's own scores (value desc, index asc), index-ascending order
         can = torch.empty(B, Hkv, kk, dtype=torch.int64)
         ties = np.zeros((B, Hkv, 3), dtype=np.int64)      # k-th value bits, #strictly greater, #equal
@@ -125,9 +176,12 @@ def main():
             arrays["tsp_canonical"] = tcan.to(torch.int32).numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
         meta[name] = {"case": case, "sha256_c_ref": sha(c_ref), "sha256_t_ref": sha(t_ref) if t_ref is not None else None,
+                      "sha256_logits_ref": sha(lg_ref), "sha256_probs_ref": sha(pr_ref),
                       "sha256_k_out": sha(ko), "sha256_v_out": sha(vo), "tsp_is_none": tsp is None,
                       "out_strides_k": list(ko.stride()), "out_contiguous": bool(ko.is_contiguous())}
         print(name, "ok", {k_: a.shape for k_, a in arrays.items()})
+
+    softmax_probe()
 
     # ---- host logic goldens (utils.py:25-46, :82-91, :123-132) -------------------------------
     host = {}

@@ -46,21 +46,39 @@ torch.set_num_threads(8)
 O.set_threads(8)
 
 
-def run_reference(q, k, v, case):
+STAGE_DIGESTS = {}          # case name -> (digest of the reference's logits, of its probabilities): the wide sweep's stage-level pin
+
+
+def tensor_digest(t) -> int:
+    """64-bit digest of a tensor's bytes (fp16 bit patterns)."""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(t.contiguous().view(torch.int16).numpy().tobytes(), digest_size=8).digest(), "little")
+
+
+def run_reference(q, k, v, case, name=None):
     cl = FastKVCluster(window_size=case["W"], max_capacity_prompt=case["cap"], kernel_size=case["ks"],
                        pooling=case["pooling"], tsp_layer=True, tsp_length=case["tsp_len"])
     spied = []
     orig = torch.Tensor.topk
+    orig_softmax = torch.nn.functional.softmax
 
     def spy(self, *a, **kw):
         spied.append(self.detach().clone())
         return orig(self, *a, **kw)
 
+    def spy_softmax(x, *a, **kw):                               # utils.py:103: input = the logits after utils.py:94-101
+        y = orig_softmax(x, *a, **kw)
+        if name is not None:
+            STAGE_DIGESTS[name] = (tensor_digest(x), tensor_digest(y.to(x.dtype)))
+        return y
+
     torch.Tensor.topk = spy
+    torch.nn.functional.softmax = spy_softmax
     try:
         cl.update_kv(k, q, v, None, q.shape[1] // k.shape[1], 0)
     finally:
         torch.Tensor.topk = orig
+        torch.nn.functional.softmax = orig_softmax
     return spied[0], spied[1]
 
 
@@ -90,23 +108,51 @@ def wilson(k, n, z=1.96):
     return [max(0.0, mid - half), min(1.0, mid + half)]
 
 
-def sweep_one(contraction, refs, arrays, cases=None, compact=False):
+def sweep_one(contraction, refs, arrays, cases=None, compact=False, softmax="contract"):
     """The oracle under one contraction contract against the reference runs in `refs`; fills `arrays` (reference-only data: the same
     for every contraction) and returns {"cases": ..., "summary": ...}.  `compact` (the wide sweep): `arrays` gets a digest per row, the
     tie metadata, and the full canonical row only where the row flips under this contraction."""
     cases = SWEEP_CASES if cases is None else cases
     O.set_contraction(contraction)
+    O.set_softmax(softmax)
     meta = {"cases": {}}
     tot_rows = tot_straddle = tot_flip_rows = tot_flips = tot_mism = tot_el = tot_invalid = max_ulp = 0
+    tot_logit_mism = tot_logit_el = tot_prob_cases_equal = 0
     fam = {}
     for name, case in cases.items():
         q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
         if name not in refs:
-            c_, t_ = run_reference(q, k, v, case)
+            c_, t_ = run_reference(q, k, v, case, name if compact else None)
             refs[name] = (c_, t_) if not compact else (c_.clone(), t_.clone())
         c_ref, t_ref = refs[name]
         _, _, idx_or, tsp_or, c_or, t_or = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"],
                                                        "index", return_scores=True)
+        stage = None
+        if compact:
+            # the stage-level pin: the oracle's logits / probabilities against the reference's (digests; the element count of the
+            # logits that differ needs the reference's tensor, which is recomputed here once per contraction and dropped again)
+            _, _, lg_or, pr_or = O.stages(q, k, case["W"], case["ks"], case["pooling"])
+            stage = {"logits_equal": tensor_digest(lg_or) == STAGE_DIGESTS[name][0], "probs_equal": tensor_digest(pr_or) == STAGE_DIGESTS[name][1]}
+            if not stage["logits_equal"]:
+                grab = {}
+                orig_softmax = torch.nn.functional.softmax
+
+                def spy_softmax(x, *a, **kw):
+                    grab["x"] = x.detach().clone()
+                    return orig_softmax(x, *a, **kw)
+
+                torch.nn.functional.softmax = spy_softmax
+                try:
+                    FastKVCluster(window_size=case["W"], max_capacity_prompt=case["cap"], kernel_size=case["ks"], pooling=case["pooling"],
+                                  tsp_layer=True, tsp_length=case["tsp_len"]).update_kv(k, q, v, None, q.shape[1] // k.shape[1], 0)
+                finally:
+                    torch.nn.functional.softmax = orig_softmax
+                stage["logits_that_differ"] = int((bits(lg_or) != bits(grab["x"])).sum())
+            else:
+                stage["logits_that_differ"] = 0
+            tot_logit_mism += stage["logits_that_differ"]
+            tot_logit_el += lg_or.numel()
+            tot_prob_cases_equal += int(stage["probs_equal"])
         B, Hkv, n = c_ref.shape
         kk, tk = case["cap"] - case["W"], case["tsp_len"] - case["W"]
         d = (bits(c_or) - bits(c_ref)).abs()
@@ -140,6 +186,9 @@ def sweep_one(contraction, refs, arrays, cases=None, compact=False):
         trf = t_ref[0].float()
         tvalid = set(torch.nonzero(trf > tvk).flatten().tolist()) <= tgot <= set(torch.nonzero(trf >= tvk).flatten().tolist())
         if compact:
+            arrays[name + ".stage_dig"] = np.array(STAGE_DIGESTS[name], dtype=np.uint64)          # reference logits, probabilities
+            arrays[name + ".c_dig"] = np.array([[tensor_digest(c_ref[b, g]) for g in range(Hkv)] for b in range(B)], dtype=np.uint64)
+            arrays[name + ".t_dig"] = np.array([tensor_digest(t_ref[0])], dtype=np.uint64)
             arrays[name + ".dig"] = np.array([[row_digest(can[b, g].numpy()) for g in range(Hkv)] for b in range(B)], dtype=np.uint64)
             arrays[name + ".tsp_dig"] = np.array([row_digest(tcan.numpy())], dtype=np.uint64)
             arrays[name + ".ties"] = ties
@@ -161,6 +210,7 @@ def sweep_one(contraction, refs, arrays, cases=None, compact=False):
         if compact:                                               # (keep the meta small: per row only what is not the default)
             m["rows"] = [r for r in rows if r["flips"] or r["straddling"] or not r["valid_topk_of_reference_scores"]]
             m["rows_total"] = len(rows)
+            m["stage"] = stage
         meta["cases"][name] = m
         f = fam.setdefault(case.get("family", "all"), dict(cases=0, rows=0, flip_rows=0, flips=0, invalid=0, mism=0, el=0))
         f["cases"] += 1
@@ -187,6 +237,11 @@ def sweep_one(contraction, refs, arrays, cases=None, compact=False):
                        "rows_whose_set_is_not_a_valid_topk_of_the_reference_scores": tot_invalid,
                        "row_flip_rate_ci95": wilson(tot_flip_rows, tot_rows), "invalid_row_rate": tot_invalid / tot_rows,
                        "invalid_row_rate_ci95": wilson(tot_invalid, tot_rows)}
+    if compact:
+        meta["summary"].update({"logit_elements": tot_logit_el, "logits_that_differ_from_the_reference": tot_logit_mism,
+                                "logit_mismatch_rate": tot_logit_mism / max(1, tot_logit_el),
+                                "cases_whose_probabilities_equal_the_reference_bit_for_bit": tot_prob_cases_equal})
+    O.set_softmax("contract")
     meta["families"] = {k_: dict(v_, mismatch_rate=v_["mism"] / v_["el"], row_flip_rate=v_["flip_rows"] / v_["rows"],
                                  row_flip_rate_ci95=wilson(v_["flip_rows"], v_["rows"]), invalid_row_rate=v_["invalid"] / v_["rows"],
                                  invalid_row_rate_ci95=wilson(v_["invalid"], v_["rows"])) for k_, v_ in fam.items()}
@@ -204,6 +259,13 @@ def main_wide():
         meta["contractions"][contraction] = sweep_one(contraction, refs, arrays, SWEEP_WIDE_CASES, compact=True)
         print(contraction, json.dumps(meta["contractions"][contraction]["summary"], indent=1))
         print(contraction, json.dumps(meta["contractions"][contraction]["families"], indent=1))
+    # round 6: the oracle with the fma chain AND the reference-order softmax (torch's AVX-512 kernel restated; its AVX2 twin beside it):
+    # what is left between the contract and the reference is exactly the denominator's summation order (+ the exp polynomial)
+    meta["reference_order"] = {}
+    for sm in ("torch_avx512", "torch_avx2"):
+        r = sweep_one("fmaf", refs, {}, SWEEP_WIDE_CASES, compact=True, softmax=sm)
+        meta["reference_order"][sm] = {"summary": r["summary"], "families": r["families"]}
+        print("fmaf +", sm, json.dumps(r["summary"], indent=1))
     np.savez_compressed(os.path.join(HERE, "sweep_wide.npz"), **arrays)
     with open(os.path.join(HERE, "sweep_wide_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -39,25 +39,23 @@ def expected_kv(k: torch.Tensor, idx: torch.Tensor, window: int) -> torch.Tensor
 
 
 # ---------------------------------------------------------------------------------------------- the two contraction contracts
-# oracle/fastkv_oracle.c "the contraction": "fmaf" = the fp32 fma chain (HIP engines "valu" / "mfma"), "mfma16" = the gfx950 fp16 matrix
-# instruction on the fp16 operands (HIP engine "mfma16"; the default of both sides).  The reference's own fp16 matmul (torch CPU)
-# accumulates in yet another order; how far each contract's fp16 SCORES are from the reference's was measured on the goldens, on the
-# 24-case sweep (tests/golden/sweep_meta.json) and on the 120-case WIDE sweep of round 5 (sweep_wide_meta.json: 35.4 M scores per contract,
-# randn + peaked inputs): fmaf 3.3e-4 of the elements (2 ulp at most; its accumulation order resembles torch's), mfma16 8.8e-4 (up to 6 ulp
-# on PEAKED inputs, where a 1-ulp logit difference of a heavy hitter moves its probability by several ulps) -- about the distance an
-# EXACTLY rounded dot product has from the reference (9.7e-4).  The gates below hold on the GOLDEN cases (measured there
-# with headroom: fmaf is SURVEY 8(c)'s own gate, mfma16 the wider one this contract needs); the wide sweep has its own bounds
-# (tests/test_oracle_golden.py WIDE_BOUNDS).  The index-level protocol is the same for both.  For accuracy / parity work against the
-# reference run the fma chain: FASTKV_CONTRACTION=fmaf (HIP side), O.set_contraction("fmaf") (oracle).
-CONTRACTIONS = ("mfma16", "fmaf")
+# oracle/fastkv_oracle.c "the contraction": "fmaf" = the fp32 fma chain (HIP engines "valu" / "mfma"; the default of both sides since
+# round 6), "mfma16" = the gfx950 fp16 matrix instruction on the fp16 operands (HIP engine "mfma16"; FASTKV_CONTRACTION=mfma16).
+# Against the REFERENCE (round 6, stage by stage: tests/test_oracle_golden.py): the fma chain reproduces the reference's fp16 LOGITS bit
+# for bit (0 of 1.0e9 over the wide sweep) and what is left at the SCORES -- 3.3e-4 of the elements, 2 ulp at most -- is the softmax
+# denominator's summation order alone (the oracle's reference-order mode removes all of it); the matrix instruction moves 1e-3 of the
+# logits by an ulp before the softmax starts: 8.8e-4 of the scores, up to 6 ulp on PEAKED inputs.  The gates below hold on the GOLDEN
+# cases (fmaf is SURVEY 8(c)'s own gate, mfma16 the wider one that contract needs); the wide sweep has its own bounds
+# (tests/test_oracle_golden.py WIDE_BOUNDS).  The index-level protocol is the same for both.
+CONTRACTIONS = ("fmaf", "mfma16")
 ENGINES_OF = {"fmaf": ("mfma", "valu"), "mfma16": ("mfma16",)}
 CONTRACTION_OF_ENGINE = {"valu": "fmaf", "mfma": "fmaf", "mfma16": "mfma16"}
 SCORE_GATES = {"fmaf": dict(max_ulp=1, frac=0.001, floor=1), "mfma16": dict(max_ulp=2, frac=0.002, floor=3)}
 
 
 def default_contraction() -> str:
-    """What "auto" means on the HIP side of THIS process (FASTKV_CONTRACTION; mfma16 unless set) -- and the oracle's default."""
-    return "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16"
+    """What "auto" means on the HIP side of THIS process (FASTKV_CONTRACTION; fmaf unless set to mfma16) -- and the oracle's default."""
+    return "mfma16" if os.environ.get("FASTKV_CONTRACTION", "fmaf")[:1] in ("m", "M") else "fmaf"
 
 
 def assert_score_parity(got: torch.Tensor, ref: torch.Tensor, contraction: str, what: str = "") -> None:

@@ -90,9 +90,6 @@ def test_70k_prefill_every_layer_against_the_oracle(monkeypatch):
     """A prompt beyond what a regular fused scoring launch holds (70,000 tokens): the three layers in front of and including the TSP
     layer are compressed TOGETHER -- one rolling launch whose entries are halves of a layer's KV heads (csrc/fused.hip) -- and every
     layer's cache equals the oracle's."""
-    from helpers import default_contraction
-    if default_contraction() != "mfma16":
-        pytest.skip("layers beyond 64k tokens are grouped through the rolling launch, which exists under the mfma16 contract only")
     _prefill_against_the_oracle("llama", "1", monkeypatch, 70000, 4, 2, [3, 1])
 
 

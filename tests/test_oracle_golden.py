@@ -1,10 +1,15 @@
 """Pins the CPU oracle (oracle/fastkv_oracle.c) against golden vectors captured from the reference
 (tests/golden/make_golden.py ran /root/reference/baselines/fastkv/utils.py:80-134 in the build container).
 
+Round 6 pins the reference STAGE BY STAGE (logits, probabilities, scores, indices): under the fma-chain contraction the oracle's
+logits are the reference's bit for bit, and with the reference-order softmax mode (torch's AVX-512 kernel restated) so is everything
+behind them -- on every golden and on all 1080 rows of the wide sweep (test_stage_goldens_*, test_reference_order_softmax_*).  What
+the CONTRACT (the arithmetic the HIP kernels share) leaves open is the softmax denominator's summation order, bounded as follows.
+
 Protocol: (1) scores within the contract's gate (tests/helpers.py SCORE_GATES: the fp32 fma chain
 <= 1 fp16 ulp on <= 0.1 % of the elements, as SURVEY wrote it; the fp16 matrix instruction <= 2 ulp on <= 0.2 % on
 these goldens, measured up to 6 ulp on the peaked family of the wide sweep) -- the reference's
-own torch kernels are not reproducible to the last bit across accumulation orders; (2) canonical top-k of
+own torch softmax is not reproducible to the last bit across vector widths; (2) canonical top-k of
 the REFERENCE's scores == oracle indices, bit-identical; (3) the reference's own (arbitrary-on-ties) pick
 lies between {c > v_k} and {c >= v_k}; (4) K/V rows are exact copies; (5) TSP index = canonical."""
 import numpy as np
@@ -73,6 +78,111 @@ def test_oracle_matches_reference_golden(name, contraction):
         assert torch.equal(tsp[:, -case["W"]:], torch.arange(n, case["S"]).expand(case["B"], -1))
     else:
         assert tsp is None
+
+
+# ------------------------------------------------------------------------------------------------ stage-level pins (round 6)
+def _sha(t: torch.Tensor) -> str:
+    import hashlib
+    return hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+def _nbits(a: torch.Tensor, b: torch.Tensor) -> int:
+    return int((a.contiguous().view(torch.int16) != b.contiguous().view(torch.int16)).sum())
+
+
+# How far the CONTRACT's fp16 probabilities (det_expf, 2^-40 fixed-point denominator) may be from the reference's (utils.py:103), as a
+# fraction of the elements: measured 6.3e-5 (cfg1) ... 1.0e-4 (cfg2_max: 850 of 8,388,608) under the fma chain -- all of it the
+# denominator's summation order (the reference-order mode below removes every one of them); the matrix-instruction contract adds the
+# probabilities its 1e-3 of differing logits move.
+PROB_GATE = {"fmaf": 3e-4, "mfma16": 1.5e-3}
+LOGIT_GATE_MFMA16 = 1.5e-3          # fraction of the fp16 logits the matrix-instruction contract moves (measured 8.5e-4 ... 1.0e-3, 1 ulp each)
+
+
+@pytest.mark.parametrize("name", SMALL + BIG)
+def test_stage_goldens_logits_and_probabilities(name):
+    """VERDICT r05 next #1 (a)-(c).  The reference's two internal stages, captured by tests/golden/make_golden.py through a spy on
+    `nn.functional.softmax`: LOGITS = the fp16 tensor after matmul, division and window mask (utils.py:94-101), PROBABILITIES = what
+    utils.py:103 hands on.  Against them, per case:
+      * contraction "fmaf": the oracle's logits ARE the reference's -- 0 mismatches, every golden (torch's CPU fp16 matmul is the
+        ascending fp32 fma chain); "mfma16" moves up to ~1e-3 of them by one ulp (stated and bounded beside it);
+      * the contract's softmax (det_expf, fixed-point denominator): probabilities within PROB_GATE of the reference's;
+      * "fmaf" + the reference-order softmax (torch's AVX-512 kernel restated: SLEEF exp, 16 lane sums + tree): probabilities, scores
+        (c and t) and canonical indices equal the reference's BIT FOR BIT -- what separates contract and reference is exactly the
+        denominator's summation order (and the exp polynomial, which changes no fp16 value on its own)."""
+    case = CASES[name]
+    g, meta = load_golden(name), load_meta()[name]
+    q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
+    full = "logits_ref" in g
+
+    def against(lg, pr):
+        """(logits that differ, probabilities that differ) on what the fixture holds; sha256 of both."""
+        if full:
+            return _nbits(lg, f16_from_bits(g["logits_ref"])), _nbits(pr, f16_from_bits(g["probs_ref"])), _sha(lg), _sha(pr)
+        return (_nbits(lg[..., ::64], f16_from_bits(g["logits_ref_sampled"])), _nbits(pr[..., ::64], f16_from_bits(g["probs_ref_sampled"])),
+                _sha(lg), _sha(pr))
+
+    try:
+        O.set_contraction("fmaf")
+        O.set_softmax("contract")
+        c, t, lg, pr = O.stages(q, k, case["W"], case["ks"], case["pooling"])
+        dl, dp, sl, sp_ = against(lg, pr)
+        assert dl == 0 and sl == meta["sha256_logits_ref"], (name, "fmaf logits differ from the reference's", dl)
+        nel = pr.numel() if full else pr[..., ::64].numel()
+        assert dp <= max(2, int(PROB_GATE["fmaf"] * nel)), (name, "fmaf / contract softmax", dp, nel)
+        O.set_softmax("torch_avx512")
+        c, t, lg, pr = O.stages(q, k, case["W"], case["ks"], case["pooling"])
+        dl, dp, sl, sp_ = against(lg, pr)
+        assert dl == 0 and dp == 0 and sl == meta["sha256_logits_ref"] and sp_ == meta["sha256_probs_ref"], (name, dl, dp)
+        assert _sha(c) == meta["sha256_c_ref"], name
+        if case["tsp_len"]:
+            assert _sha(t) == meta["sha256_t_ref"], name
+        kk = case["cap"] - case["W"]
+        for b in range(case["B"]):
+            for h in range(case["Hkv"]):
+                assert torch.equal(O.canonical_topk(c[b, h].contiguous(), kk, "index"), torch.from_numpy(g["idx_canonical"][b, h].astype(np.int64)))
+        O.set_softmax("contract")
+        O.set_contraction("mfma16")
+        c, t, lg, pr = O.stages(q, k, case["W"], case["ks"], case["pooling"])
+        dl, dp, _, _ = against(lg, pr)
+        nl = lg.numel() if full else lg[..., ::64].numel()
+        assert 0 < dl <= max(3, int(LOGIT_GATE_MFMA16 * nl)) and dp <= max(3, int(PROB_GATE["mfma16"] * nl)), (name, "mfma16", dl, dp, nl)
+    finally:
+        O.set_softmax("contract")
+
+
+def test_reference_order_softmax_is_torchs_kernel_bit_for_bit():
+    """The pin of the reference-order softmax modes (oracle/fastkv_oracle.c "the softmax"): tests/golden/softmax_probe.npz holds what the
+    installed torch's CPU softmax (fp32; this container's build uses AVX-512) computed for fp16-valued rows of 9 ... 100,003 elements, and
+    the values of its internal exponential (rows whose sum is exactly 2^14).  The restatement -- SLEEF's expf_u10, 16 lane-wise sequential
+    sums with the ragged tail in the first lanes, horizontal tree, p = e * (1 / sum) -- reproduces every fp32 bit; the contract's own
+    softmax (other exp polynomial, order-free fixed-point sum) does not, nor does the 8-lane (AVX2) order: the test is not vacuous."""
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "softmax_probe.npz"))
+    L = O.lib()
+    ex, ep = z["exp_x"].view(np.float16).astype(np.float32), z["exp_p"]        # p = exp(x) * 2^-14 as the kernel computed it
+    scale = np.float32(2.0 ** -14)
+    got = (np.array([L.fastkv_oracle_sleef_expf(float(x)) for x in ex], dtype=np.float32) * scale).view(np.int32)
+    assert np.array_equal(got, ep), int((got != ep).sum())
+    assert int((ep == 0).sum()) >= 4 and int(((ep > 0) & (ep < 0x00800000)).sum()) >= 1       # (zeros below -104 and subnormals are in there)
+    det = (np.array([L.fastkv_oracle_det_expf(float(x)) for x in ex[:4096]], dtype=np.float32) * scale).view(np.int32)
+    assert 0 < int((det != ep[:4096]).sum())                                    # (another polynomial: ~1e-1 of the values differ by an ulp)
+    rows = sorted(int(kf[3:-2]) for kf in z.files if kf.startswith("row") and kf.endswith("_x"))
+    assert len(rows) >= 6
+    differs = {"contract": 0, "torch_avx2": 0}
+    try:
+        for i in rows:
+            x = torch.from_numpy(z["row%d_x" % i].copy()).view(torch.float16)
+            want = torch.from_numpy(z["row%d_p" % i].copy())
+            O.set_softmax("torch_avx512")
+            got = O.softmax_row_f32(x).view(torch.int32)
+            assert torch.equal(got, want), (i, x.numel(), int((got != want).sum()))
+            for mode in differs:
+                O.set_softmax(mode)
+                differs[mode] += int((O.softmax_row_f32(x).view(torch.int32) != want).sum())
+    finally:
+        O.set_softmax("contract")
+    assert differs["contract"] > 0 and differs["torch_avx2"] > 0, differs
 
 
 @pytest.mark.parametrize("contraction", CONTRACTIONS)
@@ -318,6 +428,66 @@ def test_wide_sweep_statistics_and_replay(contraction):
         q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
         _, _, idx, tsp = O.update_kv(q, k, v, case["W"], case["ks"], case["pooling"], case["cap"], case["tsp_len"], "index")
         check_against_wide_sweep(name, idx, tsp, z, meta)
+
+
+def _tensor_digest(t: torch.Tensor) -> int:
+    """tests/golden/make_sweep.py tensor_digest: 64-bit digest of a tensor's fp16 bit patterns."""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(t.contiguous().view(torch.int16).numpy().tobytes(), digest_size=8).digest(), "little")
+
+
+def test_reference_order_softmax_reproduces_the_reference_bit_for_bit():
+    """VERDICT r05 next #1 (b) + (c), on the inputs of the 120-case wide sweep (S = 32768, Llama-3-8B geometry, randn + peaked): with the
+    fma-chain contraction AND the reference-order softmax (torch's AVX-512 kernel restated) the oracle reproduces the reference
+    (baselines/fastkv/utils.py:94-113,127, captured by tests/golden/make_sweep.py) BIT FOR BIT at every stage -- the logits
+    (0 of 1,006,632,960), the probabilities (every case), all 35.4 M scores and the canonical index set of all 1080 rows (8 KV heads +
+    the TSP row per case).  "Pinned within a gate" thereby becomes "bit-exact modulo one documented degree of freedom": what separates
+    the CONTRACT (det_expf, order-free 2^-40 fixed-point denominator: the same bits for any tiling and any sequence sharding) from
+    the reference is the softmax denominator's summation order -- which the reference itself does not hold fixed: with the 8-lane
+    order of an AVX2 host it is 7.1e-4 of the scores / 20 rows away from its AVX-512 self (committed beside: the contract is 3.3e-4 /
+    8 rows away).  Every case is replayed here; the committed summary is checked against the replay."""
+    import json
+    import os
+    from golden_cases import SWEEP_WIDE_CASES
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "sweep_wide.npz"))
+    with open(os.path.join(GOLDEN, "sweep_wide_meta.json")) as f:
+        meta = json.load(f)
+    ro = meta["reference_order"]
+    s512, s2 = ro["torch_avx512"]["summary"], ro["torch_avx2"]["summary"]
+    assert s512["cases"] == 120 and s512["rows"] == 1080 and s512["score_elements"] == 35380800
+    assert s512["mismatching_scores"] == 0 and s512["rows_that_flip"] == 0 and s512["rows_whose_set_is_not_a_valid_topk_of_the_reference_scores"] == 0
+    assert s512["logits_that_differ_from_the_reference"] == 0 and s512["logit_elements"] == 1006632960
+    assert s512["cases_whose_probabilities_equal_the_reference_bit_for_bit"] == 120
+    fm, mf = meta["contractions"]["fmaf"]["summary"], meta["contractions"]["mfma16"]["summary"]
+    assert fm["logits_that_differ_from_the_reference"] == 0                       # the contract's contraction IS the reference's
+    assert 5e-4 < mf["logit_mismatch_rate"] < 1.5e-3                              # ... the matrix instruction moves ~1e-3 of the logits
+    # the reference against itself on an AVX2 host is FARTHER away than the contract is from the AVX-512 reference
+    assert s2["logits_that_differ_from_the_reference"] == 0 and s2["mismatching_scores"] > fm["mismatching_scores"] > 0
+    assert s2["rows_that_flip"] > fm["rows_that_flip"]
+    try:
+        O.set_contraction("fmaf")
+        O.set_softmax("torch_avx512")
+        rows = 0
+        for name, case in SWEEP_WIDE_CASES.items():
+            q, k, v = make_qkv(case["seed"], case["B"], case["H"], case["Hkv"], case["S"], case["D"], case["W"], peaked=case.get("peaked", 0))
+            c, t, lg, pr = O.stages(q, k, case["W"], case["ks"], case["pooling"])
+            sd = z[name + ".stage_dig"]
+            assert _tensor_digest(lg) == int(sd[0]), (name, "logits")
+            assert _tensor_digest(pr) == int(sd[1]), (name, "probabilities")
+            kk, tk = case["cap"] - case["W"], case["tsp_len"] - case["W"]
+            for g in range(case["Hkv"]):
+                assert _tensor_digest(c[0, g]) == int(z[name + ".c_dig"][0, g]), (name, g, "scores")
+                assert row_digest(O.canonical_topk(c[0, g].contiguous(), kk, "index").numpy()) == int(z[name + ".dig"][0, g]), (name, g, "indices")
+                rows += 1
+            assert _tensor_digest(t[0]) == int(z[name + ".t_dig"][0]), (name, "TSP scores")
+            n = case["S"] - case["W"]
+            tsp = torch.cat([O.canonical_topk(t[0].contiguous(), tk, "index"), torch.arange(n, case["S"])])
+            assert row_digest(tsp.numpy()) == int(z[name + ".tsp_dig"][0]), (name, "TSP index")
+            rows += 1
+        assert rows == 1080
+    finally:
+        O.set_softmax("contract")
 
 
 @pytest.mark.parametrize("contraction", CONTRACTIONS)

@@ -11,15 +11,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _rolling_needs_the_default_contract():
-    """The rolling launch exists under the mfma16 contract only (csrc/fused.hip launch_score_fused): a suite run under
-    FASTKV_CONTRACTION=fmaf -- the contract for accuracy work -- has nothing to test here."""
-    from helpers import default_contraction
-    if default_contraction() != "mfma16":
-        pytest.skip("the rolling launch exists under the mfma16 contract only")
-
-
 def _fused_launches(lib):
     """Scoring launches since the last read (the library's own per-kernel counters: include/fastkv_hip.h fastkv_profile_read)."""
     n = lib.fastkv_profile_kernels()
@@ -83,6 +74,40 @@ def test_rolling_launch_changes_nothing(B, S, ks, pooling, tsp_len, order, poiso
     from fastkv_amd._lib import raise_if_aborted
     raise_if_aborted()
     assert ops.load().fastkv_placement_violations(0) == 0
+
+
+@pytest.mark.parametrize("B,S,slow", [(14, 32768, (0,)), (20, 16384, (1, 2)), (12, 24001, (3,))])
+def test_a_slow_entry_keeps_its_record_area_until_it_has_left(B, S, slow):
+    """Round 6 (found by the first soak of the rolling launch under the fp32-fma-chain contract): the record areas of the rolling launch
+    rotate over 2 F entries, and an entry that is much slower than its successors -- under the fma chain a NaN in a query row sends
+    every tile of that head's workgroups through the vector-ALU redo of phase A -- was still waiting for its head's records when entry
+    e + 2 F, dispatched into places the fast entries had vacated, wrote its own into the same area: the slow entry's waits ran into the
+    spin limit (REPORTED as FASTKV_EABORTED, never wrong).  The hand-over of an area is explicit now ("done" granules, csrc/fused.hip):
+    groups long enough for the rotation to come round while the slow entries are on the chip equal the regular launches bit for
+    bit, and nothing is reported.  (Under the mfma16 contract a NaN costs no time: the same groups, trivially.)"""
+    from fastkv_amd import ops
+    dev = torch.device("cuda:0")
+    H, Hkv, D, W, cap = 32, 8, 128, 8, 2048
+    q, k, v = _inputs(B, H, Hkv, S, D, 7000 + B, dev)
+    for e in slow:                                               # a NaN in a window row of EVERY query head: all of the entry's units redo all their tiles
+        q[e, :, S - 2, 5] = float("nan")
+    prev = ops.set_fused_rolling(True)
+    outs = {}
+    try:
+        for rolling in (True, False, True):
+            ops.set_fused_rolling(rolling)
+            got = ops.update_kv(q, k, v, W, 7, "maxpool", cap, 2048, "score", return_indices=True, return_scores=True)
+            torch.cuda.synchronize()
+            from fastkv_amd._lib import raise_if_aborted
+            raise_if_aborted("slow entry, rolling=%s" % rolling)
+            outs.setdefault(rolling, []).append(got)
+    finally:
+        ops.set_fused_rolling(prev)
+    for got in outs[True]:
+        for a, b, what in zip(got, outs[False][0], ("k_out", "v_out", "tsp_idx", "idx", "scores")):
+            same = torch.equal(a.view(torch.int16), b.view(torch.int16)) if a.dtype == torch.float16 else torch.equal(a, b)
+            assert same, (what, "rolling and regular launches differ")
+    assert not ops.no_wait_mode()
 
 
 @pytest.mark.parametrize("B,S", [(3, 32768), (6, 16384)])
@@ -377,18 +402,19 @@ print('DIGEST', h.hexdigest())
 """
 
 
-def test_the_measurement_switches_of_round_5_change_nothing():
-    """The opt-in paths round 5 left in the library -- FASTKV_FUSED_OCC3=1 (the rolling launch with three workgroups of two tiles per
-    wave on a compute unit), FASTKV_FUSED_TUNE=0 (no raised issue priority while a wave streams K: the default since round 5 is 1), FASTKV_TSP_FOLD=0 (the TSP row sums
-    as a launch of their own again) -- give the operator's outputs bit for bit (five 32k entries, a NaN key and an Inf query among them:
-    K / V rows, TSP index, per-head indices, scores)."""
+def test_the_product_switches_change_nothing():
+    """The switches the product library reads -- FASTKV_TSP_FOLD=0 (the TSP row sums as a launch of their own again), FASTKV_FUSED_ROLLING=0
+    (launches of two entries, in step), FASTKV_FUSED_ROLLING_FMAF=0 (the rolling launch under the mfma16 contract only, as in round 5) -- give
+    the operator's outputs bit for bit (five 32k entries, a NaN key and an Inf query among them: K / V rows, TSP index, per-head indices,
+    scores).  (The measurement switches of rounds 4-5 -- FASTKV_FUSED_TUNE, _ROLLING_PERT / _PARTS / _F, _MAX_WGS, _STAGGER_US, _STREAMS,
+    FASTKV_CHAIN -- are read in -DFK_EXPERIMENTS builds only since round 6; the three-workgroups-per-unit instantiations are gone.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
-    for name, extra in (("default", {}), ("occ3", {"FASTKV_FUSED_OCC3": "1"}), ("occ3_staggered", {"FASTKV_FUSED_OCC3": "3"}),
-                        ("no_setprio", {"FASTKV_FUSED_TUNE": "0"}), ("no_fold", {"FASTKV_TSP_FOLD": "0"}), ("no_rolling", {"FASTKV_FUSED_ROLLING": "0"})):
+    for name, extra in (("default", {}), ("no_fold", {"FASTKV_TSP_FOLD": "0"}), ("no_rolling", {"FASTKV_FUSED_ROLLING": "0"}),
+                        ("no_rolling_fmaf", {"FASTKV_FUSED_ROLLING_FMAF": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", _SWITCH_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "DIGEST" in r.stdout, (name, r.stdout[-800:] + r.stderr[-1500:])
