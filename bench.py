@@ -660,8 +660,12 @@ def contract_line(world, steps, warmup, ms_per_step, contraction, ranks_seen, ba
            # matrix instruction on the fp16 operands, restated bit for bit by the oracle
            "contraction": contraction, "ranks_seen": ranks_seen, "backend": backend,
            # the fused launches' own check of where their workgroups ran (include/fastkv_hip.h: fastkv_placement_violations): 0 = every
-           # pair of workgroups that shared a compute unit in the warm-up and timed steps belonged to one head, as the kernel assumes
-           "placement_violations": violations}
+           # pair of workgroups that shared a compute unit in a REGULAR launch of the warm-up and timed steps belonged to one head, as
+           # those launches assume.  `placement_check` says which launches count at all (a 0 from launches that do not arm
+           # the check would be vacuous): the rolling launches -- two of the step's three scoring launches -- never do
+           "placement_violations": violations,
+           "placement_check": {"regular_launches": "armed (fma chain: the placement policy acts on the count, fail safe by default; mfma16: counted only)",
+                               "rolling_launches": "not armed: entries share compute units out of step by design (soaks: profiles/r06_soak_*.log)"}}
     if os.environ.get("FASTKV_FUSED") == "0":
         out["no_wait_kernels"] = "FASTKV_FUSED=0: staged scoring + wait-free selection (what ranks that share one GPU must run)"
     out["config"]["schedule"] = ("deferred, as baselines/fastkv/_wiring.py runs it by default: the 16 layers behind the TSP layer in ONE launch "
@@ -952,7 +956,7 @@ def main():
                                                  "compaction launches (deferred schedule: 8 two-layer launches at 32k + one for the 16 post-TSP layers)",
                               "roofline_shape": compact_roofline_shape(lib, dev, 10)}
             # the same (default, deferred) step under the OTHER contraction contract: the fp32 fma chain on v_mfma_f32_32x32x2_f32
-            # (rounds 1-3's only contract; FASTKV_CONTRACTION=fmaf makes it the default of the library)
+            # (fmaf <-> mfma16: whichever the line's headline is not)
             other = "mfma" if out["contraction"] == "mfma16" else "mfma16"
             ops.set_score_engine(other)
             try:
@@ -1075,14 +1079,24 @@ def finish_multi_rank(a, out, work, rank, world, dev, dist, t_proc0) -> int:
          reported on STDERR (`LEGS_JSON {...}`) and, where the directory exists, in gpurun_out/bench_legs_N<world>.json -- stdout
          carries the one line and nothing else."""
     deadline = float(os.environ.get("FASTKV_BENCH_LINE_DEADLINE_S", "75"))
-    if rank == 0 and not a.no_extras and os.environ.get("FASTKV_FUSED") != "0":     # (the no-wait kernels have no grouped scoring launch to price)
-        try:
-            from fastkv_amd._lib import load
-            rf = quick_group_roofline(load(), work)
-            if rf is not None:
-                out["roofline"] = rf
-        except Exception as e:   # noqa: BLE001 -- an extra of the line
-            out["roofline_error"] = repr(e)[:200]
+    if rank == 0 and not a.no_extras:
+        # the N > 1 line ALWAYS carries a `roofline` object (VERDICT r05 next #6: the driver keeps it among the parsed keys; a line
+        # without one would lose the kernel's figure to the extra-key truncation).  Ranks that share one GPU (the rehearsal:
+        # FASTKV_FUSED=0, no grouped scoring launch to price) say so in it instead of leaving it out.
+        out["roofline"] = {"kernel": "score_fused", "bound": "mfma" if out["contraction"] == "fmaf" else "hbm", "achieved": None,
+                           "peak": FP32_MATRIX_PEAK_TFLOPS if out["contraction"] == "fmaf" else HBM_PEAK_GBPS,
+                           "unit": "TFLOP/s" if out["contraction"] == "fmaf" else "GB/s", "frac": None, "traffic": None,
+                           "note": "not measured: the no-wait kernels (FASTKV_FUSED=0, ranks sharing a GPU) have no grouped scoring launch"}
+        if os.environ.get("FASTKV_FUSED") != "0":
+            try:
+                from fastkv_amd._lib import load
+                rf = quick_group_roofline(load(), work)
+                if rf is not None:
+                    out["roofline"] = rf
+                else:
+                    out["roofline"]["note"] = "not measured: the grouped scoring launch did not run on rank 0"
+            except Exception as e:   # noqa: BLE001 -- an extra of the line
+                out["roofline"]["note"] = "not measured: " + repr(e)[:200]
     inline = [("seq_sharded_weak", 30.0), ("tp", 30.0)]
     n_inline = 0
     if not a.no_legs:

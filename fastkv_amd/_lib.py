@@ -165,6 +165,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
 _violations_seen = 0
 
 
+_no_wait_warned = False
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         if rc == FASTKV_EPLACEMENT:
@@ -172,6 +175,16 @@ def check(rc: int, what: str) -> None:
             # raise_if_aborted does not warn about them a second time
             global _violations_seen
             _violations_seen = load().fastkv_placement_violations(0)
+        if rc in (FASTKV_EABORTED, FASTKV_EPLACEMENT):
+            # under the fail-safe policy the report that is being raised has switched the process to the no-wait kernels for good
+            # (a given-up wait, a placement violation): say so once -- nothing else tells the caller why every later call is slower
+            global _no_wait_warned
+            if not _no_wait_warned and os.environ.get("FASTKV_FUSED", "1") != "0" and load().fastkv_no_wait_mode():
+                _no_wait_warned = True
+                import warnings
+                warnings.warn(f"fastkv_amd.{what}: the library has switched this process to the no-wait kernels (staged scoring, "
+                              "wait-free selection; as FASTKV_FUSED=0) with the report that follows -- ops.set_no_wait_mode(False) "
+                              "switches back", RuntimeWarning, stacklevel=3)
         msg = load().fastkv_strerror(rc).decode()
         raise FastKVNativeError(f"fastkv_amd.{what}: {msg} (code {rc})", code=rc)
 
@@ -184,17 +197,7 @@ def raise_if_aborted(what: str = "last_status") -> None:
     about everything enqueued before it (benchmark/prefill.py, benchmark/e2e.py); the wiring also calls it un-synchronised at the
     end of every prefill, which reports what has completed by then."""
     L = load()
-    before = bool(L.fastkv_no_wait_mode())
-    try:
-        check(L.fastkv_last_status(), what)
-    finally:
-        if not before and L.fastkv_no_wait_mode():
-            # the report that was just taken (a given-up wait or, under the fail-safe placement policy, a placement violation) switched
-            # the process to the no-wait kernels for good: say so once -- nothing else tells the caller why every later call is slower
-            import warnings
-            warnings.warn(f"fastkv_amd.{what}: the library has switched this process to the no-wait kernels (staged scoring, wait-free "
-                          "selection; as FASTKV_FUSED=0) after the report above -- ops.set_no_wait_mode(False) switches back",
-                          RuntimeWarning, stacklevel=2)
+    check(L.fastkv_last_status(), what)
     global _violations_seen
     total = L.fastkv_placement_violations(0)                # (not reset: bench.py and tests read the running count)
     n, _violations_seen = total - _violations_seen if total >= _violations_seen else total, total

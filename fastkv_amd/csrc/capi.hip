@@ -25,6 +25,7 @@ uint32_t *abort_flag_device()
         reinterpret_cast<volatile uint32_t *>(h)[1] = 0;
         reinterpret_cast<volatile uint32_t *>(h)[2] = 0;
         reinterpret_cast<volatile uint32_t *>(h)[3] = 0;
+        reinterpret_cast<volatile uint32_t *>(h)[4] = 0;         // placement violations that are counted and never reported (mfma16 launches)
         g_abort_host = reinterpret_cast<uint32_t *>(h);
         g_abort_dev = reinterpret_cast<uint32_t *>(d);
     });
@@ -108,6 +109,8 @@ extern "C" int fastkv_placement_violations(int reset)
     // pending (counted by launches, not yet reported) + already reported
     uint64_t v = reset ? __atomic_exchange_n(fk::g_abort_host + 3, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(fk::g_abort_host + 3, __ATOMIC_ACQUIRE);
     v += reset ? fk::g_violations_reported.exchange(0, std::memory_order_relaxed) : fk::g_violations_reported.load(std::memory_order_relaxed);
+    // + what launches of the mfma16 contract counted (word 4: no policy ever acts on it)
+    v += reset ? __atomic_exchange_n(fk::g_abort_host + 4, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(fk::g_abort_host + 4, __ATOMIC_ACQUIRE);
     return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
 }
 

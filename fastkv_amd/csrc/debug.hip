@@ -30,6 +30,15 @@ __global__ void debug_contract_kernel(int op, const float *a, const float *b, fl
         r = fix_to_f32(r64);
         break;
     }
+    case 14: {                                                   // the four-operation twin of the fused kernel's phase B (20 / 20 split, signed low part)
+        const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i];
+        uint32_t h0, l0, h1, l1;
+        exp_to_fix2_magic((i & 1) ? (f32x2){x2, x} : (f32x2){x, x2}, h0, l0, h1, l1);
+        const uint32_t h = ((i & 1) ? h1 : h0) - FIX_MAGIC_BITS, l = ((i & 1) ? l1 : l0) - FIX_MAGIC_BITS;
+        r64 = ((uint64_t)h << 20) + (uint64_t)(int64_t)(int32_t)l;
+        r = fix_to_f32(r64);
+        break;
+    }
     case 12: { const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i]; const uint32_t w = (i & 1) ? f2h2(x2, x) : f2h2(x, x2); r = h2f((uint16_t)((i & 1) ? w >> 16 : w & 0xffffu)); break; }
     case 13: {                                                   // the two-operation quotient of the fused kernel's epilogue (x: an fp16 value)
         const float x2 = a[(i ^ 1) < n ? (i ^ 1) : i];
@@ -99,7 +108,7 @@ extern "C" int fastkv_debug_mfma16(const void *a, const void *bt, const float *c
 
 extern "C" int fastkv_debug_contract(int op, const float *a, const float *b, float *out, uint64_t *out64, int n, void *stream)
 {
-    if (!a || !out || n < 0 || op < 0 || op > 13) return FASTKV_EINVAL;
+    if (!a || !out || n < 0 || op < 0 || op > 14) return FASTKV_EINVAL;
     hipLaunchKernelGGL(fk::debug_contract_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, out64, n);
     return hipGetLastError() == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }

@@ -210,6 +210,25 @@ __device__ __forceinline__ void exp_to_fix2(f32x2 e, uint32_t &hi0, uint32_t &lo
     lo0 = (uint32_t)__builtin_rintf(l.x); lo1 = (uint32_t)__builtin_rintf(l.y);
 }
 
+// The same 2^-40 fixed-point value in FOUR operations per component (round 6), split 20 / 20 with a SIGNED low part:
+//   hi = RNE(e * 2^20),   lo = RNE((e * 2^20 - hi) * 2^20) in [-2^19, 2^19],   hi * 2^20 + lo = RNE(e * 2^40)
+// -- which is what exp_to_fix defines (its trunc / RNE pair is RNE(e * 2^40) as well: hi * 2^24 is an even integer, so rounding the
+// rest to nearest even rounds the whole).  Both roundings are done by the fp32 adder against the magic constant 1.5 * 2^23: the sum
+// t = fma(e, 2^20, M) holds RNE(e * 2^20) in its low mantissa bits (e <= 1: t stays in M's binade, one ulp = 1), h = t - M and
+// r = fma(e, 2^20, -h) are exact, u = fma(r, 2^20, M) holds the signed low part.  What is returned are the RAW BITS of t and u: the
+// caller adds them up as integers and takes count * FIX_MAGIC_BITS off at the end (32-bit wrap-around cancels).  e must not be NaN.
+constexpr uint32_t FIX_MAGIC_BITS = 0x4B400000u;               // 1.5 * 2^23
+__device__ __forceinline__ void exp_to_fix2_magic(f32x2 e, uint32_t &th0, uint32_t &tl0, uint32_t &th1, uint32_t &tl1)
+{
+    const float M = 12582912.0f, S = 1048576.0f;
+    const float t0 = __builtin_fmaf(e.x, S, M), t1 = __builtin_fmaf(e.y, S, M);
+    const float h0 = t0 - M, h1 = t1 - M;
+    const float r0 = __builtin_fmaf(e.x, S, -h0), r1 = __builtin_fmaf(e.y, S, -h1);
+    const float u0 = __builtin_fmaf(r0, S, M), u1 = __builtin_fmaf(r1, S, M);
+    th0 = f32_bits(t0); th1 = f32_bits(t1);
+    tl0 = f32_bits(u0); tl1 = f32_bits(u1);
+}
+
 // scale_div of both components
 __device__ __forceinline__ f32x2 scale_div2(f32x2 x, float c, float rc)
 {

@@ -45,7 +45,7 @@ static inline int exp_env_int(const char *name, int dflt)
 // fastkv_problem.reserved bits 0-1.  Two arithmetic CONTRACTS for the contraction of utils.py:94 (oracle/fastkv_oracle.c, "the
 // contraction"): the fp32 fma chain -- engines VALU and MFMA (v_mfma_f32_32x32x2_f32), bit-identical to each other -- and "mfma16",
 // what v_mfma_f32_32x32x16_f16 computes on the fp16 operands themselves (16x the matrix rate).  AUTO = the library's default
-// contract (FASTKV_CONTRACTION=mfma16 | fmaf, default mfma16) with the engine that suits the shape.
+// contract (FASTKV_CONTRACTION=fmaf | mfma16, default fmaf since round 6) with the engine that suits the shape.
 enum { ENGINE_AUTO = 0, ENGINE_VALU = 1, ENGINE_MFMA = 2, ENGINE_MFMA16 = 3 };
 bool default_contract_f16();      // capi.hip
 

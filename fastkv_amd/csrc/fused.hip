@@ -261,7 +261,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // theirs.  Those workgroups were dispatched long before this one and need nothing from it: the wait cannot deadlock.  The
     // granules are looked at once at the start (in the common case they are all there: the predecessor left the chip an entry's
     // lifetime ago) and polled before the first publish only if they were not.
-    const bool area_handover = rolling && ent >= 2 * rolling;
+    const bool area_handover = rolling && done && ent >= 2 * rolling;      // (done == nullptr: experiments builds only, FASTKV_FUSED_NO_HANDOVER=1)
     const uint32_t token_prev = area_handover ? handoff_token(ctrl[2] + sub + (uint32_t)(ent - 2 * rolling)) : 0u;
     uint64_t *done_unit = done + (size_t)bgv_s[0] * nblk;
     bool prev_done = true;
@@ -278,6 +278,14 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                                         __HIP_MEMORY_SCOPE_AGENT);
     }
     FKF_STAMP(0);
+#ifdef FK_STAMP
+    // (where the wave runs: slot 40 = XCC_ID << 32 | HW_ID, slot 41 = entry << 32 | unit << 16 | span -- tools/stamp_arrivals.py)
+    if (lane == 0) {
+        unsigned long long *row = g_fstamps + (size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) % 4096) * 48;
+        row[40] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+        row[41] = ((unsigned long long)ent << 32) | ((unsigned long long)(yb * UH + hvp) << 16) | (unsigned long long)blk;
+    }
+#endif
     FKH_DELAY_AT_START();
     // Zero what later stages accumulate into.  The key histogram of score row bg is filled in THIS launch (phase D) by the
     // workgroups of bg: they zero it themselves with write-through stores that are drained before their first hand-off record
@@ -520,7 +528,10 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
         float gm[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) gm[i] = s_gm[s][(i & 3) + 8 * (i >> 2) + 4 * hi];
+        // row sums in 2^-40 fixed point, per lane as two 32-bit words: ahi in units of 2^-20, alo (signed) in units of 2^-40
+        // (fk_device.h exp_to_fix2_magic); `nmagic` = elements per accumulator whose raw magic-sum bits are still in there
         uint32_t ahi[16], alo[16], nanbits = 0;
+        int nmagic = 0;
         bool gm_ok = true;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { ahi[i] = 0; alo[i] = 0; gm_ok = gm_ok && __builtin_fabsf(gm[i]) < INFINITY; }
@@ -552,7 +563,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     const f32x2 e = det_expf2_clamped(dlt);
                     keep(t, i, e);
                     uint32_t h0, l0, h1, l1;
-                    exp_to_fix2(e, h0, l0, h1, l1);
+                    exp_to_fix2_magic(e, h0, l0, h1, l1);            // raw bits: the magic constant comes off once, below
                     if (NB == 2) {
                         ahi[i] += h0 + h1;
                         alo[i] += l0 + l1;
@@ -561,6 +572,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                         ahi[rB] += h1; alo[rB] += l1;
                     }
                 }
+                nmagic += NB;                                        // every accumulator took NB elements of this tile
             } else {
                 const bool inA = key0 + n31 < S, inB = NB == 2 ? key0 + 32 + n31 < S : inA;
 #pragma unroll
@@ -570,8 +582,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
                     const f32x2 e = det_expf2(x - (f32x2){gm[i], gm[rB]});
                     keep(t, i, e);
                     uint32_t h0, l0, h1, l1;
-                    exp_to_fix2(e, h0, l0, h1, l1);
                     const bool nan0 = e.x != e.x, nan1 = e.y != e.y;
+                    exp_to_fix2_magic((f32x2){nan0 ? 0.0f : e.x, nan1 ? 0.0f : e.y}, h0, l0, h1, l1);
+                    h0 -= FIX_MAGIC_BITS; l0 -= FIX_MAGIC_BITS; h1 -= FIX_MAGIC_BITS; l1 -= FIX_MAGIC_BITS;
                     if (inA && nan0) nanbits |= 1u << i;
                     if (inB && nan1) nanbits |= 1u << rB;
                     ahi[i] += inA && !nan0 ? h0 : 0u;
@@ -582,12 +595,13 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
             }
         }
         FKF_STAMP(25);
-        // per lane at most 2*PS <= 8 elements per row (hi <= 2^16, lo <= 2^24 each): the 32-bit lane sums are exact; they
+        // per lane at most 2*PS <= 8 elements per row (hi <= 2^20, |lo| <= 2^19 each): the 32-bit lane sums are exact; they
         // are combined to the 2^-40 fixed-point value before the half-wave reduction
         {
             uint64_t tot[16];
+            const uint32_t off = (uint32_t)nmagic * FIX_MAGIC_BITS;     // (wave-uniform; 32-bit wrap-around cancels)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) tot[i] = ((uint64_t)ahi[i] << 24) + alo[i];
+            for (int i = 0; i < 16; ++i) tot[i] = ((uint64_t)(ahi[i] - off) << 20) + (uint64_t)(int64_t)(int32_t)(alo[i] - off);
             const uint64_t r = halfwave_reduce16(tot, lane, [](uint64_t a, uint64_t b2) { return a + b2; });
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) nanbits |= (uint32_t)__shfl_xor((int)nanbits, o, 64);
@@ -1016,9 +1030,9 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     FKF_STAMP(14);
     // this workgroup has read its last hand-off record (row maxima, row sums, halo: all behind barriers above): the area may go to
     // entry e + 2 F once every workgroup of the unit has said so
-    if (rolling && tix == 0) __hip_atomic_store(done_unit + blk, granule(token, 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rolling && done && tix == 0) __hip_atomic_store(done_unit + blk, granule(token, 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cu_slots && tix == 0 && (uint32_t)(cu_seen >> 32) == token && (uint32_t)cu_seen != my_unit)
-        __hip_atomic_fetch_add(host_flag + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(host_flag + (F16 ? 4 : 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (word 4: counted, never reported -- capi.hip)
     return true;
 }
 
@@ -1212,13 +1226,17 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
     const uint64_t spin_ticks = spin_limit_ticks();
     uint64_t *edges = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * 32 * 24);   // [unit span][2][4][31] halo granules
     uint32_t *zero = reinterpret_cast<uint32_t *>(ws + L.off_hist);
-    // The placement check (fastkv_placement_violations) guards the compute-unit pairing of the fp32-fma-chain contract: the hazard it
-    // fences off needs that contract's matrix phase (K from LDS into fp16 MFMAs, those into fp32 MFMAs) beside packed-fp32 arithmetic
-    // (docs/HISTORY.md).  Launches of the mfma16 contract issue neither, so they do not arm it -- regular launches no more than the
-    // rolling launch: on a shared or partly occupied GPU a harmless displacement would otherwise fail the caller's prefill with
-    // FASTKV_EPLACEMENT and drop the process to the no-wait kernels for good.
+    // The placement check (fastkv_placement_violations) guards the compute-unit pairing of the REGULAR launches (two workgroups of one
+    // head on a compute unit, kept in step by the hand-offs).  The hazard the pairing fences off needs the fp32-fma-chain contract's
+    // matrix phase (K from LDS into fp16 MFMAs, those into fp32 MFMAs) beside packed-fp32 arithmetic (docs/HISTORY.md), and the library
+    // holds no packed-fp32 instruction: launches of the fma chain count into the word the placement policy acts on (fail safe by
+    // default, as since round 4); launches of the mfma16 contract issue neither half of the hazard and count into a word that is
+    // only ever COUNTED (round 6, ADVICE r05: armed, never raised -- a harmless displacement on a shared GPU does not fail a prefill,
+    // and `placement_violations: 0` in a bench line is a measurement again).  The ROLLING launch arms nothing under either contract:
+    // its entries share compute units out of step by design, which the soaks of round 6 (profiles/r06_soak_*.log) stand for.
     uint64_t *cu_slots = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8));
     uint64_t *done = reinterpret_cast<uint64_t *>(ws + L.off_fpart + (size_t)FUSED_MAX_WGS * (32 * 24 + 2 * 4 * 31 * 8) + (size_t)FUSED_CU_SLOTS * 8);   // rolling launch: one "done" granule per (unit, span) of a record area
+    if (exp_env_int("FASTKV_FUSED_NO_HANDOVER", 0)) done = nullptr;      // (experiments builds: the rolling launch as round 5 had it, to show what the hand-over is for)
     if (FKH_OLD_NUMBERING) cu_slots = nullptr;                   // (hunt builds: other units share compute units by design, every workgroup would report)
     uint64_t *chain = reinterpret_cast<uint64_t *>(ws + L.off_fchain);   // [unit span][positions of a span] head-sum granules (VH > 1)
     // Two fused launches should not overlap on a GPU (each needs ALL its workgroups resident; overlapping ones would wait
@@ -1310,7 +1328,7 @@ bool launch_score_fused(const fastkv_problem &p, const Layout &L, const void *q,
             decltype(fl)::launch(grid, st, (const uint16_t *)k, ks[0], ks[1], ks[2], (const uint16_t *)q, qs[0], qs[1], qs[2], p.H, p.Hkv,
                                  p.S, sqrtD, 1.0f / sqrtD, edges, pmax, psum, ctrl, zero, L.zero_words, p.kernel, p.pooling, c_out,
                                  c_row_stride, all_idx, all_keys, all_key_stride, VH, chain, host_flag, spin_ticks, pt ? pt->q : nullptr,
-                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), f16 ? (uint64_t *)nullptr : cu_slots, done, 0, 0, 1, 0);
+                                 pt ? pt->k : nullptr, HV, b0, p.B * p.Hkv, sub, device_cus(), placement_buffer(), cu_slots, done, 0, 0, 1, 0);
         });
         *err = hipGetLastError();
         b0 += take;

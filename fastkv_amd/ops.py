@@ -81,7 +81,7 @@ def set_no_wait_mode(on: bool) -> bool:
 
 # contraction engines.  Two arithmetic CONTRACTS (oracle/fastkv_oracle.c, "the contraction"): the fp32 fma chain ("valu", "mfma": the
 # fp32 matrix instruction; bit-identical) and "mfma16" (the gfx950 fp16 matrix instruction on the fp16 operands themselves).  "auto" =
-# the library's default contract (FASTKV_CONTRACTION=mfma16 | fmaf; mfma16 unless set)
+# the library's default contract (FASTKV_CONTRACTION=fmaf | mfma16; fmaf unless set)
 ENGINE = {"auto": 0, "valu": 1, "mfma": 2, "mfma16": 3}
 _engine = ENGINE[os.environ.get("FASTKV_SCORE_ENGINE", "auto")]
 

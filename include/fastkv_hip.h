@@ -61,14 +61,18 @@ typedef struct fastkv_problem {
     int32_t capacity;  /* max_capacity_prompt after the proportional rule (utils.py:86-87); window < capacity <= S */
     int32_t tsp_len;   /* 0 = no TSP on this layer; else window < tsp_len < S (utils.py:126) */
     int32_t order;     /* FASTKV_ORDER_* for the K/V rows */
-    int32_t reserved;  /* 0 = the library's default contraction contract (FASTKV_CONTRACTION=mfma16 | fmaf at load; mfma16 unless
+    int32_t reserved;  /* 0 = the library's default contraction contract (FASTKV_CONTRACTION=fmaf | mfma16 at load; fmaf unless
                           set).  Bits 0-1 force an engine of the scoring kernels.  Two arithmetic CONTRACTS for the fp16 matmul
-                          of utils.py:94, whose accumulation order the reference leaves open (both restated bit for bit by
-                          oracle/fastkv_oracle.c, tested against each other's oracle):
-                            3 = "mfma16": v_mfma_f32_32x32x16_f16 on the fp16 operands, chained over ascending chunks of 16
-                                dims (the default; 16x the matrix rate; tools/probes/README.md has the instruction's arithmetic)
+                          of utils.py:94 (both restated bit for bit by oracle/fastkv_oracle.c, tested against each other's oracle):
                             1 = vector ALU, 2 = FP32 matrix pipe (v_mfma_f32_32x32x2_f32): "fmaf", the fp32 fma chain in
-                                ascending head-dim order; the two produce the same bits */
+                                ascending head-dim order; the two produce the same bits.  THE DEFAULT since round 6: it IS the
+                                reference's matmul -- torch's CPU kernel accumulates exactly so: 0 of 1.0e9 fp16 logits differ
+                                over the 120-case sweep (tests/test_oracle_golden.py) -- and what then remains between this
+                                library and the reference is the softmax denominator's summation order alone
+                            3 = "mfma16": v_mfma_f32_32x32x16_f16 on the fp16 operands, chained over ascending chunks of 16
+                                dims (the opt-in fast mode: 16x the matrix rate, 0.58 instead of 0.78 ms per 32-layer step; 1e-3
+                                of the logits one fp16 ulp away from the reference's; tools/probes/README.md has the
+                                instruction's arithmetic) */
 } fastkv_problem;
 
 /* Bytes of scratch `fastkv_update_kv_f16` / `fastkv_score_f16` need for this problem (>= ~23 MiB: the hand-off records of the fused
@@ -114,15 +118,21 @@ int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
  * Host-only (reads two words of pinned memory); call it after synchronising to learn about the calls just completed. */
 int fastkv_last_status(void);
 /*
- * The fused scoring kernel gives the two workgroups that share a compute unit adjacent spans of one (batch row, kv head): which two
- * share is the GPU's dispatch order on an idle device, an observation and not a promise (docs/HISTORY.md on why the kernel
- * cares: a workgroup that ran a phase ahead of a DIFFERENT unit's workgroup on its compute unit was measured to produce wrong sums
- * now and then -- under the fp32-fma-chain contract (FASTKV_CONTRACTION=fmaf), whose matrix phase is one half of that hazard; launches of
- * the default "mfma16" contract issue neither half and do not arm the check).  Every launch of the fma-chain contract checks it: a workgroup that finds another unit's workgroup of the same launch on its compute unit
- * is counted in pinned host memory.  Returns the count since the last reset (host only, no synchronisation; complete once the
- * stream has been synchronised).  0 on an idle GPU (the tests assert it); > 0 beside foreign kernels, or when a launch could not
- * become resident all at once -- results were bit-exact in every such test, but the guarantee of the pairing is gone: a shared GPU
- * should run FASTKV_FUSED=0.  The count is a running total (reported violations included) until `reset`.
+ * A REGULAR launch of the fused scoring kernel (a call of one or two 32k layers; more entries of shorter ones) gives the two workgroups
+ * that share a compute unit adjacent spans of one (batch row, kv head): which two share is the GPU's dispatch order on an idle device,
+ * an observation and not a promise (docs/HISTORY.md on why the kernel cares: in round 3 a workgroup that ran a phase ahead of a
+ * DIFFERENT unit's workgroup on its compute unit produced wrong sums now and then -- narrowed down to packed-fp32 instructions beside
+ * the fp32-fma-chain contract's matrix phase; the library has been compiled WITHOUT packed-fp32 instructions since, which took the
+ * strongest reproducer from 40 % wrong launches to 0 of 600).  Every regular launch checks the pairing: a workgroup that finds another
+ * unit's workgroup of the same launch on its compute unit is counted in pinned host memory.  Launches of the fma-chain contract count
+ * into the word the placement policy below acts on; launches of the "mfma16" contract, which issue neither half of that hazard, are
+ * counted and never reported.  The ROLLING launch (fastkv_set_fused_rolling) runs its entries on shared compute units OUT OF STEP by
+ * design, under both contracts, and arms nothing: that this is safe without packed-fp32 instructions is what the soaks of round 6
+ * stand for (profiles/r06_soak_*.log: 240,000 + 200,000 random groups against the in-step launches, bit for bit).
+ * Returns the count since the last reset (host only, no synchronisation; complete once the stream has been synchronised).  0 on an
+ * idle GPU (the tests assert it); > 0 beside foreign kernels, or when a launch could not become resident all at once -- results were
+ * bit-exact in every such test, but the guarantee of the pairing is gone: a shared GPU should run FASTKV_FUSED=0.  The count is a
+ * running total (reported violations included) until `reset`.
  */
 int fastkv_placement_violations(int reset);
 /*
@@ -141,8 +151,12 @@ int fastkv_set_placement_policy(int policy);
 int fastkv_set_no_wait_mode(int on);
 /* The rolling launch of the fused scoring kernel (csrc/fused.hip launch_score_fused): a call with more entries than the chip holds
  * at a time (8k - 32k token layers: 8 - 2 of them) scores ALL of them in one launch whose entries follow each other over the chip
- * out of step; a layer of more than 64k tokens (no regular fused launch holds it) is taken in parts of its KV heads the same way.  Same results bit for bit; on by default (FASTKV_FUSED_ROLLING=0 turns it off for the
- * process); returns the previous setting.  For A/B measurements and tests. */
+ * out of step; a layer of more than 64k tokens (no regular fused launch holds it) is taken in parts of its KV heads the same way.
+ * Both contraction contracts (round 6; FASTKV_FUSED_ROLLING_FMAF=0 keeps the fma chain on the in-step launches).  The hand-off
+ * record areas rotate over twice the entries the chip holds, and an area changes hands EXPLICITLY: a workgroup publishes into it only
+ * when every workgroup of its unit in the area's previous entry has left a "done" record -- an entry that is slower than its successors
+ * (the fma chain's NaN redo, a compute unit held by a foreign kernel) keeps its records until it has read them.  Same results bit
+ * for bit; on by default (FASTKV_FUSED_ROLLING=0 turns it off for the process); returns the previous setting. */
 int fastkv_set_fused_rolling(int on);
 int fastkv_no_wait_mode(void);
 

@@ -131,7 +131,7 @@ static inline float fix_to_f32(uint64_t s)
  *
  * utils.py:103 is torch's CPU softmax in fp32 (`softmax(x, dim=-1, dtype=torch.float32)`), rounded to fp16.  Its arithmetic on the
  * AVX-512 build of torch 2.10 (aten/src/ATen/native/cpu/SoftMaxKernel.cpp vec_softmax_lastdim; established in round 6 by running
- * the installed torch against this restatement: 0 of 11 M fp32 outputs differ, rows of 777 .. 100,003 elements,
+ * the installed torch against this restatement: 0 of 8.8 M fp32 outputs differ, rows of 777 .. 100,003 elements,
  * tests/golden/make_golden.py `softmax_probe`):
  *     m = max_j x_j;   e_j = Sleef_expf16_u10(x_j - m)  (at::vec::Vectorized<float>::exp);
  *     sum = 16 lane-wise SEQUENTIAL fp32 sums (lane l adds elements l, l + 16, l + 32, ...; a ragged tail goes to lanes 0 .. r-1),

@@ -21,13 +21,14 @@ def golden_dir():
 @pytest.fixture(autouse=True)
 def _contracts_back_to_default():
     """The oracle's contraction contract and the HIP library's engine are process-wide switches: whatever a test selected, the next
-    test starts from the defaults (both sides: FASTKV_CONTRACTION, mfma16 unless set)."""
+    test starts from the defaults (both sides: FASTKV_CONTRACTION, fmaf unless set)."""
     yield
     import sys as _sys
     orc = _sys.modules.get("oracle.fastkv_oracle")
     if orc is not None and orc._lib is not None:
         from helpers import default_contraction
         orc.set_contraction(default_contraction())
+        orc.set_softmax("contract")                              # (the reference-order modes are for the stage-level pins only)
     ops = _sys.modules.get("fastkv_amd.ops")
     if ops is not None:
         ops._engine = ops.ENGINE[os.environ.get("FASTKV_SCORE_ENGINE", "auto")]

@@ -21,7 +21,8 @@ def run_stress(N=200, seed=12345, entries_p=0.25, all_entries=False, only=-1, re
     dev = torch.device("cuda:0")
     violations0 = int(_load().fastkv_placement_violations(0))          # (a running count of the process)
     import os
-    default_contraction = "fmaf" if os.environ.get("FASTKV_CONTRACTION", "mfma16")[:1] in ("f", "F") else "mfma16"
+    from helpers import default_contraction as _dc
+    default_contraction = _dc()                                         # (what "auto" means on both sides of THIS process)
     t0 = time.time()
     st = dict(cases=0, mismatches=0, entries_runs=0, entries_refused=0, max_entry_rows=0, special=0, engines=set())
     main_stream = torch.cuda.current_stream()

@@ -356,6 +356,17 @@ def test_arithmetic_contract_on_gpu(dev):
     wf = torch.tensor([Lo.fastkv_oracle_fix_to_f32(int(v)) for v in w64.tolist()])
     assert torch.equal(bits(g), bits(wf))
     assert torch.equal(run(10, e)[1], w64)
+    # ... and the four-operation conversion of the fused kernel's phase B (round 6: hi = RNE(e * 2^20), signed lo, both by the fp32
+    # adder against a magic constant): the same 64-bit value RNE(e * 2^40) -- random values, the exponentials themselves, and every
+    # kind of tie (k + 1/2) * 2^-40 and (k + 1/2) * 2^-20 the fp32 grid holds near the ranges where the roundings happen
+    ties = torch.cat([(torch.arange(0, 4096, dtype=torch.float64) + 0.5) * 2.0 ** -40, (torch.arange(0, 4096, dtype=torch.float64) + 0.5) * 2.0 ** -20,
+                      (torch.arange(0, 4096, dtype=torch.float64) * 2 + 1) * 2.0 ** -41 + 2.0 ** -20,
+                      1.0 - (torch.arange(0, 4096, dtype=torch.float64) + 0.5) * 2.0 ** -24]).float()
+    ee = torch.cat([e, ties, want[torch.isfinite(want)][:60000], torch.tensor([1.6e-38, 2.0 ** -42, 3 * 2.0 ** -42, 0.5, 0.9999999])])
+    if ee.numel() % 2:
+        ee = torch.cat([ee, ee[:1]])
+    w64b = torch.tensor([Lo.fastkv_oracle_exp_to_fix(float(v)) for v in ee.tolist()], dtype=torch.int64)
+    assert torch.equal(run(14, ee)[1], w64b)
     big = torch.randint(0, 2 ** 62, (50000,), generator=gen, dtype=torch.int64)
     hi, lo = (big >> 32).to(torch.int32).view(torch.float32), (big & 0xFFFFFFFF).to(torch.int64).to(torch.int32).view(torch.float32)
     # NaN bit patterns survive the device copy, so op 5 sees exactly `big`
@@ -725,15 +736,16 @@ def test_operator_next_to_a_kernel_that_holds_half_the_chip(dev):
     """A long-running kernel on another stream holds half of the compute units while the operator runs (32k shape: the fused
     scoring kernel's 512 workgroups and the split selection wait for partners that cannot become resident until the other
     kernel ends).  The launch is delayed, not broken: same bits as the oracle, no report."""
-    # The placement check belongs to the fp32-fma-chain contract (the hazard it fences off needs that contract's matrix phase:
-    # include/fastkv_hip.h fastkv_placement_violations): those launches count.  Launches of the default mfma16 contract do not arm it
-    # (ADVICE r04): same delay, same bits, nothing counted and nothing reported under the DEFAULT policy.
+    # The placement policy belongs to the fp32-fma-chain contract (the hazard the pairing fences off needs that contract's matrix phase:
+    # include/fastkv_hip.h fastkv_placement_violations): what those launches count is acted upon.  Launches of the mfma16 contract
+    # COUNT as well (round 6, ADVICE r05: the check is armed, so a 0 is a measurement) and nothing ever acts on their count: same
+    # delay, same bits, violations counted, nothing reported and no switch of kernels under the DEFAULT policy.
     r = _child("HOLD_MS = 300\nRESET = 1\n" + _RESIDENCY_CHILD +
                "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nassert viol > 0, viol\nprint('child ok')\n",
                {"FASTKV_STRICT_PLACEMENT": "0", "FASTKV_CONTRACTION": "fmaf"})
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     r = _child("HOLD_MS = 300\nRESET = 0\n" + _RESIDENCY_CHILD +
-               "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nassert viol == 0, viol\n"
+               "assert same(out) and L.fastkv_last_status() == 0\nassert dt > 150, dt\nassert viol > 0, viol\n"
                "assert same(run()) and L.fastkv_last_status() == 0 and not ops.no_wait_mode()\nprint('child ok')\n",
                {"FASTKV_CONTRACTION": "mfma16"})
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -50,4 +50,4 @@ while time.time() - t0 < budget_s:
         print("REPORTED", it, repr(ex)[:160], flush=True)
     it += 1
 torch.cuda.synchronize()
-print(f"{it} calls in {time.time() - t0:.0f} s, {squeezed} with placement violations, {bad} differing outputs; contraction {os.environ.get('FASTKV_CONTRACTION', 'mfma16')}")
+print(f"{it} calls in {time.time() - t0:.0f} s, {squeezed} with placement violations, {bad} differing outputs; contraction {os.environ.get('FASTKV_CONTRACTION', 'fmaf')}")

@@ -48,8 +48,17 @@ while time.time() - t0 < budget_s:
         if rolling and rng.random() < 0.25:                      # a foreign kernel takes 16-96 compute units for a few hundred microseconds
             assert L.fastkv_debug_occupy(rng.choice([16, 48, 96]), 128 * 1024, rng.choice([200, 600, 1500]), side.cuda_stream) == 0
             held += 1
-        outs[rolling] = ops.update_kv(q, k, v, W, ks, pooling, cap, tsp, order, return_indices=True, return_scores=True)
-        torch.cuda.current_stream().synchronize()
+        try:
+            outs[rolling] = ops.update_kv(q, k, v, W, ks, pooling, cap, tsp, order, return_indices=True, return_scores=True)
+            torch.cuda.current_stream().synchronize()
+            raise_if_aborted()
+        except Exception as ex:   # noqa: BLE001 -- a REPORTED launch (FASTKV_EABORTED / FASTKV_EPLACEMENT): say which group, go on with the fused kernels
+            bad += 1
+            print("REPORTED", dict(it=it, rolling=rolling), repr(ex)[:160], "groups:", history[-3:], flush=True)
+            torch.cuda.synchronize()
+            ops.set_no_wait_mode(False)
+            outs[rolling] = ops.update_kv(q, k, v, W, ks, pooling, cap, tsp, order, return_indices=True, return_scores=True)
+            torch.cuda.current_stream().synchronize()
     for t, ix, val in saved:
         t[ix] = val
     same = True
