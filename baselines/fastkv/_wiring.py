@@ -304,10 +304,15 @@ def decoderlayer_forward_fastkv(self, hidden_states, attention_mask=None, positi
         hidden_states = sp_model.tsp_assemble(hidden_states, tsp_idx, fastkv_sp)
         fastkv_sp.reduced = True
     elif self.self_attn.kv_cluster.tsp_layer and tsp_idx is not None:
-        self.new_position_ids = torch.gather(position_ids, dim=1, index=tsp_idx)
-        if hidden_states.is_cuda:
+        if hidden_states.is_cuda and position_ids.is_cuda and position_ids.dtype == torch.int64 and position_ids.dim() == 2 \
+                and position_ids.stride(1) == 1 and position_ids.shape[0] in (1, hidden_states.shape[0]):
+            # llama_model.py:254 and :255-257 in one HIP launch (clamped indices: the index tensor of a reported call cannot fault)
+            hidden_states, self.new_position_ids = ops.tsp_propagate(hidden_states.contiguous(), position_ids, tsp_idx)
+        elif hidden_states.is_cuda:
+            self.new_position_ids = torch.gather(position_ids, dim=1, index=tsp_idx)
             hidden_states = ops.gather_rows(hidden_states.contiguous(), tsp_idx)          # HIP row gather
         else:
+            self.new_position_ids = torch.gather(position_ids, dim=1, index=tsp_idx)
             hidden_states = torch.gather(hidden_states, 1, tsp_idx.unsqueeze(-1).expand(-1, -1, hidden_states.size(2)))
     else:
         self.new_position_ids = None

@@ -128,14 +128,12 @@ class HotPathPrefill:
                 for j, kr, vr in ready:
                     cache[j] = (kr, vr)
                 if tsp is not None:
-                    hidden = ops.gather_rows(self.hidden, tsp)               # llama_model.py:255-257
-                    _pos = torch.gather(self.position_ids, 1, tsp)           # llama_model.py:254 (16 KiB)
+                    hidden, _pos = ops.tsp_propagate(self.hidden, self.position_ids, tsp)     # llama_model.py:254-257, one launch (as the wiring)
                 continue
             ko, vo, tsp = cl.update_kv(k, q, v, None, G, i)
             cache[i] = (ko, vo)
             if cl.tsp_layer and tsp is not None:
-                hidden = ops.gather_rows(self.hidden, tsp)                   # llama_model.py:255-257
-                _pos = torch.gather(self.position_ids, 1, tsp)               # llama_model.py:254 (16 KiB)
+                hidden, _pos = ops.tsp_propagate(self.hidden, self.position_ids, tsp)         # llama_model.py:254-257, one launch (as the wiring)
         if defer is not None:
             for i, ko, vo in defer.flush():
                 cache[i] = (ko, vo)

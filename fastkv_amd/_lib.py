@@ -36,7 +36,7 @@ class SPWindow(ctypes.Structure):
 
 
 EXPORTS = ["fastkv_workspace_bytes", "fastkv_workspace_init", "fastkv_update_kv_f16", "fastkv_update_kv_strided_f16", "fastkv_score_f16", "fastkv_select_f16",
-           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_compact_ranked_f16", "fastkv_gather_rows", "fastkv_head_sum_f16", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
+           "fastkv_select_workspace_bytes", "fastkv_compact_f16", "fastkv_compact_ranked_f16", "fastkv_gather_rows", "fastkv_tsp_propagate", "fastkv_head_sum_f16", "fastkv_sp_workspace_bytes", "fastkv_sp_logits_f16", "fastkv_sp_rowmax_f16", "fastkv_sp_rowsum_f16",
            "fastkv_sp_scores_f16", "fastkv_sp_pack_f16", "fastkv_sp_unpack_f16", "fastkv_sp_pick",
            "fastkv_sp_compact_f16", "fastkv_decode_workspace_bytes", "fastkv_decode_append_f16", "fastkv_decode_attention_f16",
            "fastkv_decode_rmsnorm_f16", "fastkv_decode_rope_f16", "fastkv_decode_silu_mul_f16", "fastkv_decode_greedy_f16", "fastkv_decode_rotary_f16", "fastkv_decode_gemv_f16", "fastkv_update_kv_ptrs_f16", "fastkv_fused_entries_f16", "fastkv_pool_f16", "fastkv_decode_step_attention_f16", "fastkv_debug_contract", "fastkv_debug_mfma16", "fastkv_debug_granule_areas", "fastkv_debug_occupy", "fastkv_debug_fused_placement", "fastkv_placement_violations", "fastkv_set_placement_policy", "fastkv_set_no_wait_mode", "fastkv_set_fused_rolling", "fastkv_no_wait_mode", "fastkv_last_status", "fastkv_profile_enable",
@@ -81,6 +81,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     L.fastkv_compact_ranked_f16.restype = ci
     L.fastkv_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp]
     L.fastkv_gather_rows.restype = ci
+    L.fastkv_tsp_propagate.argtypes = [vp, i64, i64, vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp]
+    L.fastkv_tsp_propagate.restype = ci
     wp = ctypes.POINTER(SPWindow)
     L.fastkv_sp_workspace_bytes.argtypes = [pp]
     L.fastkv_sp_workspace_bytes.restype = sz

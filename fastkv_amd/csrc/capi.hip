@@ -434,6 +434,21 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
     return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
 }
 
+int fastkv_tsp_propagate(const void *hidden, int64_t hidden_batch_stride_bytes, int64_t hidden_row_stride_bytes, const int64_t *position_ids,
+                         int64_t pos_batch_stride, const int64_t *tsp_idx, int64_t idx_batch_stride, int64_t batches, int64_t rows_out,
+                         int64_t rows_in, int64_t row_bytes, void *hidden_out, int64_t *position_ids_out, void *stream)
+{
+    if (!hidden || !position_ids || !tsp_idx || !hidden_out || !position_ids_out || batches < 0 || rows_out < 0 || rows_in < 1 ||
+        row_bytes < 16 || (row_bytes & 15))
+        return FASTKV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(hidden) & 15) || (reinterpret_cast<uintptr_t>(hidden_out) & 15) || (hidden_row_stride_bytes & 15) ||
+        (hidden_batch_stride_bytes & 15))
+        return FASTKV_EINVAL;
+    hipError_t e = launch_gather_rows(hidden, hidden_batch_stride_bytes, hidden_row_stride_bytes, tsp_idx, idx_batch_stride, batches, rows_out,
+                                      rows_in, row_bytes, hidden_out, (hipStream_t)stream, position_ids, pos_batch_stride, position_ids_out);
+    return e == hipSuccess ? FASTKV_OK : FASTKV_ELAUNCH;
+}
+
 int fastkv_pool_f16(const void *in, int64_t rows, int64_t in_row_stride, int64_t n, int32_t kernel, int32_t pooling, void *out,
                     int64_t out_row_stride, void *stream)
 {

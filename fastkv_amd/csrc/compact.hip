@@ -306,10 +306,13 @@ hipError_t launch_winner_keys(const uint16_t *scores, int64_t row_stride, int64_
 
 // Generic row gather, rows of `row_bytes` (multiple of 16).  `lpr` lanes (power of two <= 256) cooperate on a row,
 // 256/lpr rows per workgroup, one 16-B piece per lane per iteration; grid (ceil(rows_out/rpb), batches).
+// (pos_in / pos_out, optional: the position ids ride along -- pos_out[b, r] = pos_in[b, idx[b, r]] by the first lane of a row's group:
+// llama_model.py:254 and :255-257 in ONE launch, round 6)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *__restrict__ src, int64_t sbs, int64_t srs,
                                                           const int64_t *__restrict__ idx, int64_t ibs, int64_t rows_out,
                                                           int64_t rows_in, int64_t row_bytes, int lpr_shift,
-                                                          unsigned char *__restrict__ dst, uint32_t *__restrict__ bounds_flag)
+                                                          unsigned char *__restrict__ dst, uint32_t *__restrict__ bounds_flag,
+                                                          const int64_t *__restrict__ pos_in, int64_t pbs, int64_t *__restrict__ pos_out)
 {
     const int lpr = 1 << lpr_shift;
     const int sub = threadIdx.x & (lpr - 1);
@@ -319,6 +322,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *_
     int64_t s = idx[b * ibs + r];
     if (bounds_flag && (s < 0 || s >= rows_in)) __hip_atomic_store(bounds_flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // FASTKV_EBOUNDS
     s = s < 0 ? 0 : (s >= rows_in ? rows_in - 1 : s);          // out-of-range indices read a clamped row (never faults)
+    if (pos_out && sub == 0) pos_out[b * rows_out + r] = pos_in[b * pbs + s];
     const unsigned char *sp = src + b * sbs + s * srs;
     unsigned char *dp = dst + (b * rows_out + r) * row_bytes;
     const int64_t pieces = row_bytes >> 4;
@@ -342,7 +346,8 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char *_
 }
 
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
-                              int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st)
+                              int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st, const int64_t *pos_in,
+                              int64_t pbs, int64_t *pos_out)
 {
     if (rows_out == 0 || batches == 0) return hipSuccess;
     int lpr_shift = 0;
@@ -353,7 +358,7 @@ hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const i
     dim3 grid((unsigned)((rows_out + rpb - 1) / rpb), (unsigned)batches);
     ProfScope ps_(K_GATHER, st);
     hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, st, (const unsigned char *)src, sbs, srs, idx, ibs, rows_out,
-                       rows_in, row_bytes, lpr_shift, (unsigned char *)dst, debug_bounds() ? abort_flag_device() : nullptr);
+                       rows_in, row_bytes, lpr_shift, (unsigned char *)dst, debug_bounds() ? abort_flag_device() : nullptr, pos_in, pbs, pos_out);
     return hipGetLastError();
 }
 

@@ -181,6 +181,7 @@ hipError_t launch_compact(const fastkv_problem &p, const void *k, const int64_t 
 hipError_t launch_winner_keys(const uint16_t *scores, int64_t row_stride, int64_t n, const int64_t *idx, int64_t rows, int kk,
                               uint16_t *keys, hipStream_t st);
 hipError_t launch_gather_rows(const void *src, int64_t sbs, int64_t srs, const int64_t *idx, int64_t ibs, int64_t batches,
-                              int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st);
+                              int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *dst, hipStream_t st, const int64_t *pos_in = nullptr,
+                              int64_t pos_batch_stride = 0, int64_t *pos_out = nullptr);
 
 }  // namespace fk

@@ -138,7 +138,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     // Entries 1 .. F-1 of a rolling launch (launch_score_fused; `rolling` = F, the entries the chip holds at a time) start late ON
     // PURPOSE, one K-streaming time apart: entries that begin together stay in step -- all stream K, then all do arithmetic -- and
     // gain nothing from sharing the chip.
-    if (rolling && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
+    if (rolling && !(tune & 2) && start_delay > 0 && blockIdx.y > 0 && (int)blockIdx.y < rolling) { const uint64_t t_end = wall_clock64() + (uint64_t)start_delay * blockIdx.y; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16); }
     // A KV head with G = 4*VH query heads is worked on by VH "virtual heads" of 4 query heads each (own workgroups, own
     // softmax hand-offs, the same K rows); phase D chains them: virtual head vh continues the fp32 head sum that vh - 1
     // hands over per position (utils.py:112 adds the G pooled values in head order), the last one rounds and writes.
@@ -1003,6 +1003,25 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NS - 1>;            // (== S0 when NS == 1: the second calls below are compiled out)
+    // ---- Pacing of the rolling launch (round 6; tune bit 1, experiments builds; OFF: a measured negative).  The launch is built on the
+    // idea that one entry runs phase A (matrix pipe / memory) while its partner on the compute unit runs phases B-D (vector work,
+    // hand-off latency).  Nothing enforces that: per-entry stamps (profiles/r06_stamps_rolling_fmaf.log) show the two entries of the
+    // chip only 8 us apart in a 66 us residency -- they contract together, do their vector work together and wait together.  With
+    // this switch the offset is explicit, through records that exist anyway: a workgroup of entry e starts phase A only when its
+    // unit's workgroups of entry e - 1 have PUBLISHED THEIR ROW MAXIMA (entry e - 1 was dispatched before entry e and waits for nothing
+    // of it: no deadlock; its record area cannot change hands meanwhile -- entry e - 1 + 2 F publishes only behind entry e, by this very
+    // rule).  Bit-exact (the rolling suite under both contracts), and 4 % SLOWER under the fma chain (276.5 against 265.4 us per eight
+    // layers, alternating runs), no change under mfma16: phase A alone takes 26 us, not the 15.8 us of its matrix instructions -- its own
+    // epilogue is vector work on the same lanes --, the partner's phase B then takes 23 us instead of 11 beside it, and the sum does not
+    // move: the FP32 lanes are the bottleneck whoever uses them when (profiles/r06_pacing.log).
+    if ((tune & 2) && rolling == 2 && ent >= 1) {
+        const uint32_t token_before = handoff_token(ctrl[2] + sub + (uint32_t)(ent - 1));
+        const uint64_t *pm_before = pmax + ((size_t)((ent - 1) % (2 * rolling)) * UPE + (size_t)(hvp - part_base)) * nblk * 32;
+        if (w == 0 && !wait_first_granules(pm_before, 32, nblk, token_before, lane, sp)) s_abort = 1;
+        __syncthreads();
+        if (s_abort) return false;
+    }
+    FKF_STAMP(15);
     if (tune & 1) __builtin_amdgcn_s_setprio(3);
     phaseA(S0{});
     if (tune & 1) __builtin_amdgcn_s_setprio(0);
@@ -1120,7 +1139,9 @@ template <typename F> static bool fused_dispatch(int D, int per, int nb, int ns,
     return false;
 }
 
-// switch of the rolling launch (FASTKV_FUSED_TUNE, bits; default 1): 1 = the waves of an entry run phase A (K streaming) at raised
+// switches of the rolling launch (FASTKV_FUSED_TUNE, bits, experiments builds; default 1): 2 = pacing (an entry starts phase A when the
+// entry before it has published its row maxima: see the kernel; round 6: measured 4 % SLOWER under the fma chain, no change under
+// mfma16 -- profiles/r06_pacing.log -- and left off); 1 = the waves of an entry run phase A (K streaming) at raised
 // issue priority (s_setprio 3), so that their loads / LDS commits are never queued behind the other entry's vector work -- measured in
 // round 5 at -3 ... -5 us per eight-layer launch (203.7 / 206.0 / 204.5 -> 200.7 / 201.1 / 201.7 us, alternating runs on one box)
 static int fused_tune()

@@ -295,6 +295,29 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def tsp_propagate(hidden: torch.Tensor, position_ids: torch.Tensor, tsp_idx: torch.Tensor):
+    """The decoder layer's TSP propagation (llama_model.py:252-259) in ONE launch: returns (hidden[b, tsp_idx[b]], position_ids
+    .gather(1, tsp_idx)).  `hidden` [B,S,...] with contiguous trailing dims (16-byte multiple), `position_ids` [B,S] or [1,S]
+    (broadcast over the batch) int64.  Indices outside [0, S) read a clamped row: the index tensor of a call that was REPORTED
+    (FASTKV_EABORTED) cannot fault here, where `torch.gather` would assert on the device."""
+    _require_cuda(hidden, tsp_idx)
+    assert tsp_idx.dtype == torch.int64 and tsp_idx.dim() == 2 and tsp_idx.stride(1) == 1
+    assert position_ids.dtype == torch.int64 and position_ids.dim() == 2 and position_ids.stride(1) == 1 and position_ids.is_cuda
+    B, S = hidden.shape[0], hidden.shape[1]
+    assert position_ids.shape[1] == S and position_ids.shape[0] in (1, B)
+    row_bytes = hidden[0, 0].numel() * hidden.element_size()
+    if not hidden[0, 0].is_contiguous() and hidden[0, 0].numel() > 1:
+        raise ValueError("fastkv_amd.tsp_propagate: trailing dims must be contiguous")
+    out = torch.empty((B, tsp_idx.shape[1]) + tuple(hidden.shape[2:]), dtype=hidden.dtype, device=hidden.device)
+    pos = torch.empty(B, tsp_idx.shape[1], dtype=torch.int64, device=hidden.device)
+    rc = load().fastkv_tsp_propagate(hidden.data_ptr(), hidden.stride(0) * hidden.element_size(), hidden.stride(1) * hidden.element_size(),
+                                     position_ids.data_ptr(), position_ids.stride(0) if position_ids.shape[0] == B and B > 1 else 0,
+                                     tsp_idx.data_ptr(), tsp_idx.stride(0), B, tsp_idx.shape[1], S, row_bytes, out.data_ptr(), pos.data_ptr(),
+                                     _stream())
+    check(rc, "tsp_propagate")
+    return out, pos
+
+
 # ------------------------------------------------------------------------------------------------- decode over the slab cache
 DECODE_NSPLIT = int(os.environ.get("FASTKV_DECODE_NSPLIT", "16"))
 
@@ -641,7 +664,9 @@ def update_kv_entries(qs, ks, vs, window: int, kernel_size: int, pooling: str, c
     q_back = (S_full - window) * q0.stride(2) * 2 if q_window else 0
     tab = _device_ptr_table([rows_of(qs, q_back)] + [rows_of(lst) for lst in (ks, vs, k_outs, v_outs)], dev)
     kv_idx = torch.empty(n * Bq, Hkv, capacity - window, dtype=torch.int64, device=dev) if return_indices else None
-    tsp = torch.zeros(n * Bq, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None        # (see update_kv)
+    # (empty, not zeros as in update_kv: the consumer of a grouped call's TSP index is this package's own wiring, whose propagation
+    # -- ops.tsp_propagate -- clamps its indices; the 128 KiB fill in front of the TSP group's scoring launch cost 4.8 us per prefill)
+    tsp = torch.empty(n * Bq, tsp_len, dtype=torch.int64, device=dev) if tsp_len else None
     ws = _workspace(L.fastkv_workspace_bytes(ctypes.byref(p)), dev)
     rc = L.fastkv_update_kv_ptrs_f16(ctypes.byref(p), tab[0].data_ptr(), _strides(q0), tab[1].data_ptr(), _strides(k0), tab[2].data_ptr(),
                                      _strides(v0), tab[3].data_ptr(), tab[4].data_ptr(), ostr,

@@ -266,6 +266,18 @@ int fastkv_gather_rows(const void *src, int64_t src_batch_stride_bytes, int64_t 
                        int64_t rows_in, int64_t row_bytes, void *dst, void *stream);
 
 /*
+ * The decoder layer's whole TSP propagation (llama_model.py:252-259; mistral_model.py:217-224) in ONE launch:
+ *   position_ids_out[b, r] = position_ids[b, tsp_idx[b, r]]          (:254, `position_ids.gather(1, tsp_idx)`)
+ *   hidden_out[b, r, :]    = hidden[b, tsp_idx[b, r], :]             (:255-257)
+ * position_ids [batches, rows_in] int64 (pos_batch_stride in elements), outputs contiguous.  Indices outside [0, rows_in) read a
+ * clamped row, as in fastkv_gather_rows -- so the TSP index tensor of a call that was REPORTED (FASTKV_EABORTED) cannot fault here.
+ */
+int fastkv_tsp_propagate(const void *hidden, int64_t hidden_batch_stride_bytes, int64_t hidden_row_stride_bytes,
+                         const int64_t *position_ids, int64_t pos_batch_stride, const int64_t *tsp_idx, int64_t idx_batch_stride,
+                         int64_t batches, int64_t rows_out, int64_t rows_in, int64_t row_bytes, void *hidden_out,
+                         int64_t *position_ids_out, void *stream);
+
+/*
  * ---- Sequence-sharded building blocks (one prompt split over P GPUs on the sequence axis; fastkv_amd/dist.py) ----
  * The reference has no multi-GPU path; these stages let P ranks reproduce the single-GPU result bit for bit:
  * scores are local per position, the only global quantities are the per-row softmax max / sum (two tiny all-reduces;

@@ -114,6 +114,7 @@ def test_contract_keys_are_the_same_for_every_n_and_match_the_driver_record():
         _check_driver_record(rec, one, "synthetic, %d of %d extra key names kept" % (cap, len(extra)))
 
 
+NEW_KEYS = {5: ("placement_check",)}      # keys of the line that did not exist when the record of round <key> was written
 DRIVER_EXTRA_KEYS_CAP = 20        # the driver's record lists at most this many non-contract key NAMES, in sorted order (BENCH_r05.json)
 
 
@@ -129,8 +130,12 @@ def _check_driver_record(rec, one, what):
     extra = sorted(extra) if isinstance(extra, (list, tuple, dict)) else []
     truncated = len(extra) >= DRIVER_EXTRA_KEYS_CAP or (extra and len(extra) < len([k for k in one if k not in parsed]))
     visible = (lambda k: k <= extra[-1]) if (truncated and extra) else (lambda k: True)
-    missing = [k for k in one if k not in parsed and k not in extra and visible(k)]
+    # (a record is of the round that WROTE it: a key this round added to the line -- NEW_KEYS -- cannot be in an older record)
+    missing = [k for k in one if k not in parsed and k not in extra and visible(k) and k not in NEW_KEYS.get(rec.get("n"), ())]
     assert not missing, (what, missing)
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config")
+    assert all(k in parsed for k in contract), (what, [k for k in contract if k not in parsed])
     assert parsed["metric"] == one["metric"] and parsed["unit"] == one["unit"]
     w = parsed["config"]["workload"]                                          # (the driver keeps the first ~120 characters of a string)
     assert one["config"]["workload"].startswith(w[:100]) and len(w) >= 100

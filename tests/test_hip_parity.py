@@ -156,6 +156,26 @@ def test_gather_rows_tsp_propagation(dev):
     assert torch.equal(out, torch.gather(h, 1, idx[..., None].expand(-1, -1, 4096)))
 
 
+def test_tsp_propagate_is_both_gathers_of_the_decoder_layer(dev):
+    """fastkv_tsp_propagate = `position_ids.gather(1, tsp_idx)` + `hidden.gather(1, tsp_idx[..., None].expand(...))` of
+    llama_model.py:254-257 in one launch: both outputs against torch, batched and broadcast position ids, odd hidden sizes; and an
+    index outside the prompt reads the clamped row instead of faulting (what the index tensor of a REPORTED call may hold)."""
+    from fastkv_amd import ops
+    for B, S, hid, k in ((2, 700, 4096, 333), (1, 32768, 4096, 2048), (3, 100, 64, 100), (1, 9, 8, 4)):
+        h = torch.randn(B, S, hid, dtype=torch.float16, device=dev)
+        idx = torch.stack([torch.sort(torch.randperm(S, device=dev)[:k]).values for _ in range(B)])
+        for pos in (torch.arange(S, device=dev)[None].expand(B, -1), (torch.arange(S, device=dev) * 3 + 5)[None].repeat(B, 1), torch.arange(S, device=dev)[None]):
+            if pos.shape[0] != B and B > 1:
+                continue                                                   # (torch.gather itself needs the batch to match)
+            out, npos = ops.tsp_propagate(h, pos, idx)
+            assert torch.equal(out, torch.gather(h, 1, idx[..., None].expand(-1, -1, hid)))
+            assert torch.equal(npos, torch.gather(pos, 1, idx)) and npos.is_contiguous() and npos.shape == idx.shape
+    h = torch.randn(1, 64, 4096, dtype=torch.float16, device=dev)
+    out, npos = ops.tsp_propagate(h, torch.arange(64, device=dev)[None], torch.tensor([[3, 64, -5, 10 ** 12]], device=dev))
+    assert torch.equal(out[0, 0], h[0, 3]) and torch.equal(out[0, 1], h[0, 63]) and torch.equal(out[0, 2], h[0, 0]) and torch.equal(out[0, 3], h[0, 63])
+    assert npos.tolist() == [[3, 63, 0, 63]]
+
+
 def test_cluster_dropin_matches_oracle_cluster(dev):
     """FastKVCluster.update_kv end to end incl. host logic: early-out identity, proportional mode, TSP guard."""
     from fastkv_amd import FastKVCluster

@@ -9,7 +9,7 @@ from fastkv_amd import ops, _lib
 dev = torch.device('cuda:0')
 H, Hkv, D, W, S, B = 32, 8, 128, 8, 32768, int(sys.argv[1]) if len(sys.argv) > 1 else 4
 lib = _lib.load()
-slots = [(0, "start"), (1, "phase A end"), (3, "max known"), (4, "B end (published)"), (7, "sum known"), (8, "C end (halo out)"), (11, "halo in"), (12, "D end")]
+slots = [(0, "start"), (15, "phase A begins (paced)"), (1, "phase A end"), (3, "max known"), (4, "B end (published)"), (7, "sum known"), (8, "C end (halo out)"), (11, "halo in"), (12, "D end")]
 sets = [(torch.randn(B, S, H, D, device=dev, dtype=torch.float16).transpose(1, 2), torch.randn(B, S, Hkv, D, device=dev, dtype=torch.float16).transpose(1, 2)) for _ in range(3)]
 for i in range(9):
     ops.scores(*sets[i % 3], W, 7, 'maxpool', want_tsp=False)
