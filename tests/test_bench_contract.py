@@ -159,6 +159,28 @@ def test_the_eight_rank_rehearsal_line_survives_the_drivers_truncation():
     assert abs(line["value"] - 8 * 32768 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
 
 
+def test_roofline_object_follows_the_contract_of_the_line():
+    """bench.roofline_of_the_contract: under the fma chain (the default) the dominant launch is priced against the fp32 matrix peak --
+    algorithmic flops / the SAME HIP-event duration -- with the HBM view (and the PMC traffic) beside it; under mfma16 the HBM view is
+    the line's roofline unchanged.  Pure arithmetic: checked here so that the N > 1 path, which no box has run, cannot get it wrong."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    alg, us, n = 8 * 67174400, 265.0, 8
+    hbm = {"kernel": "k", "bound": "hbm", "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+           "frac": round(alg / (us * 1e-6) / 1e9 / 8000.0, 4), "traffic": 573000000, "traffic_static": True, "algorithmic_bytes_per_launch": alg,
+           "avg_launch_us": us, "entries_per_launch": n}
+    flops = 2.0 * 32 * 8 * 128 * 32768 * n
+    assert bench.roofline_of_the_contract(dict(hbm), "mfma16", flops) == hbm
+    r = bench.roofline_of_the_contract(dict(hbm), "fmaf", flops)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["avg_launch_us"] == us and r["traffic"] == 573000000
+    assert abs(r["achieved"] - flops / (us * 1e-6) / 1e12) < 0.01 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["hbm_view"]["bound"] == "hbm" and r["hbm_view"]["frac"] == hbm["frac"] and r["hbm_view"]["algorithmic_bytes_per_launch"] == alg
+    assert bench.roofline_of_the_contract(None, "fmaf", flops) is None
+    assert bench.default_contraction() in ("fmaf", "mfma16")
+
+
 def test_cpu_leg_reads_the_cgroup_quota(monkeypatch, tmp_path):
     import importlib
     import sys
