@@ -1025,6 +1025,7 @@ __device__ __forceinline__ bool score_fused_body(const uint16_t *__restrict__ k,
     if (tune & 1) __builtin_amdgcn_s_setprio(3);
     phaseA(S0{});
     if (tune & 1) __builtin_amdgcn_s_setprio(0);
+    if (tune & 4) __builtin_amdgcn_s_setprio(3);                 // (experiments builds: the phases behind phase A at raised priority instead)
     if (area_handover && s_abort) return false;                  // (uniform: read behind phase A's barrier)
     FKF_STAMP(1);
     if (NS == 2) phaseA(S1{});
