@@ -25,6 +25,7 @@ xcc = ((st[:, 40] >> np.uint64(32)) & np.uint64(7)).astype(np.int64); hw = (st[:
 ok = t[:, 14] > 0
 print(f"contraction {os.environ.get('FASTKV_CONTRACTION', 'fmaf (default)')}; rolling launch of {B} entries of {S} tokens; entries in the table: {sorted(set(ent[ok].tolist()))}")
 last_span = collections.Counter(); last_xcc = collections.Counter(); rows = []
+behind = []                                                      # every workgroup: its arrival at hand-off 1 behind its head's FIRST arrival (us)
 for e in sorted(set(ent[ok].tolist())):
     for u in range(Hkv):
         m = ok & (ent == e) & (unit == u)
@@ -41,6 +42,7 @@ for e in sorted(set(ent[ok].tolist())):
         pm = np.array([wg[s_]["pub_max"] for s_ in spans]) / 100.0; ps = np.array([wg[s_]["pub_sum"] for s_ in spans]) / 100.0
         stt = np.array([wg[s_]["start"] for s_ in spans]) / 100.0; pa = pm - stt
         mk = np.array([wg[s_]["max_known"] for s_ in spans]) / 100.0
+        behind.extend((pm - pm.min()).tolist())
         i_last = int(np.argmax(pm))
         last_span[spans[i_last]] += 1; last_xcc[wg[spans[i_last]]["xcc"]] += 1
         rows.append(dict(e=e, u=u, n=len(spans), spread_max=float(pm.max() - np.median(pm)), spread_sum=float(ps.max() - np.median(ps)), last_span=spans[i_last],
@@ -51,4 +53,6 @@ for r in rows:
     print(f"  e{r['e']} u{r['u']} ({r['n']} wgs): +{r['spread_max']:5.2f} / +{r['spread_sum']:5.2f} us   last = span {r['last_span']:2d}  started {r['last_started_late']:+5.2f}  phase A {r['last_phaseA']:5.2f} vs {r['med_phaseA']:5.2f}   wait {r['wait_med']:5.2f} / {r['wait_max']:5.2f}   resident {r['resident_med']:5.1f}")
 sm = np.array([r["spread_max"] for r in rows]); lt = np.array([r["last_started_late"] for r in rows]); pa = np.array([r["last_phaseA"] - r["med_phaseA"] for r in rows])
 print(f"over {len(rows)} (entry, unit) pairs: last arrival behind the median {np.median(sm):.2f} us (max {sm.max():.2f}); of that, late START {np.median(lt):+.2f} us, longer PHASE A {np.median(pa):+.2f} us")
+hb = np.histogram(np.array(behind), bins=[0, 1, 2, 3, 4, 5, 6, 8, 10, 15, 1000])[0]
+print("histogram over all", len(behind), "workgroups -- arrival at hand-off 1 behind the head's FIRST arrival, bins [0,1) [1,2) [2,3) [3,4) [4,5) [5,6) [6,8) [8,10) [10,15) [15,inf) us:", hb.tolist())
 print("span of the last arrival:", dict(sorted(last_span.items())), " XCD of the last arrival:", dict(sorted(last_xcc.items())))
