@@ -159,6 +159,30 @@ def test_the_eight_rank_rehearsal_line_survives_the_drivers_truncation():
     assert abs(line["value"] - 8 * 32768 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
 
 
+def test_the_full_line_fits_the_drivers_key_list():
+    """bench.nest_extras: the N = 1 line with every extra the default run adds keeps its top-level key count inside the contract keys +
+    the driver's 20 names, and what BASELINE.json and the verdicts read stays on top."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    line = bench.contract_line(1, 20, 5, 0.77, "fmaf", 1, "none", 0, True, 8)
+    for k in ("roofline", "cpu_baseline", "kernels", "fp32_pipe_view", "roofline_pair_launch", "roofline_one_layer_launch", "layer_by_layer", "hold_2",
+              "deferred_all_layers", "kv_order_index", "compact", "other_contract", "kv_compact_GBps", "kv_compact_frac", "kv_compact_note",
+              "step_ms_by_contract", "cpu_ms_by_contract", "published_recipe", "ttft", "ttft_ms", "rccl_one_rank", "no_wait_kernels"):
+        line[k] = {"x": 1}
+    line = bench.nest_extras(line)
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline")
+    extra = sorted(k for k in line if k not in contract)
+    assert len(extra) <= bench.DRIVER_EXTRA_KEYS_CAP, (len(extra), extra)
+    for k in ("step_ms_by_contract", "ttft_ms", "kv_compact_GBps", "kv_compact_frac", "kernels", "placement_violations", "placement_check", "contraction"):
+        assert k in line, k
+    assert set(line["schedules"]) == {"layer_by_layer", "hold_2", "deferred_all_layers", "kv_order_index", "published_recipe"}
+    assert set(line["roofline_other_launches"]) == {"one_layer", "pair", "matrix_pipe_view"} and "note" in line["compact"]
+    assert "contraction" in line["config"] and line["config"]["contraction"].startswith("fmaf")
+
+
 def test_roofline_object_follows_the_contract_of_the_line():
     """bench.roofline_of_the_contract: under the fma chain (the default) the dominant launch is priced against the fp32 matrix peak --
     algorithmic flops / the SAME HIP-event duration -- with the HBM view (and the PMC traffic) beside it; under mfma16 the HBM view is
