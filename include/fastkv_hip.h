@@ -108,7 +108,8 @@ size_t fastkv_workspace_bytes(const fastkv_problem *p);
  *     taken under a lock that also covers the enqueue), so two such launches of one process never overlap;
  *   - processes that share a GPU, or graphs replayed concurrently on several streams, should set FASTKV_FUSED=0: the
  *     library then runs without ANY in-launch wait (three-kernel scoring; the split selection counts the row in every
- *     chunk instead of exchanging counters) at 2.08 ms instead of 1.50 ms per 32-layer step; if they do not, overlapping
+ *     chunk instead of exchanging counters) at 2.02 ms instead of 0.77 ms per 32-layer step (1.79 ms against 0.57 under the mfma16
+ *     contract; round 6); if they do not, overlapping
  *     launches end in FASTKV_EABORTED.
  */
 int fastkv_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
