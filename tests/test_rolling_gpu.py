@@ -84,7 +84,11 @@ def test_a_slow_entry_keeps_its_record_area_until_it_has_left(B, S, slow):
     e + 2 F, dispatched into places the fast entries had vacated, wrote its own into the same area: the slow entry's waits ran into the
     spin limit (REPORTED as FASTKV_EABORTED, never wrong).  The hand-over of an area is explicit now ("done" granules, csrc/fused.hip):
     groups long enough for the rotation to come round while the slow entries are on the chip equal the regular launches bit for
-    bit, and nothing is reported.  (Under the mfma16 contract a NaN costs no time: the same groups, trivially.)"""
+    bit, and nothing is reported.  (Under the mfma16 contract a NaN costs no time: the same groups, trivially.)
+    Honest scope: these three groups alone did NOT provoke the report on a build without the hand-over (profiles/
+    r06_slow_entry_test_without_handover.log: 3 passed) -- whether a slow entry is overtaken by a whole rotation depends on timing; the
+    soak's seed 62 does provoke it (2 reports in 98,007 groups without the hand-over, 0 in 192,196 with it: profiles/r06_soak_fmaf_*
+    _seed62.log).  The test pins the geometry and the bit-exactness of the protocol's slow path, not the race itself."""
     from fastkv_amd import ops
     dev = torch.device("cuda:0")
     H, Hkv, D, W, cap = 32, 8, 128, 8, 2048
